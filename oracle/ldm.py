@@ -1,0 +1,522 @@
+"""fp32 PyTorch-CPU restatement of the reference's latent-diffusion hot path.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py) -- PARITY UNPINNED by the reference.
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference/vision/stablediffusionv2 unless prefixed WK/ = wukong-huahua).
+Layout is the reference's: NCHW activations, ``nn.Dense`` weights [out,in],
+``nn.Conv2d`` weights [out,in,kh,kw]; parameters are looked up in a flat dict
+keyed by the reference's parameter names.
+
+MindSpore operator semantics restated here:
+  * nn.GroupNorm(32, C, eps): biased variance over (C/32, H, W), affine gamma/beta.
+  * nn.LayerNorm([C], epsilon=1e-5): last axis.
+  * ops.GeLU: tanh approximation.
+  * ops.ResizeNearestNeighbor (align_corners=False): exact 2x pixel duplication.
+  * nn.Dropout(keep_prob=1.0): identity.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- schedule
+def make_beta_schedule(schedule="linear", n_timestep=1000, linear_start=1e-4, linear_end=2e-2):
+    """ldm/modules/diffusionmodules/util.py:172-185 -- fp32 linspace of sqrt, squared."""
+    if schedule != "linear":
+        raise ValueError(f"schedule '{schedule}' unknown.")
+    start = np.float32(linear_start ** 0.5)
+    stop = np.float32(linear_end ** 0.5)
+    lin = np.linspace(start, stop, n_timestep, dtype=np.float32)
+    return (lin ** 2).astype(np.float32)
+
+
+def register_schedule(linear_start=0.00085, linear_end=0.0120, timesteps=1000):
+    """ldm/models/diffusion/ddpm.py:111-139 (inference part), dtype fp32 ('use_fp16: False')."""
+    betas = make_beta_schedule("linear", timesteps, linear_start, linear_end)
+    alphas = 1.0 - betas
+    alphas_cumprod = np.cumprod(alphas, axis=0)
+    alphas_cumprod_prev = np.append(1.0, alphas_cumprod[:-1])
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    return {
+        "num_timesteps": int(timesteps),
+        "betas": f32(betas),
+        "alphas_cumprod": f32(alphas_cumprod),
+        "alphas_cumprod_prev": f32(alphas_cumprod_prev),
+        "sqrt_alphas_cumprod": f32(np.sqrt(alphas_cumprod)),
+        "sqrt_one_minus_alphas_cumprod": f32(np.sqrt(1.0 - alphas_cumprod)),
+    }
+
+
+def make_ddim_timesteps(num_ddim_timesteps, num_ddpm_timesteps=1000, method="uniform"):
+    """util.py:134-148."""
+    if method == "uniform":
+        c = num_ddpm_timesteps // num_ddim_timesteps
+        ts = np.asarray(list(range(0, num_ddpm_timesteps, c)), dtype=np.int64)
+    elif method == "quad":
+        ts = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * 0.8), num_ddim_timesteps)) ** 2).astype(int)
+    else:
+        raise NotImplementedError(method)
+    return ts + 1
+
+
+def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta=0.0):
+    """util.py:151-162."""
+    alphacums = np.asarray(alphacums, dtype=np.float32)
+    alphas = alphacums[ddim_timesteps]
+    alphas_prev = np.concatenate([alphacums[:1], alphacums[ddim_timesteps[:-1]]]).astype(np.float32)
+    sigmas = np.float32(eta) * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    return sigmas.astype(np.float32), alphas, alphas_prev
+
+
+def timestep_embedding(timesteps, dim, max_period=10000):
+    """util.py:111-131 (fp32; timesteps may be fractional)."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = timesteps.to(torch.float32)[:, None] * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+# ----------------------------------------------------------------------------- primitives
+def gelu_tanh(x):
+    """ops.GeLU == tanh approximation."""
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+def silu(x):
+    return x * torch.sigmoid(x)
+
+
+def group_norm(x, gamma, beta, eps, groups=32):
+    """nn.GroupNorm(32, C, eps) on NCHW: biased variance over each (C/32,H,W) slab."""
+    n, c = x.shape[:2]
+    xr = x.reshape(n, groups, -1)
+    mean = xr.mean(dim=2, keepdim=True)
+    var = ((xr - mean) ** 2).mean(dim=2, keepdim=True)
+    y = ((xr - mean) / torch.sqrt(var + eps)).reshape(x.shape)
+    shape = (1, c) + (1,) * (x.dim() - 2)
+    return y * gamma.reshape(shape) + beta.reshape(shape)
+
+
+def layer_norm(x, gamma, beta, eps):
+    mean = x.mean(dim=-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps) * gamma + beta
+
+
+def dense(x, w, b=None):
+    """nn.Dense: y = x W^T + b, W [out,in]."""
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def conv2d(x, w, b, stride=1, padding=1):
+    """nn.Conv2d(pad_mode='pad'): NCHW cross-correlation with symmetric zero pad."""
+    return F.conv2d(x, w, b, stride=stride, padding=padding)
+
+
+def upsample_nearest2x(x):
+    """ops.ResizeNearestNeighbor((2H,2W)), align_corners=False -> src = floor(dst/2)."""
+    return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+
+
+# ----------------------------------------------------------------------------- UNet
+SD2_UNET = dict(  # configs/v2-inference.yaml:21-38
+    in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
+    num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_head_channels=64, num_heads=-1,
+    use_spatial_transformer=True, use_linear_in_transformer=True, transformer_depth=1,
+    context_dim=1024, legacy=False)
+
+WUKONG_UNET = dict(  # WK/configs/v1-inference-chinese.yaml:24-37
+    in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
+    num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, num_head_channels=-1,
+    use_spatial_transformer=True, use_linear_in_transformer=False, transformer_depth=1,
+    context_dim=768, legacy=False)
+
+
+def unet_structure(cfg):
+    """Walk UNetModel.__init__ (openaimodel.py:351-526) and return the block lists.
+
+    Each block is a list of layer descriptors:
+      ('conv', cin, cout) | ('res', cin, cout) | ('st', ch, heads, dim_head)
+      | ('down', ch) | ('up', ch)
+    """
+    mc = cfg["model_channels"]
+    nh_cfg = cfg.get("num_heads", -1)
+    nhc = cfg.get("num_head_channels", -1)
+    legacy = cfg.get("legacy", True)
+    ust = cfg.get("use_spatial_transformer", False)
+    assert ust, "only the spatial-transformer UNet is on the hot path (AttentionBlock is an empty stub)"
+
+    def heads_for(ch, num_heads):
+        if nhc == -1:
+            dim_head = ch // num_heads
+        else:
+            num_heads = ch // nhc
+            dim_head = nhc
+        if legacy:
+            dim_head = ch // num_heads
+        return num_heads, dim_head
+
+    num_heads = nh_cfg
+    input_blocks = [[("conv", cfg["in_channels"], mc)]]
+    chans = [mc]
+    ch, ds = mc, 1
+    cm = cfg["channel_mult"]
+    for level, mult in enumerate(cm):
+        for _ in range(cfg["num_res_blocks"]):
+            layers = [("res", ch, mult * mc)]
+            ch = mult * mc
+            if ds in cfg["attention_resolutions"]:
+                num_heads, dim_head = heads_for(ch, num_heads)
+                layers.append(("st", ch, num_heads, dim_head))
+            input_blocks.append(layers)
+            chans.append(ch)
+        if level != len(cm) - 1:
+            input_blocks.append([("down", ch)])
+            chans.append(ch)
+            ds *= 2
+    num_heads, dim_head = heads_for(ch, num_heads)
+    middle = [("res", ch, ch), ("st", ch, num_heads, dim_head), ("res", ch, ch)]
+    output_blocks = []
+    for level, mult in list(enumerate(cm))[::-1]:
+        for i in range(cfg["num_res_blocks"] + 1):
+            ich = chans.pop()
+            layers = [("res", ch + ich, mc * mult)]
+            ch = mc * mult
+            if ds in cfg["attention_resolutions"]:
+                num_heads, dim_head = heads_for(ch, num_heads)
+                layers.append(("st", ch, num_heads, dim_head))
+            if level and i == cfg["num_res_blocks"]:
+                layers.append(("up", ch))
+                ds //= 2
+            output_blocks.append(layers)
+    return input_blocks, middle, output_blocks
+
+
+class UNetOracle:
+    """UNetModel.construct (openaimodel.py:536-576) in fp32 on the CPU."""
+
+    def __init__(self, cfg, params):
+        self.cfg = dict(cfg)
+        self.p = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in params.items()}
+        self.input_blocks, self.middle, self.output_blocks = unet_structure(cfg)
+
+    # -- layers ---------------------------------------------------------------
+    def _res(self, pre, x, emb):
+        """ResBlock.construct openaimodel.py:176-205 (use_scale_shift_norm=False, no up/down)."""
+        p = self.p
+        h = group_norm(x, p[pre + "in_layers_norm.gamma"], p[pre + "in_layers_norm.beta"], 1e-5)
+        h = silu(h)
+        h = conv2d(h, p[pre + "in_layers_conv.conv.weight"], p[pre + "in_layers_conv.conv.bias"])
+        emb_out = dense(silu(emb), p[pre + "emb_layers.1.weight"], p[pre + "emb_layers.1.bias"])
+        h = h + emb_out[:, :, None, None]
+        h = group_norm(h, p[pre + "out_layers_norm.gamma"], p[pre + "out_layers_norm.beta"], 1e-5)
+        h = silu(h)
+        h = conv2d(h, p[pre + "out_layers_conv.conv.weight"], p[pre + "out_layers_conv.conv.bias"])
+        if (pre + "skip_connection.conv.weight") in p:
+            x = conv2d(x, p[pre + "skip_connection.conv.weight"], p[pre + "skip_connection.conv.bias"], padding=0)
+        return x + h
+
+    def _attn(self, pre, x, context, heads):
+        """CrossAttention.construct attention.py:117-166 (mask branch has no effect)."""
+        p = self.p
+        q = dense(x, p[pre + "to_q.weight"])
+        ctx = x if context is None else context
+        k = dense(ctx, p[pre + "to_k.weight"])
+        v = dense(ctx, p[pre + "to_v.weight"])
+        b, n, c = q.shape
+        d = c // heads
+
+        def rin(t):
+            bb, nn_, _ = t.shape
+            return t.reshape(bb, nn_, heads, d).permute(0, 2, 1, 3).reshape(bb * heads, nn_, d)
+
+        q, k, v = rin(q), rin(k), rin(v)
+        sim = torch.matmul(q, k.transpose(1, 2)) * (d ** -0.5)
+        attn = torch.softmax(sim, dim=-1)
+        out = torch.matmul(attn, v)
+        out = out.reshape(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, heads * d)
+        return dense(out, p[pre + "to_out.0.weight"], p[pre + "to_out.0.bias"])
+
+    def _st(self, pre, x, context, heads):
+        """SpatialTransformer.construct attention.py:237-256 + BasicTransformerBlock :181-185."""
+        p = self.p
+        use_linear = self.cfg.get("use_linear_in_transformer", False)
+        b, c, h, w = x.shape
+        x_in = x
+        x = group_norm(x, p[pre + "norm.gamma"], p[pre + "norm.beta"], 1e-6)
+        if not use_linear:
+            x = conv2d(x, p[pre + "proj_in.weight"], p[pre + "proj_in.bias"], padding=0)
+        x = x.reshape(b, c, h * w).permute(0, 2, 1)
+        if use_linear:
+            x = dense(x, p[pre + "proj_in.weight"], p[pre + "proj_in.bias"])
+        t = pre + "transformer_blocks.0."
+        x = self._attn(t + "attn1.", layer_norm(x, p[t + "norm1.gamma"], p[t + "norm1.beta"], 1e-5), None, heads) + x
+        x = self._attn(t + "attn2.", layer_norm(x, p[t + "norm2.gamma"], p[t + "norm2.beta"], 1e-5), context, heads) + x
+        y = layer_norm(x, p[t + "norm3.gamma"], p[t + "norm3.beta"], 1e-5)
+        y = dense(y, p[t + "ff.net.0.proj.weight"], p[t + "ff.net.0.proj.bias"])  # GEGLU attention.py:41-51
+        a, gate = y.chunk(2, dim=-1)
+        y = a * gelu_tanh(gate)
+        y = dense(y, p[t + "ff.net.2.weight"], p[t + "ff.net.2.bias"])
+        x = y + x
+        if use_linear:
+            x = dense(x, p[pre + "proj_out.weight"], p[pre + "proj_out.bias"])
+        x = x.reshape(b, h, w, c).permute(0, 3, 1, 2)
+        if not use_linear:
+            x = conv2d(x, p[pre + "proj_out.weight"], p[pre + "proj_out.bias"], padding=0)
+        return x + x_in
+
+    def _layer(self, pre, layer, h, emb, context):
+        p = self.p
+        kind = layer[0]
+        if kind == "conv":
+            return conv2d(h, p[pre + "conv.weight"], p[pre + "conv.bias"])
+        if kind == "res":
+            return self._res(pre, h, emb)
+        if kind == "st":
+            return self._st(pre, h, context, layer[2])
+        if kind == "down":  # Downsample openaimodel.py:63-88
+            return conv2d(h, p[pre + "op.conv.weight"], p[pre + "op.conv.bias"], stride=2, padding=1)
+        if kind == "up":  # Upsample openaimodel.py:33-60
+            return conv2d(upsample_nearest2x(h), p[pre + "conv.conv.weight"], p[pre + "conv.conv.bias"])
+        raise ValueError(kind)
+
+    # -- forward --------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x, timesteps, context):
+        p = self.p
+        x = torch.as_tensor(x, dtype=torch.float32)
+        context = torch.as_tensor(context, dtype=torch.float32)
+        timesteps = torch.as_tensor(timesteps)
+        t_emb = timestep_embedding(timesteps, self.cfg["model_channels"])
+        emb = dense(t_emb, p["time_embed.0.weight"], p["time_embed.0.bias"])
+        emb = dense(silu(emb), p["time_embed.2.weight"], p["time_embed.2.bias"])
+        hs = []
+        h = x
+        for i, block in enumerate(self.input_blocks):
+            for j, layer in enumerate(block):
+                h = self._layer(f"input_blocks.{i}.{j}.", layer, h, emb, context)
+            hs.append(h)
+        for j, layer in enumerate(self.middle):
+            h = self._layer(f"middle_block.{j}.", layer, h, emb, context)
+        for i, block in enumerate(self.output_blocks):
+            h = torch.cat([h, hs.pop()], dim=1)
+            for j, layer in enumerate(block):
+                h = self._layer(f"output_blocks.{i}.{j}.", layer, h, emb, context)
+        h = silu(group_norm(h, p["out.0.gamma"], p["out.0.beta"], 1e-5))
+        return conv2d(h, p["out.2.conv.weight"], p["out.2.conv.bias"])
+
+    __call__ = forward
+
+
+def unet_param_shapes(cfg):
+    """Parameter name -> shape for the reference's UNetModel."""
+    inb, mid, outb = unet_structure(cfg)
+    mc = cfg["model_channels"]
+    ted = 4 * mc
+    ctx = cfg["context_dim"]
+    use_linear = cfg.get("use_linear_in_transformer", False)
+    shapes = {
+        "time_embed.0.weight": (ted, mc), "time_embed.0.bias": (ted,),
+        "time_embed.2.weight": (ted, ted), "time_embed.2.bias": (ted,),
+    }
+
+    def add_layer(pre, layer):
+        kind = layer[0]
+        if kind == "conv":
+            shapes[pre + "conv.weight"] = (layer[2], layer[1], 3, 3)
+            shapes[pre + "conv.bias"] = (layer[2],)
+        elif kind == "res":
+            cin, cout = layer[1], layer[2]
+            shapes[pre + "in_layers_norm.gamma"] = (cin,)
+            shapes[pre + "in_layers_norm.beta"] = (cin,)
+            shapes[pre + "in_layers_conv.conv.weight"] = (cout, cin, 3, 3)
+            shapes[pre + "in_layers_conv.conv.bias"] = (cout,)
+            shapes[pre + "emb_layers.1.weight"] = (cout, ted)
+            shapes[pre + "emb_layers.1.bias"] = (cout,)
+            shapes[pre + "out_layers_norm.gamma"] = (cout,)
+            shapes[pre + "out_layers_norm.beta"] = (cout,)
+            shapes[pre + "out_layers_conv.conv.weight"] = (cout, cout, 3, 3)
+            shapes[pre + "out_layers_conv.conv.bias"] = (cout,)
+            if cin != cout:
+                shapes[pre + "skip_connection.conv.weight"] = (cout, cin, 1, 1)
+                shapes[pre + "skip_connection.conv.bias"] = (cout,)
+        elif kind == "st":
+            ch, heads, dh = layer[1], layer[2], layer[3]
+            inner = heads * dh
+            shapes[pre + "norm.gamma"] = (ch,)
+            shapes[pre + "norm.beta"] = (ch,)
+            if use_linear:
+                shapes[pre + "proj_in.weight"] = (inner, ch)
+                shapes[pre + "proj_out.weight"] = (ch, inner)
+            else:
+                shapes[pre + "proj_in.weight"] = (inner, ch, 1, 1)
+                shapes[pre + "proj_out.weight"] = (ch, inner, 1, 1)
+            shapes[pre + "proj_in.bias"] = (inner,)
+            shapes[pre + "proj_out.bias"] = (ch,)
+            t = pre + "transformer_blocks.0."
+            for a, cd in (("attn1.", inner), ("attn2.", ctx)):
+                shapes[t + a + "to_q.weight"] = (inner, inner)
+                shapes[t + a + "to_k.weight"] = (inner, cd)
+                shapes[t + a + "to_v.weight"] = (inner, cd)
+                shapes[t + a + "to_out.0.weight"] = (inner, inner)
+                shapes[t + a + "to_out.0.bias"] = (inner,)
+            shapes[t + "ff.net.0.proj.weight"] = (inner * 8, inner)
+            shapes[t + "ff.net.0.proj.bias"] = (inner * 8,)
+            shapes[t + "ff.net.2.weight"] = (inner, inner * 4)
+            shapes[t + "ff.net.2.bias"] = (inner,)
+            for n in ("norm1", "norm2", "norm3"):
+                shapes[t + n + ".gamma"] = (inner,)
+                shapes[t + n + ".beta"] = (inner,)
+        elif kind == "down":
+            shapes[pre + "op.conv.weight"] = (layer[1], layer[1], 3, 3)
+            shapes[pre + "op.conv.bias"] = (layer[1],)
+        elif kind == "up":
+            shapes[pre + "conv.conv.weight"] = (layer[1], layer[1], 3, 3)
+            shapes[pre + "conv.conv.bias"] = (layer[1],)
+
+    for i, block in enumerate(inb):
+        for j, layer in enumerate(block):
+            add_layer(f"input_blocks.{i}.{j}.", layer)
+    for j, layer in enumerate(mid):
+        add_layer(f"middle_block.{j}.", layer)
+    for i, block in enumerate(outb):
+        for j, layer in enumerate(block):
+            add_layer(f"output_blocks.{i}.{j}.", layer)
+    shapes["out.0.gamma"] = (mc,)
+    shapes["out.0.beta"] = (mc,)
+    shapes["out.2.conv.weight"] = (cfg["out_channels"], mc, 3, 3)
+    shapes["out.2.conv.bias"] = (cfg["out_channels"],)
+    return shapes
+
+
+def init_params(cfg, seed=0, zero_init=False, dtype=np.float32):
+    """Seeded synthetic weights: fan-in scaled normals so activations stay O(1).
+
+    zero_init=True reproduces the reference constructor's ``zero_module`` layers
+    (openaimodel.py:162-165,524; attention.py:223-231) for the structural KAT.
+    """
+    rng = np.random.RandomState(seed)
+    params = {}
+    for name, shape in unet_param_shapes(cfg).items():
+        if name.endswith(".gamma"):
+            v = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif name.endswith(".beta"):
+            v = 0.1 * rng.standard_normal(shape)
+        elif name.endswith(".bias"):
+            v = 0.05 * rng.standard_normal(shape)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            v = rng.standard_normal(shape) / math.sqrt(fan_in)
+        if zero_init and (name.endswith("out_layers_conv.conv.weight") or name.endswith("out_layers_conv.conv.bias")
+                          or name.startswith("out.2.") or ".proj_out." in name):
+            v = np.zeros(shape)
+        params[name] = v.astype(dtype)
+    return params
+
+
+# ----------------------------------------------------------------------------- samplers
+class ModelOracle:
+    """The attributes/methods PLMSSampler needs from LatentDiffusion (plms.py:31,40-46; ddpm.py:290-306)."""
+
+    def __init__(self, unet, linear_start=0.00085, linear_end=0.0120, timesteps=1000):
+        self.unet = unet
+        s = register_schedule(linear_start, linear_end, timesteps)
+        self.num_timesteps = s["num_timesteps"]
+        self.betas = s["betas"]
+        self.alphas_cumprod = s["alphas_cumprod"]
+        self.alphas_cumprod_prev = s["alphas_cumprod_prev"]
+        self.sqrt_alphas_cumprod = s["sqrt_alphas_cumprod"]
+        self.sqrt_one_minus_alphas_cumprod = s["sqrt_one_minus_alphas_cumprod"]
+        self.parameterization = "eps"
+        self.calls = 0
+
+    def apply_model(self, x, t, cond):
+        self.calls += 1
+        return self.unet(x, t, cond)
+
+    def q_sample(self, x0, t, noise):
+        """ddpm.py:197-200."""
+        a = torch.as_tensor(self.sqrt_alphas_cumprod)[t].reshape(-1, 1, 1, 1)
+        b = torch.as_tensor(self.sqrt_one_minus_alphas_cumprod)[t].reshape(-1, 1, 1, 1)
+        return a * x0 + b * noise
+
+
+def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0.0,
+           unconditional_guidance_scale=1.0, unconditional_conditioning=None, noise_fn=None,
+           temperature=1.0, log_every_t=100):
+    """PLMSSampler.sample/plms_sampling/p_sample_plms (plms.py:69-247).
+
+    sampler='ddim' applies get_x_prev_and_pred_x0 (plms.py:210-228) with e'=e_t each step
+    (SURVEY 0.4): S model calls instead of S+1, eta may be != 0 (noise from noise_fn(shape)).
+    Returns (samples, intermediates).
+    """
+    if sampler == "plms" and eta != 0:
+        raise ValueError("ddim_eta must be 0 for PLMS")  # plms.py:35-36
+    ts = make_ddim_timesteps(S, model.num_timesteps)
+    sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(model.alphas_cumprod, ts, eta)
+    sqrt_one_minus_alphas = np.sqrt(1.0 - alphas).astype(np.float32)
+    b = batch_size
+    img = torch.as_tensor(x_T, dtype=torch.float32)
+    assert tuple(img.shape) == (b,) + tuple(shape)
+    cond = torch.as_tensor(conditioning, dtype=torch.float32)
+    uc = None if unconditional_conditioning is None else torch.as_tensor(unconditional_conditioning, dtype=torch.float32)
+    time_range = np.flip(ts)
+    total = len(ts)
+    intermediates = {"x_inter": [img], "pred_x0": [img]}
+    old_eps = []
+    scale = float(unconditional_guidance_scale)
+
+    def get_model_output(x, t):  # plms.py:188-203
+        if uc is None or scale == 1.0:
+            return model.apply_model(x, t, cond)
+        x_in = torch.cat([x, x], 0)
+        t_in = torch.cat([t, t], 0)
+        c_in = torch.cat([uc, cond], 0)
+        e_u, e_c = model.apply_model(x_in, t_in, c_in).chunk(2, dim=0)
+        return e_u + scale * (e_c - e_u)
+
+    def x_prev_and_pred_x0(x, e_t, index):  # plms.py:210-228
+        a_t = torch.tensor(alphas[index])
+        a_prev = torch.tensor(alphas_prev[index])
+        sigma_t = torch.tensor(sigmas[index])
+        s1m = torch.tensor(sqrt_one_minus_alphas[index])
+        pred_x0 = (x - s1m * e_t) / a_t.sqrt()
+        dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t
+        if float(sigma_t) != 0.0:
+            noise = sigma_t * torch.as_tensor(noise_fn(tuple(x.shape)), dtype=torch.float32) * temperature
+        else:
+            noise = 0.0
+        return a_prev.sqrt() * pred_x0 + dir_xt + noise, pred_x0
+
+    for i, step in enumerate(time_range):
+        index = total - i - 1
+        t = torch.full((b,), int(step), dtype=torch.int64)
+        t_next = torch.full((b,), int(time_range[min(i + 1, total - 1)]), dtype=torch.int64)
+        e_t = get_model_output(img, t)
+        if sampler == "ddim":
+            e_prime = e_t
+        elif len(old_eps) == 0:
+            x_prev, _ = x_prev_and_pred_x0(img, e_t, index)
+            e_next = get_model_output(x_prev, t_next)
+            e_prime = (e_t + e_next) / 2
+        elif len(old_eps) == 1:
+            e_prime = (3 * e_t - old_eps[-1]) / 2
+        elif len(old_eps) == 2:
+            e_prime = (23 * e_t - 16 * old_eps[-1] + 5 * old_eps[-2]) / 12
+        else:
+            e_prime = (55 * e_t - 59 * old_eps[-1] + 37 * old_eps[-2] - 9 * old_eps[-3]) / 24
+        img, pred_x0 = x_prev_and_pred_x0(img, e_prime, index)
+        old_eps.append(e_t)
+        if len(old_eps) >= 4:
+            old_eps.pop(0)
+        if index % log_every_t == 0 or index == total - 1:
+            intermediates["x_inter"].append(img)
+            intermediates["pred_x0"].append(pred_x0)
+    return img, intermediates
