@@ -1,0 +1,148 @@
+/* mdx.h -- C-ABI of libmdx.so: the MI355X (gfx950) kernels under the minddiffusion
+ * UNet-denoising hot path.
+ *
+ * The reference (mindspore-lab/minddiffusion) has no FFI / operator-plugin interface:
+ * its hot path is Python calling stock MindSpore primitives.  Each
+ * entry point below therefore replaces one *primitive call site group* of the reference;
+ * the file:line it replaces is cited per function (paths under
+ * vision/stablediffusionv2/ unless noted).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers (HBM) unless noted; the caller owns every buffer
+ *    including workspaces; the library never allocates device memory and never
+ *    synchronises.  All work is enqueued on the caller's stream (hipStream_t passed as
+ *    void*), so calls are capturable into a hipGraph.
+ *  - Activations are NHWC ("token-major") fp16: [B][H*W][C]; the reference's NCHW fp32
+ *    tensors exist only at the apply_model boundary (mdx_nchw_to_nhwc_f16 /
+ *    mdx_nhwc_to_nchw_f32).
+ *  - Weights are fp16, packed [N][K] (K contiguous): nn.Dense weight [out][in] as is;
+ *    nn.Conv2d weight [out][in][kh][kw] repacked to [out][kh*kw][in].
+ *  - Return value: 0 = ok, negative = error (MDX_E_*); mdx_last_error() returns a
+ *    thread-local message.  Nothing throws or exits across the ABI.
+ */
+#ifndef MDX_H_
+#define MDX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDX_OK 0
+#define MDX_E_INVALID (-1)     /* bad argument / unsupported shape */
+#define MDX_E_WORKSPACE (-2)   /* workspace too small */
+#define MDX_E_HIP (-3)         /* HIP runtime error at launch */
+
+typedef void* mdx_stream_t; /* hipStream_t */
+
+int mdx_version(void);
+const char* mdx_last_error(void);
+
+/* ---- layout boundary: LatentDiffusion.apply_model casts/wraps (ldm/models/diffusion/ddpm.py:290-306) */
+/* x [B][C][H][W] fp32 -> y [B][H*W][Cpad] fp16, channels C..Cpad-1 zero-filled. */
+int mdx_nchw_to_nhwc_f16(const float* x, void* y, int B, int C, int H, int W, int Cpad, mdx_stream_t s);
+/* x [B][H*W][Cstride] fp16 -> y [B][C][H][W] fp32 (first C channels). */
+int mdx_nhwc_to_nchw_f32(const void* x, float* y, int B, int C, int H, int W, int Cstride, mdx_stream_t s);
+
+/* ---- nn.GroupNorm(32,C,eps) [+ SiLU]  (ldm/modules/diffusionmodules/util.py:87-108,
+ *      openaimodel.py:136-137,159-160,521-523; attention.py:83-84 eps 1e-6)
+ * Input is the channel-concatenation of x1 [B][HW][C1] and optional x2 [B][HW][C2]
+ * (openaimodel.py:568 Concat is never materialised).  Statistics in fp32.
+ * y [B][HW][C1+C2] fp16.  gamma/beta fp32 [C1+C2].
+ * ws: fp32 workspace of at least mdx_groupnorm_ws_floats(B, HW, C1+C2, groups) floats. */
+size_t mdx_groupnorm_ws_floats(int B, int HW, int C, int groups);
+int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
+                      void* y, int B, int HW, int groups, float eps, int silu, float* ws, mdx_stream_t s);
+
+/* ---- nn.LayerNorm([C], eps) (attention.py:176-178): rows x C fp16 -> fp16, fp32 statistics. */
+int mdx_layernorm_f16(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
+                      mdx_stream_t s);
+
+/* ---- nn.Conv2d 3x3/1x1 and nn.Dense as one MFMA implicit-GEMM
+ *      (openaimodel.py:50,81,138,163,174,352,524; attention.py:44,66,108-112,212,231)
+ * out[m][n] = sum_k A[m][k] * W[n][k]  (+bias[n]) (+rowbias[b(m)][n]) (+residual[m][n])
+ *   m = (b, yo, xo) output pixel / token;  k = (tap, cin);  A gathered on the fly from the
+ *   NHWC source(s) with zero padding, optional stride 2 (Downsample) and optional nearest-2x
+ *   upsample of the source (Upsample, openaimodel.py:57) folded into the gather.             */
+typedef struct mdx_gemm_desc {
+    const void* a;        /* source 1, NHWC fp16 [B][H][W][c1] */
+    const void* a2;       /* optional source 2 (channel concat), [B][H][W][c2], or NULL */
+    int c1, c2;           /* Cin = c1 + c2 (each a multiple of 8) */
+    const void* w;        /* packed weights fp16 [N][ksize*ksize*Cin] */
+    const float* bias;    /* [N] fp32 or NULL */
+    const float* rowbias; /* [B][rowbias_ld] fp32 per-sample bias (ResBlock emb add, openaimodel.py:188-200) or NULL */
+    int rowbias_ld;
+    const void* residual; /* fp16 [M][residual_ld] or NULL (skip / transformer residual adds) */
+    int residual_ld;
+    void* out;            /* fp16 */
+    int out_ld;           /* row stride (elements) of out for out_mode 0; token stride for out_mode 1 */
+    int B, H, W;          /* source spatial extent per sample (Dense: H = tokens, W = 1) */
+    int N;                /* output channels (multiple of 8; GEGLU: 2x the produced width, interleaved packing) */
+    int ksize;            /* 1 or 3 (3 => pad 1) */
+    int stride;           /* 1 or 2 */
+    int upsample;         /* 1: nearest-2x upsample the source before the conv */
+    int epilogue;         /* MDX_EPI_* */
+    int out_mode;         /* MDX_OUT_* */
+    int splitk;           /* 0 = auto, >=1 = number of K splits */
+    void* workspace;      /* fp32 split-K slabs (may be NULL when splitk <= 1) */
+    size_t workspace_bytes;
+} mdx_gemm_desc;
+
+#define MDX_EPI_NONE 0
+#define MDX_EPI_GEGLU 1 /* out[m][j] = a * gelu_tanh(g); packed so that each 128-wide N tile = 64 'a' | 64 'gate' cols
+                           (attention.py:41-51) */
+#define MDX_OUT_ROWMAJOR 0   /* out[m * out_ld + n] */
+#define MDX_OUT_TRANSPOSED 1 /* out[(b * N + n) * out_ld + tok]: V^T for mdx_attention_f16 */
+
+int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s);
+/* Bytes of split-K workspace mdx_gemm_f16 wants for this problem under its auto heuristic (0 if none). */
+size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d);
+/* Host-only validation of a descriptor (no launch): MDX_OK or MDX_E_INVALID with mdx_last_error() set. */
+int mdx_gemm_check(const mdx_gemm_desc* d);
+
+/* ---- CrossAttention core: softmax(q k^T * scale) v, flash-style (attention.py:138-152);
+ *      the [b*h, N, N] score tensor of the reference is never materialised.
+ * q  : fp16, element (b, i, h*D + d) at q[b*q_bs + i*q_ld + h*D + d]
+ * k  : fp16, element (b, j, h*D + d) at k[b*k_bs + j*k_ld + h*D + d]
+ * vt : fp16 TRANSPOSED values, element (b, h*D + d, j) at vt[b*vt_bs + (h*D+d)*vt_ld + j];
+ *      columns Nk..vt_ld-1 must be finite (zero-filled by the caller)
+ * o  : fp16, same addressing as q with o_bs/o_ld.   D in {64}. */
+int mdx_attention_f16(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld, const void* vt,
+                      long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads, int D, int Nq, int Nk,
+                      float scale, mdx_stream_t s);
+
+/* ---- timestep_embedding (util.py:111-131): t [M] fp32 -> out [M][dim] fp32 = [cos | sin]. */
+int mdx_timestep_embedding_f32(const float* t, float* out, int M, int dim, float max_period, mdx_stream_t s);
+
+/* ---- small-M nn.Dense for the time-embedding MLP and the 22 emb_layers
+ *      (openaimodel.py:341-345,150-157): out[M][N] = act_out(act_in(x)[M][K] @ W[N][K]^T + b)
+ * x, out fp32; W fp16; b fp32.  act: 0 none, 1 SiLU. */
+int mdx_dense_small_f32(const float* x, int x_ld, const void* w, const float* b, float* out, int out_ld, int M,
+                        int N, int K, int act_in, int act_out, mdx_stream_t s);
+
+/* ---- fused sampler update (ldm/models/diffusion/plms.py:188-197, 210-244)
+ * eps_u / eps_c: UNet outputs, NHWC fp16 [B][HW][eps_ld] (first C channels used).
+ *   e_t = eps_c                                  if eps_u == NULL
+ *       = eps_u + cfg_scale * (eps_c - eps_u)    otherwise            (plms.py:197)
+ *   e'  = coef[0]*e_t + coef[1]*old1 + coef[2]*old2 + coef[3]*old3     (plms.py:231-244; DDIM: coef = {1,0,0,0};
+ *         the 'pseudo improved Euler' second call passes coef = {.5,.5,0,0} with old1 = first e_t)
+ *   pred_x0 = (x - sqrt_one_minus_at * e') / sqrt_at                   (plms.py:218)
+ *   x_prev  = sqrt_a_prev * pred_x0 + dir_coef * e' + sigma * noise    (plms.py:222-226)
+ * x, old*, noise, e_t_out, x_prev, pred_x0: NCHW fp32 [B][C][H][W] (noise may be NULL when sigma == 0;
+ * old* may be NULL when their coef is 0; e_t_out / pred_x0 may be NULL).  x_prev may alias x.
+ * coef4 is a HOST pointer to 4 floats (read at call time). */
+int mdx_sampler_step_f32(const float* x, const void* eps_u, const void* eps_c, int eps_ld, float cfg_scale,
+                         const float* old1, const float* old2, const float* old3, const float* coef4,
+                         float sqrt_at, float sqrt_one_minus_at, float sqrt_a_prev, float dir_coef, float sigma,
+                         const float* noise, float* e_t_out, float* x_prev, float* pred_x0, int B, int C, int H,
+                         int W, mdx_stream_t s);
+
+/* ---- probes used by tests to pin hardware layout assumptions (not on the hot path) */
+int mdx_probe_mfma_32x32x16_f16(const void* a, const void* b, float* c, mdx_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDX_H_ */

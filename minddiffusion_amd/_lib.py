@@ -1,0 +1,85 @@
+"""ctypes binding of libmdx.so (include/mdx.h).  The product path has NO fallback: if the HIP
+library is missing or a kernel call fails, we raise."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdx.so")
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_long = ctypes.c_long
+c_float = ctypes.c_float
+c_size_t = ctypes.c_size_t
+
+
+class MdxError(RuntimeError):
+    pass
+
+
+class GemmDesc(ctypes.Structure):
+    """struct mdx_gemm_desc (include/mdx.h)."""
+    _fields_ = [
+        ("a", c_void_p), ("a2", c_void_p), ("c1", c_int), ("c2", c_int),
+        ("w", c_void_p), ("bias", c_void_p), ("rowbias", c_void_p), ("rowbias_ld", c_int),
+        ("residual", c_void_p), ("residual_ld", c_int),
+        ("out", c_void_p), ("out_ld", c_int),
+        ("B", c_int), ("H", c_int), ("W", c_int), ("N", c_int),
+        ("ksize", c_int), ("stride", c_int), ("upsample", c_int),
+        ("epilogue", c_int), ("out_mode", c_int), ("splitk", c_int),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+    ]
+
+
+EPI_NONE, EPI_GEGLU = 0, 1
+OUT_ROWMAJOR, OUT_TRANSPOSED = 0, 1
+
+# name -> (restype, argtypes); also the list the CPU test checks against include/mdx.h
+SIGNATURES = {
+    "mdx_version": (c_int, []),
+    "mdx_last_error": (ctypes.c_char_p, []),
+    "mdx_nchw_to_nhwc_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdx_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdx_groupnorm_ws_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mdx_groupnorm_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_int, c_float, c_int, c_void_p, c_void_p]),
+    "mdx_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "mdx_gemm_f16": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
+    "mdx_gemm_workspace_bytes": (c_size_t, [ctypes.POINTER(GemmDesc)]),
+    "mdx_gemm_check": (c_int, [ctypes.POINTER(GemmDesc)]),
+    "mdx_attention_f16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,
+                                  c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "mdx_timestep_embedding_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "mdx_dense_small_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_void_p]),
+    "mdx_sampler_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdx_probe_mfma_32x32x16_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmdx.so (built by ``__graft_entry__.build()`` / ``make -C minddiffusion_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MdxError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C minddiffusion_amd/csrc`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mdx_last_error()
+        raise MdxError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

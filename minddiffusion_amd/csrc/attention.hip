@@ -1,0 +1,238 @@
+// Fused flash-style attention for gfx950: O = softmax(Q K^T * scale) V without materialising scores.
+// Replaces ops.matmul + ops.Softmax + ops.matmul of CrossAttention.construct
+// (vision/stablediffusionv2/ldm/modules/attention.py:138-152), self- and cross-attention.
+//
+// Block = 4 wave64, 128 queries (32 per wave); K/V^T tiles of 64 keys are DMA'd HBM->LDS
+// (buffer_load ... lds, XOR-swizzled on the source side) and double-buffered.
+// Per wave and KV tile:
+//   S^T[key][q] = K Q^T     : MFMA 32x32x16 f16, A = K rows (ds_read_b128), B = Q (registers)
+//   online softmax           : every lane owns ONE query (col = lane&31) and 32 of the 64 keys,
+//                              so row max / row sum need a single lane^32 exchange
+//   O^T[d][q] += V^T P^T    : A = V^T rows (2 x ds_read_b64), B = P straight from the S^T
+//                              accumulator registers (the C layout of S^T IS the B layout of PV
+//                              under the key permutation kappa(c,hi,j) = 16c + 4hi + (j&3) + 8(j>>2);
+//                              the same permutation is applied to the V^T reads) -- no cross-lane moves.
+// V must be supplied TRANSPOSED ([b][h*D+d][key]); the projection GEMM writes it that way
+// (MDX_OUT_TRANSPOSED), which keeps every LDS read of this kernel wide and conflict-light.
+#include "mdx_common.h"
+
+namespace {
+
+struct AttnParams {
+    const f16* q;
+    const f16* k;
+    const f16* vt;
+    f16* o;
+    long q_bs, k_bs, vt_bs, o_bs;
+    int q_ld, k_ld, vt_ld, o_ld;
+    int B, heads, Nq, Nk;
+    float scale_log2;  // scale * log2(e)
+    unsigned k_bytes, vt_bytes;  // per-batch extents for the buffer descriptors
+};
+
+constexpr int BQ = 128;
+constexpr int BKV = 64;
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
+    static_assert(D == 64, "head dim 64 only in this instantiation");
+    constexpr int KS = D / 16;        // k-steps of QK^T
+    constexpr int DT = D / 32;        // 32-row d tiles of O^T
+    constexpr int ROWB = 128;         // LDS row bytes (64 f16)
+    constexpr int K_BYTES = BKV * ROWB;   // 8 KiB : [key][d]
+    constexpr int V_BYTES = D * ROWB;     // 8 KiB : [d][key]
+    constexpr int STAGE = K_BYTES + V_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * BQ + wave * 32;
+
+    const f16* kb = p.k + (size_t)b * p.k_bs + h * D;
+    const f16* vb = p.vt + (size_t)b * p.vt_bs + (size_t)h * D * p.vt_ld;
+    const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(kb, p.k_bytes);
+    const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(vb, p.vt_bytes);
+
+    // ---- Q fragments (B operand): lane (q = l31, hi) holds Q[q][16s + 8hi .. +7]
+    f16x8 qf[KS];
+    {
+        const int qi = q0 + l31;
+        const f16* qp = p.q + (size_t)b * p.q_bs + (size_t)qi * p.q_ld + h * D + hi * 8;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (qi < p.Nq)
+                qf[s] = *reinterpret_cast<const f16x8*>(qp + s * 16);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[s][e] = (f16)0.f;
+        }
+    }
+
+    // ---- DMA coordinates: per stage 8 K instructions + 8 V instructions of 8 rows each; 2+2 per wave
+    const int drow = lane >> 3;  // row within the 8-row DMA group
+    auto stage_tile = [&](int t, int buf) {
+        char* sb = smem + buf * STAGE;
+        const int key0 = t * BKV;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * 2 + j) * 8 + drow;           // key row within the tile
+            const unsigned chunk = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+            const int key = key0 + row;
+            const unsigned off = (key < p.Nk) ? (unsigned)(((size_t)key * p.k_ld + chunk * 8) * 2) : MDX_OOB;
+            dma16(rs_k, sb + (wave * 2 + j) * 1024, off);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (wave * 2 + j) * 8 + drow;           // d row
+            const unsigned chunk = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+            const int kc = key0 + (int)chunk * 8;                  // first key of this 16-B chunk
+            const unsigned off = (kc < p.vt_ld) ? (unsigned)(((size_t)row * p.vt_ld + kc) * 2) : MDX_OOB;
+            dma16(rs_v, sb + K_BYTES + (wave * 2 + j) * 1024, off);
+        }
+    };
+
+    f32x16 acc_o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
+    float m_run = -INFINITY;  // running max of raw scores (same value in lanes l and l^32)
+    float l_run = 0.f;        // lane-partial running sum
+
+    const int swz = (lane >> 1) & 7;
+    const int ntiles = (p.Nk + BKV - 1) / BKV;
+    stage_tile(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) stage_tile(t + 1, buf ^ 1);
+        const char* sk = smem + buf * STAGE;
+        const char* sv = sk + K_BYTES;
+
+        // ---- S^T = K Q^T : two 32-key tiles
+        f32x16 acc_s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_s[kt][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + (kt * 32 + l31) * ROWB + (((2 * s + hi) ^ swz) << 4));
+                acc_s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], acc_s[kt], 0, 0, 0);
+            }
+        }
+        // ---- mask keys beyond Nk (last tile only)
+        const int key0 = t * BKV;
+        if (key0 + BKV > p.Nk) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= p.Nk) acc_s[kt][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax (one query per lane, keys split between lane and lane^32)
+        float mx = acc_s[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc_s[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);           // finite: every tile has >= 1 valid key
+        const float alpha = exp2f((m_run - m_new) * p.scale_log2);  // first tile: exp2(-inf) = 0
+        const float mb = m_new * p.scale_log2;
+        float psum = 0.f;
+        f16x8 pf[4];  // B fragments for the 4 16-key chunks
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(acc_s[kt][r] * p.scale_log2 - mb);
+                psum += pv;
+                pf[kt * 2 + (r >> 3)][r & 7] = (f16)pv;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const char* vr = sv + (d * 32 + l31) * ROWB + 8 * hi;
+                const f16x4 lo = *reinterpret_cast<const f16x4*>(vr + (((2 * c) ^ swz) << 4));
+                const f16x4 hi4 = *reinterpret_cast<const f16x4*>(vr + (((2 * c + 1) ^ swz) << 4));
+                f16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
+                acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c], acc_o[d], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- finalize: O /= l ; stage [q][d] per wave in LDS, then 128-B row stores
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    constexpr int OLD = D + 8;
+    f16* og = reinterpret_cast<f16*>(smem) + wave * 32 * OLD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (f16)(acc_o[d][4 * g + e] * inv);
+            *reinterpret_cast<f16x4*>(&og[l31 * OLD + d * 32 + 8 * g + 4 * hi]) = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < (32 * D / 8) / 64; ++pass) {
+        const int row = pass * (64 / (D / 8)) + lane / (D / 8);
+        const int chunk = lane % (D / 8);
+        const int qi = q0 + row;
+        if (qi < p.Nq) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(&og[row * OLD + chunk * 8]);
+            *reinterpret_cast<f16x8*>(p.o + (size_t)b * p.o_bs + (size_t)qi * p.o_ld + h * D + chunk * 8) = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mdx_attention_f16(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld,
+                                 const void* vt, long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads,
+                                 int D, int Nq, int Nk, float scale, mdx_stream_t s) {
+    MDX_REQUIRE(q && k && vt && o, "mdx_attention_f16: null pointer");
+    MDX_REQUIRE(D == 64, "mdx_attention_f16: head dim %d not supported (64 only)", D);
+    MDX_REQUIRE(B > 0 && heads > 0 && Nq > 0 && Nk > 0, "mdx_attention_f16: bad extents");
+    MDX_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vt_ld % 8 == 0 && o_ld % 8 == 0, "mdx_attention_f16: strides must be multiples of 8");
+    MDX_REQUIRE(vt_ld >= Nk, "mdx_attention_f16: vt_ld < Nk");
+    AttnParams p{};
+    p.q = (const f16*)q;
+    p.k = (const f16*)k;
+    p.vt = (const f16*)vt;
+    p.o = (f16*)o;
+    p.q_bs = q_bs; p.k_bs = k_bs; p.vt_bs = vt_bs; p.o_bs = o_bs;
+    p.q_ld = q_ld; p.k_ld = k_ld; p.vt_ld = vt_ld; p.o_ld = o_ld;
+    p.B = B; p.heads = heads; p.Nq = Nq; p.Nk = Nk;
+    p.scale_log2 = scale * 1.4426950408889634f;
+    const size_t kbytes = ((size_t)(Nk - 1) * k_ld + D) * 2;
+    const size_t vbytes = ((size_t)(D - 1) * vt_ld + vt_ld) * 2;
+    MDX_REQUIRE(kbytes <= 0x80000000ull && vbytes <= 0x80000000ull, "mdx_attention_f16: K/V extent too large");
+    p.k_bytes = (unsigned)kbytes;
+    p.vt_bytes = (unsigned)vbytes;
+    dim3 grid((Nq + BQ - 1) / BQ, heads, B);
+    const size_t lds = 2 * (size_t)(BKV * 128 + D * 128);
+    hipLaunchKernelGGL(attn_kernel<64>, grid, dim3(256), lds, (hipStream_t)s, p);
+    MDX_LAUNCH_CHECK("mdx_attention_f16");
+    return MDX_OK;
+}

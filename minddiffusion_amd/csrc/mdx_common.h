@@ -1,0 +1,66 @@
+// Shared device/host helpers for libmdx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "mdx.h"
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MDX_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// error plumbing (host)
+void mdx_set_error(const char* fmt, ...);
+
+#define MDX_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            mdx_set_error(__VA_ARGS__);   \
+            return MDX_E_INVALID;         \
+        }                                 \
+    } while (0)
+
+#define MDX_LAUNCH_CHECK(name)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            mdx_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return MDX_E_HIP;                                                         \
+        }                                                                             \
+    } while (0)
+
+// ---- device helpers
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ops.GeLU == tanh approximation: 0.5 x (1 + tanh(sqrt(2/pi)(x + 0.044715 x^3)))
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    // tanh(u) = 1 - 2/(exp(2u)+1); stable for large |u|
+    const float t = 1.0f - 2.0f / (__expf(2.0f * u) + 1.0f);
+    return 0.5f * x * (1.0f + t);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// 16-byte direct-to-LDS DMA through a buffer descriptor: per-lane source byte offset `voff`
+// (offsets >= num_records return zeros: this is how conv zero padding and tile tails are done),
+// destination = wave-uniform `lds` + lane*16.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_uniform, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MDX_LDS_PTR(lds_wave_uniform), 16, voff, 0, 0, 0);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+
+#define MDX_OOB 0x80000000u

@@ -1,0 +1,261 @@
+// Small / elementwise kernels of the path: layout boundary, timestep embedding, small-M Dense,
+// fused sampler update, hardware-layout probes, and the library's error plumbing.
+#include "mdx_common.h"
+
+#include <string.h>
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+
+void mdx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* mdx_last_error(void) { return g_err; }
+extern "C" int mdx_version(void) { return 1; }
+
+namespace {
+
+// ------------------------------------------------------------------ layout boundary
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, f16* __restrict__ y, int B,
+                                                           int C, int HW, int Cpad) {
+    const size_t total = (size_t)B * HW * Cpad;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % Cpad);
+        const size_t bp = i / Cpad;
+        const int pix = (int)(bp % HW);
+        const int b = (int)(bp / HW);
+        y[i] = c < C ? (f16)x[((size_t)b * C + c) * HW + pix] : (f16)0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const f16* __restrict__ x, float* __restrict__ y, int B,
+                                                           int C, int HW, int Cs) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int pix = (int)(i % HW);
+        const size_t bc = i / HW;
+        const int c = (int)(bc % C);
+        const int b = (int)(bc / C);
+        y[i] = (float)x[((size_t)b * HW + pix) * Cs + c];
+    }
+}
+
+// ------------------------------------------------------------------ timestep embedding (util.py:111-131)
+__global__ __launch_bounds__(256) void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out,
+                                                                 int M, int dim, float neg_log_period) {
+    const int half = dim / 2;
+    const int total = M * half;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int m = i / half, k = i - m * half;
+        const float freq = expf(neg_log_period * (float)k / (float)half);
+        const float arg = t[m] * freq;
+        out[(size_t)m * dim + k] = cosf(arg);
+        out[(size_t)m * dim + half + k] = sinf(arg);
+        if ((dim & 1) && k == 0) out[(size_t)m * dim + dim - 1] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ small-M Dense
+// One wave per output column n, MB rows of x per pass.  W row is streamed once per pass
+// (16 B per lane); x is tiny and L2-resident.
+template <int MB>
+__global__ __launch_bounds__(256) void dense_small_kernel(const float* __restrict__ x, int x_ld,
+                                                          const f16* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int out_ld, int M, int N, int K,
+                                                          int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const f16* wr = w + (size_t)n * K;
+    for (int m0 = 0; m0 < M; m0 += MB) {
+        float acc[MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) acc[i] = 0.f;
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            const f16x8 wv = *reinterpret_cast<const f16x8*>(wr + k);
+            float wf[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wf[e] = (float)wv[e];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                if (m0 + i < M) {
+                    const float4* xp = reinterpret_cast<const float4*>(x + (size_t)(m0 + i) * x_ld + k);
+                    const float4 a = xp[0], b = xp[1];
+                    float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = act_in ? silu_f(xv[e]) : xv[e];
+                        acc[i] += v * wf[e];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const float s = wave_sum(acc[i]);
+            if (lane == 0 && m0 + i < M) {
+                float v = s + (bias ? bias[n] : 0.f);
+                if (act_out) v = silu_f(v);
+                out[(size_t)(m0 + i) * out_ld + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ fused sampler update (plms.py:188-244)
+struct StepParams {
+    const float* x;
+    const f16* eps_u;
+    const f16* eps_c;
+    const float* old1;
+    const float* old2;
+    const float* old3;
+    const float* noise;
+    float* e_t_out;
+    float* x_prev;
+    float* pred_x0;
+    int eps_ld, B, C, HW;
+    float cfg_scale, c0, c1, c2, c3;
+    float sqrt_at, sqrt_one_minus_at, sqrt_a_prev, dir_coef, sigma;
+};
+
+__global__ __launch_bounds__(256) void sampler_step_kernel(const StepParams p) {
+    const size_t total = (size_t)p.B * p.C * p.HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int pix = (int)(i % p.HW);
+        const size_t bc = i / p.HW;
+        const int c = (int)(bc % p.C);
+        const int b = (int)(bc / p.C);
+        const size_t ei = ((size_t)b * p.HW + pix) * p.eps_ld + c;
+        float e_t = (float)p.eps_c[ei];
+        if (p.eps_u) {
+            const float eu = (float)p.eps_u[ei];
+            e_t = eu + p.cfg_scale * (e_t - eu);
+        }
+        if (p.e_t_out) p.e_t_out[i] = e_t;
+        float ep = p.c0 * e_t;
+        if (p.old1) ep += p.c1 * p.old1[i];
+        if (p.old2) ep += p.c2 * p.old2[i];
+        if (p.old3) ep += p.c3 * p.old3[i];
+        const float xv = p.x[i];
+        const float px0 = (xv - p.sqrt_one_minus_at * ep) / p.sqrt_at;
+        float xp = p.sqrt_a_prev * px0 + p.dir_coef * ep;
+        if (p.noise) xp += p.sigma * p.noise[i];
+        if (p.pred_x0) p.pred_x0[i] = px0;
+        p.x_prev[i] = xp;
+    }
+}
+
+// ------------------------------------------------------------------ MFMA layout probe
+__global__ void probe_mfma_kernel(const f16* a, const f16* b, float* c) {
+    const int lane = threadIdx.x;
+    const f16x8 av = *reinterpret_cast<const f16x8*>(a + lane * 8);
+    const f16x8 bv = *reinterpret_cast<const f16x8*>(b + lane * 8);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[lane * 16 + r] = acc[r];
+}
+
+inline int grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int mdx_nchw_to_nhwc_f16(const float* x, void* y, int B, int C, int H, int W, int Cpad, mdx_stream_t s) {
+    MDX_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "mdx_nchw_to_nhwc_f16: bad arguments");
+    const size_t total = (size_t)B * H * W * Cpad;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, x, (f16*)y, B, C,
+                       H * W, Cpad);
+    MDX_LAUNCH_CHECK("mdx_nchw_to_nhwc_f16");
+    return MDX_OK;
+}
+
+extern "C" int mdx_nhwc_to_nchw_f32(const void* x, float* y, int B, int C, int H, int W, int Cstride,
+                                    mdx_stream_t s) {
+    MDX_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && Cstride >= C, "mdx_nhwc_to_nchw_f32: bad arguments");
+    const size_t total = (size_t)B * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, (const f16*)x, y, B,
+                       C, H * W, Cstride);
+    MDX_LAUNCH_CHECK("mdx_nhwc_to_nchw_f32");
+    return MDX_OK;
+}
+
+extern "C" int mdx_timestep_embedding_f32(const float* t, float* out, int M, int dim, float max_period,
+                                          mdx_stream_t s) {
+    MDX_REQUIRE(t && out && M > 0 && dim >= 2 && max_period > 0.f, "mdx_timestep_embedding_f32: bad arguments");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(grid_for((size_t)M * (dim / 2))), dim3(256), 0, (hipStream_t)s,
+                       t, out, M, dim, -logf(max_period));
+    MDX_LAUNCH_CHECK("mdx_timestep_embedding_f32");
+    return MDX_OK;
+}
+
+extern "C" int mdx_dense_small_f32(const float* x, int x_ld, const void* w, const float* b, float* out, int out_ld,
+                                   int M, int N, int K, int act_in, int act_out, mdx_stream_t s) {
+    MDX_REQUIRE(x && w && out, "mdx_dense_small_f32: null pointer");
+    MDX_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && x_ld % 4 == 0 && x_ld >= K && out_ld >= N,
+                "mdx_dense_small_f32: bad extents (M=%d N=%d K=%d)", M, N, K);
+    dim3 grid((N + 3) / 4);
+    hipStream_t st = (hipStream_t)s;
+    if (M <= 2)
+        hipLaunchKernelGGL(dense_small_kernel<2>, grid, dim3(256), 0, st, x, x_ld, (const f16*)w, b, out, out_ld, M, N, K, act_in, act_out);
+    else
+        hipLaunchKernelGGL(dense_small_kernel<8>, grid, dim3(256), 0, st, x, x_ld, (const f16*)w, b, out, out_ld, M, N, K, act_in, act_out);
+    MDX_LAUNCH_CHECK("mdx_dense_small_f32");
+    return MDX_OK;
+}
+
+extern "C" int mdx_sampler_step_f32(const float* x, const void* eps_u, const void* eps_c, int eps_ld, float cfg_scale,
+                                    const float* old1, const float* old2, const float* old3, const float* coef4,
+                                    float sqrt_at, float sqrt_one_minus_at, float sqrt_a_prev, float dir_coef,
+                                    float sigma, const float* noise, float* e_t_out, float* x_prev, float* pred_x0,
+                                    int B, int C, int H, int W, mdx_stream_t s) {
+    MDX_REQUIRE(x && eps_c && coef4 && x_prev, "mdx_sampler_step_f32: null pointer");
+    MDX_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && eps_ld >= C, "mdx_sampler_step_f32: bad extents");
+    MDX_REQUIRE(sigma == 0.f || noise, "mdx_sampler_step_f32: sigma != 0 needs a noise tensor");
+    MDX_REQUIRE((coef4[1] == 0.f || old1) && (coef4[2] == 0.f || old2) && (coef4[3] == 0.f || old3),
+                "mdx_sampler_step_f32: non-zero multistep coefficient without its eps history");
+    StepParams p{};
+    p.x = x;
+    p.eps_u = (const f16*)eps_u;
+    p.eps_c = (const f16*)eps_c;
+    p.old1 = coef4[1] != 0.f ? old1 : nullptr;
+    p.old2 = coef4[2] != 0.f ? old2 : nullptr;
+    p.old3 = coef4[3] != 0.f ? old3 : nullptr;
+    p.noise = sigma != 0.f ? noise : nullptr;
+    p.e_t_out = e_t_out;
+    p.x_prev = x_prev;
+    p.pred_x0 = pred_x0;
+    p.eps_ld = eps_ld;
+    p.B = B;
+    p.C = C;
+    p.HW = H * W;
+    p.cfg_scale = cfg_scale;
+    p.c0 = coef4[0];
+    p.c1 = coef4[1];
+    p.c2 = coef4[2];
+    p.c3 = coef4[3];
+    p.sqrt_at = sqrt_at;
+    p.sqrt_one_minus_at = sqrt_one_minus_at;
+    p.sqrt_a_prev = sqrt_a_prev;
+    p.dir_coef = dir_coef;
+    p.sigma = sigma;
+    hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, (hipStream_t)s, p);
+    MDX_LAUNCH_CHECK("mdx_sampler_step_f32");
+    return MDX_OK;
+}
+
+extern "C" int mdx_probe_mfma_32x32x16_f16(const void* a, const void* b, float* c, mdx_stream_t s) {
+    MDX_REQUIRE(a && b && c, "mdx_probe_mfma_32x32x16_f16: null pointer");
+    hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const f16*)a, (const f16*)b, c);
+    MDX_LAUNCH_CHECK("mdx_probe_mfma_32x32x16_f16");
+    return MDX_OK;
+}

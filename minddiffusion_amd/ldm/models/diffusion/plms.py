@@ -1,0 +1,205 @@
+"""PLMSSampler -- MI355X-native mirror of the reference's ldm/models/diffusion/plms.py
+(make_schedule :34-67, sample :69-122, plms_sampling :124-179, p_sample_plms :182-247; Wukong copy
+WK/ldm/models/diffusion/plms.py:185-215 for the dict-conditioning form).
+
+Same class name, constructor and ``sample(...)`` keyword surface.  What changes is the execution:
+  * the host loop only enqueues work: one UNet forward (a replayed hipGraph) and ONE fused
+    elementwise kernel per step (mdx_sampler_step_f32: CFG combine + Adams-Bashforth mix + x0/dir/x_prev),
+    instead of ~15 separately dispatched MindSpore ops (plms.py:192-197, 218-226, 235-244);
+  * the constant [2B,77,D] CFG context concat (plms.py:194) is built once, not every step, and its
+    cross-attention K/V projections are cached inside the UNet;
+  * per-step scalars are host floats (no `ms.numpy.full` tensors, plms.py:212-215).
+Results are identical in structure to the reference (S+1 UNet calls for PLMS, intermediates dict,
+callbacks once per step).
+"""
+import numpy as np
+import torch
+
+from .... import ops
+from ...._lib import MdxError
+from ...modules.diffusionmodules.util import make_ddim_sampling_parameters, make_ddim_timesteps
+
+
+def _first_tensor(c):
+    while isinstance(c, (dict, list, tuple)):
+        c = c[list(c.keys())[0]] if isinstance(c, dict) else c[0]
+    return c
+
+
+class _SamplerBase:
+    """Shared loop for PLMSSampler (multistep) and DDIMSampler (single step)."""
+
+    multistep = True
+
+    def __init__(self, model, schedule="linear", **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+        self.verbose_print = kwargs.get("verbose_print", False)
+        self.generator = kwargs.get("generator", None)
+
+    # ---- plms.py:34-67
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        if self.multistep and ddim_eta != 0:
+            raise ValueError('ddim_eta must be 0 for PLMS')
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discr_method=ddim_discretize,
+                                                  num_ddim_timesteps=ddim_num_steps,
+                                                  num_ddpm_timesteps=self.ddpm_num_timesteps,
+                                                  verbose=verbose and self.verbose_print)
+        alphas_cumprod = np.asarray(self.model.alphas_cumprod, dtype=np.float32)
+        assert alphas_cumprod.shape[0] == self.ddpm_num_timesteps, 'alphas have to be defined for each timestep'
+        self.betas = self.model.betas
+        self.alphas_cumprod = alphas_cumprod
+        self.alphas_cumprod_prev = np.asarray(self.model.alphas_cumprod_prev, dtype=np.float32)
+        self.sqrt_alphas_cumprod = np.sqrt(alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1. - alphas_cumprod)
+        self.log_one_minus_alphas_cumprod = np.log(1. - alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1. / alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1. / alphas_cumprod - 1)
+        ddim_sigmas, ddim_alphas, ddim_alphas_prev = make_ddim_sampling_parameters(
+            alphacums=alphas_cumprod, ddim_timesteps=self.ddim_timesteps, eta=ddim_eta,
+            verbose=verbose and self.verbose_print)
+        self.ddim_sigmas = ddim_sigmas
+        self.ddim_alphas = ddim_alphas
+        self.ddim_alphas_prev = ddim_alphas_prev
+        self.ddim_sqrt_one_minus_alphas = np.sqrt(1. - ddim_alphas).astype(np.float32)
+        self.ddim_sigmas_for_original_num_steps = np.float32(ddim_eta) * np.sqrt(
+            (1 - self.alphas_cumprod_prev) / (1 - self.alphas_cumprod) *
+            (1 - self.alphas_cumprod / self.alphas_cumprod_prev))
+
+    # ---- plms.py:69-122
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None,
+               img_callback=None, quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0.,
+               score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100,
+               unconditional_guidance_scale=1., unconditional_conditioning=None, **kwargs):
+        if conditioning is not None:
+            cbs = _first_tensor(conditioning).shape[0]
+            if cbs != batch_size:
+                print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        C, H, W = shape
+        size = (batch_size, C, H, W)
+        if verbose:
+            print(f'Data shape for {type(self).__name__} sampling is {size}')
+        return self.plms_sampling(conditioning, size, callback=callback, img_callback=img_callback,
+                                  quantize_denoised=quantize_x0, mask=mask, x0=x0, ddim_use_original_steps=False,
+                                  noise_dropout=noise_dropout, temperature=temperature,
+                                  score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, x_T=x_T,
+                                  log_every_t=log_every_t,
+                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning, verbose=verbose)
+
+    # ---- model call: prefer the NHWC fast path of our LatentDiffusion; any object with the reference's
+    #      apply_model(x, t, cond) -> NCHW eps still works (its output is re-laid-out by a HIP kernel).
+    def _eps_nhwc(self, x, t, cond):
+        if hasattr(self.model, "apply_model_nhwc"):
+            return self.model.apply_model_nhwc(x, t, cond), None
+        e = self.model.apply_model(x, t, cond)
+        e = e.to(torch.float32).contiguous()
+        buf = ops.nchw_to_nhwc(e, 8)
+        return buf, buf
+
+    # ---- plms.py:124-179 + 182-247
+    def plms_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None, timesteps=None,
+                      quantize_denoised=False, mask=None, x0=None, img_callback=None, log_every_t=100,
+                      temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, verbose=True):
+        if ddim_use_original_steps or timesteps is not None:
+            raise NotImplementedError("ddim_use_original_steps / timesteps subsets are not used by the reference's CLIs")
+        if mask is not None or x0 is not None:
+            raise NotImplementedError("mask/x0 blending is the inpainting path (WK/inpaint.py): SURVEY 8(f) 'next'")
+        if quantize_denoised or score_corrector is not None or noise_dropout > 0.:
+            raise NotImplementedError("quantize_x0 / score_corrector / noise_dropout are never set by the reference's CLIs")
+        cond = _first_tensor(cond)
+        uc = _first_tensor(unconditional_conditioning) if unconditional_conditioning is not None else None
+        if not (isinstance(cond, torch.Tensor) and cond.is_cuda):
+            raise MdxError("conditioning must be a CUDA(HIP) tensor [B, T, context_dim]")
+        dev = cond.device
+        b = shape[0]
+        if x_T is None:
+            img = torch.randn(shape, device=dev, dtype=torch.float32, generator=self.generator)
+        else:
+            img = torch.as_tensor(x_T).to(device=dev, dtype=torch.float32).contiguous().clone()
+        ts = self.ddim_timesteps
+        time_range = np.flip(ts)
+        total_steps = ts.shape[0]
+        if verbose:
+            print(f"Running {type(self).__name__} Sampling with {total_steps} timesteps")
+        scale = float(unconditional_guidance_scale)
+        use_cfg = not (uc is None or scale == 1.)
+        if use_cfg:
+            c_in = torch.cat([uc.to(cond.dtype), cond], 0).contiguous()   # built ONCE (plms.py:194 rebuilds it per step)
+            x_in = torch.empty((2 * b,) + tuple(shape[1:]), device=dev, dtype=torch.float32)
+        else:
+            c_in = cond.contiguous()
+            x_in = None
+        nb = 2 * b if use_cfg else b
+        # per-step timestep vectors, fp32 on the device (the UNet's sinusoid takes float timesteps, util.py:111-131)
+        t_all = torch.as_tensor(np.ascontiguousarray(time_range), dtype=torch.float32, device=dev)
+        t_all = t_all[:, None].expand(total_steps, nb).contiguous()
+
+        alphas, alphas_prev = self.ddim_alphas, self.ddim_alphas_prev
+        sqrt_one_minus_alphas, sigmas = self.ddim_sqrt_one_minus_alphas, self.ddim_sigmas
+        intermediates = {'x_inter': [img.clone()], 'pred_x0': [img.clone()]}
+        pool = [torch.empty_like(img) for _ in range(4)]  # eps history buffers (3 live + 1 being written)
+        hist = []                                         # newest first; at most 3 (plms.py:169-171)
+        pred_x0 = torch.empty_like(img)
+        x_next = torch.empty_like(img)
+
+        def model_eps(x, t_row):
+            if use_cfg:
+                x_in[:b].copy_(x)
+                x_in[b:].copy_(x)
+                eps, keep = self._eps_nhwc(x_in, t_row, c_in)
+                return eps[:b], eps[b:], keep           # batch = [uncond ; cond] (plms.py:192-195)
+            eps, keep = self._eps_nhwc(x, t_row, c_in)
+            return None, eps, keep
+
+        def step(x, eps_u, eps_c, index, coef, olds, e_out, x_out, p_out):
+            a_t, a_prev = np.float32(alphas[index]), np.float32(alphas_prev[index])
+            sigma_t = np.float32(sigmas[index])
+            noise = None
+            if float(sigma_t) != 0.0:
+                noise = torch.randn(x.shape, device=dev, dtype=torch.float32, generator=self.generator) * temperature
+            ops.sampler_step(x, eps_u, eps_c, eps_c.shape[-1], scale, olds, coef,
+                             np.sqrt(a_t), np.float32(sqrt_one_minus_alphas[index]), np.sqrt(a_prev),
+                             np.sqrt(np.float32(1.) - a_prev - sigma_t ** 2), sigma_t, noise, e_out, x_out, p_out)
+
+        for i, step_t in enumerate(time_range):
+            index = total_steps - i - 1
+            eps_u, eps_c, _keep = model_eps(img, t_all[i])
+            if not self.multistep:
+                step(img, eps_u, eps_c, index, (1., 0., 0., 0.), [], None, x_next, pred_x0)
+            else:
+                e_buf = pool.pop()
+                n_old = len(hist)
+                if n_old == 0:
+                    # Pseudo Improved Euler (2nd order), plms.py:231-235: S+1 UNet calls in total
+                    step(img, eps_u, eps_c, index, (1., 0., 0., 0.), [], e_buf, x_next, None)
+                    eps_u2, eps_c2, _keep2 = model_eps(x_next, t_all[min(i + 1, total_steps - 1)])
+                    step(img, eps_u2, eps_c2, index, (.5, .5, 0., 0.), [e_buf], None, x_next, pred_x0)
+                elif n_old == 1:  # Adams-Bashforth 2, plms.py:236-238
+                    step(img, eps_u, eps_c, index, (3. / 2, -1. / 2, 0., 0.), hist[:1], e_buf, x_next, pred_x0)
+                elif n_old == 2:  # AB-3, plms.py:239-241
+                    step(img, eps_u, eps_c, index, (23. / 12, -16. / 12, 5. / 12, 0.), hist[:2], e_buf, x_next,
+                         pred_x0)
+                else:             # AB-4, plms.py:242-244
+                    step(img, eps_u, eps_c, index, (55. / 24, -59. / 24, 37. / 24, -9. / 24), hist[:3], e_buf,
+                         x_next, pred_x0)
+                hist.insert(0, e_buf)
+                if len(hist) > 3:
+                    pool.append(hist.pop())
+            img, x_next = x_next, img
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total_steps - 1:
+                intermediates['x_inter'].append(img.clone())
+                intermediates['pred_x0'].append(pred_x0.clone())
+        return img, intermediates
+
+
+class PLMSSampler(_SamplerBase):
+    """Reference: ldm/models/diffusion/plms.py:27 ``class PLMSSampler``."""
+    multistep = True

@@ -1,0 +1,643 @@
+"""UNetModel -- MI355X-native mirror of the reference's
+vision/stablediffusionv2/ldm/modules/diffusionmodules/openaimodel.py:245-577 (and the Wukong copy).
+
+Same constructor keywords (the ``unet_config.params`` keys of the reference YAMLs) and the same
+``construct(x, timesteps, context)`` call; parameters are loaded by the reference's names
+ via ``load_state_dict``.  Execution is completely different from the
+reference's per-primitive MindSpore graph:
+
+  * activations live in HBM as NHWC fp16 ([B, H*W, C] == token-major), so SpatialTransformer's
+    NCHW<->NLC transposes (attention.py:243-253) vanish and every conv is an implicit GEMM;
+  * the forward pass is PLANNED once per (B, H, W): a flat list of C-ABI kernel calls on
+    pre-allocated, liveness-reused buffers (static addresses => capturable as ONE hipGraph);
+  * Concat of skip connections (openaimodel.py:568) is never materialised (two-source kernels),
+    nearest-2x Upsample is folded into the following conv's gather, the ResBlock time-embedding
+    add / bias / residual adds / GEGLU are GEMM epilogues;
+  * cross-attention K / V^T of the text context (constant over the sampling loop) are cached.
+
+There is no CPU path: every op is a HIP kernel from libmdx.so.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from .... import ops
+from ...._lib import MdxError
+
+f16, f32 = torch.float16, torch.float32
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Arena:
+    """Liveness-based buffer reuse at PLAN time (exact-size buckets).  Execution never allocates."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free = {}
+        self.total = 0
+
+    def get(self, shape, dtype=f16):
+        n = int(np.prod(shape))
+        nbytes = _round_up(n * torch.empty((), dtype=dtype).element_size(), 256)
+        lst = self.free.get(nbytes)
+        if lst:
+            base = lst.pop()
+        else:
+            base = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.total += nbytes
+        t = base[: n * torch.empty((), dtype=dtype).element_size()].view(dtype).view(*shape)
+        t._mdx_base = base
+        return t
+
+    def release(self, t):
+        base = t._mdx_base
+        self.free.setdefault(base.numel(), []).append(base)
+
+
+class UNetModel:
+    def __init__(self, image_size=32, in_channels=4, model_channels=320, out_channels=4, num_res_blocks=2,
+                 attention_resolutions=(4, 2, 1), dropout=0.0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2,
+                 num_classes=None, use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1,
+                 num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
+                 use_new_attention_order=False, use_spatial_transformer=False, transformer_depth=1, context_dim=None,
+                 n_embed=None, legacy=True, use_linear_in_transformer=False, device="cuda:0"):
+        # openaimodel.py:305-321 argument checks
+        if use_spatial_transformer:
+            assert context_dim is not None, "context_dim is required with use_spatial_transformer"
+        if context_dim is not None:
+            assert use_spatial_transformer, "context_dim requires use_spatial_transformer"
+        if num_heads == -1:
+            assert num_head_channels != -1, "Either num_heads or num_head_channels has to be set"
+        if num_head_channels == -1:
+            assert num_heads != -1, "Either num_heads or num_head_channels has to be set"
+        if not use_spatial_transformer:
+            raise NotImplementedError("AttentionBlock is an empty stub in the reference (openaimodel.py:208-242)")
+        if dims != 2 or num_classes is not None or use_scale_shift_norm or resblock_updown or transformer_depth != 1 \
+                or n_embed is not None or not conv_resample:
+            raise NotImplementedError("configuration outside the reference's shipped SD / Wukong YAMLs")
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = list(attention_resolutions)
+        self.channel_mult = list(channel_mult)
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        self.context_dim = int(context_dim)
+        self.legacy = legacy
+        self.use_linear = use_linear_in_transformer
+        self.use_fp16 = use_fp16
+        self.device = torch.device(device)
+        self.time_embed_dim = model_channels * 4
+        self.input_blocks, self.middle_block, self.output_blocks = self._structure()
+        self.cin_pad = _round_up(in_channels, 8)
+        self.cout_pad = _round_up(out_channels, 8)
+        self.w = None          # packed device weights
+        self._plans = {}
+        self._ctx_key = None
+        self.use_graph = True
+        self.max_context_len = 80  # 77 CLIP tokens rounded up to a multiple of 8 (V^T rows are 16-B chunked)
+        self.last_launch_count = 0
+
+    # ------------------------------------------------------------------ structure (openaimodel.py:351-526)
+    def _heads(self, ch, num_heads):
+        if self.num_head_channels == -1:
+            dim_head = ch // num_heads
+        else:
+            num_heads = ch // self.num_head_channels
+            dim_head = self.num_head_channels
+        if self.legacy:
+            dim_head = ch // num_heads  # use_spatial_transformer branch of openaimodel.py:375-376
+        return num_heads, dim_head
+
+    def _structure(self):
+        mc = self.model_channels
+        nh = self.num_heads
+        inb = [[("conv", self.in_channels, mc)]]
+        chans = [mc]
+        ch, ds = mc, 1
+        for level, mult in enumerate(self.channel_mult):
+            for _ in range(self.num_res_blocks):
+                layers = [("res", ch, mult * mc)]
+                ch = mult * mc
+                if ds in self.attention_resolutions:
+                    nh, dh = self._heads(ch, nh)
+                    layers.append(("st", ch, nh, dh))
+                inb.append(layers)
+                chans.append(ch)
+            if level != len(self.channel_mult) - 1:
+                inb.append([("down", ch)])
+                chans.append(ch)
+                ds *= 2
+        nh, dh = self._heads(ch, nh)
+        mid = [("res", ch, ch), ("st", ch, nh, dh), ("res", ch, ch)]
+        outb = []
+        for level, mult in list(enumerate(self.channel_mult))[::-1]:
+            for i in range(self.num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [("res", ch + ich, mc * mult)]
+                ch = mc * mult
+                if ds in self.attention_resolutions:
+                    nh, dh = self._heads(ch, nh)
+                    layers.append(("st", ch, nh, dh))
+                if level and i == self.num_res_blocks:
+                    layers.append(("up", ch))
+                    ds //= 2
+                outb.append(layers)
+        return inb, mid, outb
+
+    def _named_layers(self):
+        for i, blk in enumerate(self.input_blocks):
+            for j, layer in enumerate(blk):
+                yield f"input_blocks.{i}.{j}.", layer
+        for j, layer in enumerate(self.middle_block):
+            yield f"middle_block.{j}.", layer
+        for i, blk in enumerate(self.output_blocks):
+            for j, layer in enumerate(blk):
+                yield f"output_blocks.{i}.{j}.", layer
+
+    def parameter_shapes(self):
+        """name -> shape, in the reference's naming."""
+        mc, ted, ctx = self.model_channels, self.time_embed_dim, self.context_dim
+        s = {"time_embed.0.weight": (ted, mc), "time_embed.0.bias": (ted,),
+             "time_embed.2.weight": (ted, ted), "time_embed.2.bias": (ted,)}
+        for pre, layer in self._named_layers():
+            kind = layer[0]
+            if kind == "conv":
+                s[pre + "conv.weight"] = (layer[2], layer[1], 3, 3)
+                s[pre + "conv.bias"] = (layer[2],)
+            elif kind == "res":
+                cin, cout = layer[1], layer[2]
+                s[pre + "in_layers_norm.gamma"] = (cin,)
+                s[pre + "in_layers_norm.beta"] = (cin,)
+                s[pre + "in_layers_conv.conv.weight"] = (cout, cin, 3, 3)
+                s[pre + "in_layers_conv.conv.bias"] = (cout,)
+                s[pre + "emb_layers.1.weight"] = (cout, ted)
+                s[pre + "emb_layers.1.bias"] = (cout,)
+                s[pre + "out_layers_norm.gamma"] = (cout,)
+                s[pre + "out_layers_norm.beta"] = (cout,)
+                s[pre + "out_layers_conv.conv.weight"] = (cout, cout, 3, 3)
+                s[pre + "out_layers_conv.conv.bias"] = (cout,)
+                if cin != cout:
+                    s[pre + "skip_connection.conv.weight"] = (cout, cin, 1, 1)
+                    s[pre + "skip_connection.conv.bias"] = (cout,)
+            elif kind == "st":
+                ch, inner = layer[1], layer[2] * layer[3]
+                s[pre + "norm.gamma"] = (ch,)
+                s[pre + "norm.beta"] = (ch,)
+                s[pre + "proj_in.weight"] = (inner, ch) if self.use_linear else (inner, ch, 1, 1)
+                s[pre + "proj_in.bias"] = (inner,)
+                s[pre + "proj_out.weight"] = (ch, inner) if self.use_linear else (ch, inner, 1, 1)
+                s[pre + "proj_out.bias"] = (ch,)
+                t = pre + "transformer_blocks.0."
+                for a, cd in (("attn1.", inner), ("attn2.", ctx)):
+                    s[t + a + "to_q.weight"] = (inner, inner)
+                    s[t + a + "to_k.weight"] = (inner, cd)
+                    s[t + a + "to_v.weight"] = (inner, cd)
+                    s[t + a + "to_out.0.weight"] = (inner, inner)
+                    s[t + a + "to_out.0.bias"] = (inner,)
+                s[t + "ff.net.0.proj.weight"] = (inner * 8, inner)
+                s[t + "ff.net.0.proj.bias"] = (inner * 8,)
+                s[t + "ff.net.2.weight"] = (inner, inner * 4)
+                s[t + "ff.net.2.bias"] = (inner,)
+                for n in ("norm1", "norm2", "norm3"):
+                    s[t + n + ".gamma"] = (inner,)
+                    s[t + n + ".beta"] = (inner,)
+            elif kind == "down":
+                s[pre + "op.conv.weight"] = (layer[1], layer[1], 3, 3)
+                s[pre + "op.conv.bias"] = (layer[1],)
+            elif kind == "up":
+                s[pre + "conv.conv.weight"] = (layer[1], layer[1], 3, 3)
+                s[pre + "conv.conv.bias"] = (layer[1],)
+        s["out.0.gamma"] = (mc,)
+        s["out.0.beta"] = (mc,)
+        s["out.2.conv.weight"] = (self.out_channels, mc, 3, 3)
+        s["out.2.conv.bias"] = (self.out_channels,)
+        return s
+
+    # ------------------------------------------------------------------ weights
+    def _dev(self, a, dtype):
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def _pack_conv(self, wt, cin_pad=None, cout_pad=None):
+        """[Cout,Cin,kh,kw] -> fp16 [Cout_pad][kh*kw*Cin_pad] (tap-major, cin-minor)."""
+        wt = wt if isinstance(wt, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(wt))
+        wt = wt.to(self.device, f32)
+        co, ci, kh, kw = wt.shape
+        cip = cin_pad or ci
+        cop = cout_pad or co
+        p = torch.zeros((cop, kh * kw, cip), dtype=f32, device=self.device)
+        p[:co, :, :ci] = wt.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
+        return p.reshape(cop, kh * kw * cip).to(f16).contiguous()
+
+    def _pad_vec(self, v, n):
+        v = self._dev(v, f32)
+        if v.numel() == n:
+            return v
+        out = torch.zeros(n, dtype=f32, device=self.device)
+        out[: v.numel()] = v
+        return out
+
+    def load_state_dict(self, params, strict=True):
+        """params: name -> array/tensor keyed by the reference's parameter names.  Packs everything into
+        the kernels' layouts on the device (fp16 weights, fp32 biases / norm affine)."""
+        shapes = self.parameter_shapes()
+        if strict:
+            missing = [k for k in shapes if k not in params]
+            if missing:
+                raise KeyError(f"missing parameters: {missing[:5]} ... ({len(missing)} total)")
+        for k, shp in shapes.items():
+            if tuple(params[k].shape) != tuple(shp):
+                raise ValueError(f"{k}: expected shape {shp}, got {tuple(params[k].shape)}")
+        P = params
+        w = {}
+        w["te0.w"] = self._dev(P["time_embed.0.weight"], f16)
+        w["te0.b"] = self._dev(P["time_embed.0.bias"], f32)
+        w["te2.w"] = self._dev(P["time_embed.2.weight"], f16)
+        w["te2.b"] = self._dev(P["time_embed.2.bias"], f32)
+        emb_w, emb_b, self._emb_off = [], [], {}
+        off = 0
+        for pre, layer in self._named_layers():
+            kind = layer[0]
+            if kind == "conv":
+                w[pre + "w"] = self._pack_conv(P[pre + "conv.weight"], cin_pad=self.cin_pad)
+                w[pre + "b"] = self._dev(P[pre + "conv.bias"], f32)
+            elif kind == "res":
+                cin, cout = layer[1], layer[2]
+                for n in ("in_layers_norm", "out_layers_norm"):
+                    w[pre + n + ".g"] = self._dev(P[pre + n + ".gamma"], f32)
+                    w[pre + n + ".b"] = self._dev(P[pre + n + ".beta"], f32)
+                w[pre + "conv1.w"] = self._pack_conv(P[pre + "in_layers_conv.conv.weight"])
+                w[pre + "conv1.b"] = self._dev(P[pre + "in_layers_conv.conv.bias"], f32)
+                w[pre + "conv2.w"] = self._pack_conv(P[pre + "out_layers_conv.conv.weight"])
+                w[pre + "conv2.b"] = self._dev(P[pre + "out_layers_conv.conv.bias"], f32)
+                if cin != cout:
+                    w[pre + "skip.w"] = self._pack_conv(P[pre + "skip_connection.conv.weight"])
+                    w[pre + "skip.b"] = self._dev(P[pre + "skip_connection.conv.bias"], f32)
+                emb_w.append(self._dev(P[pre + "emb_layers.1.weight"], f16))
+                emb_b.append(self._dev(P[pre + "emb_layers.1.bias"], f32))
+                self._emb_off[pre] = off
+                off += cout
+            elif kind == "st":
+                inner = layer[2] * layer[3]
+                w[pre + "norm.g"] = self._dev(P[pre + "norm.gamma"], f32)
+                w[pre + "norm.b"] = self._dev(P[pre + "norm.beta"], f32)
+                for n in ("proj_in", "proj_out"):
+                    wt = self._dev(P[pre + n + ".weight"], f16)
+                    w[pre + n + ".w"] = wt.reshape(wt.shape[0], wt.shape[1]).contiguous()  # 1x1 conv == Dense in NHWC
+                    w[pre + n + ".b"] = self._dev(P[pre + n + ".bias"], f32)
+                t = pre + "transformer_blocks.0."
+                # self-attention: fused [q | k] projection, separate (transposed-store) v projection
+                w[t + "attn1.qk.w"] = torch.cat([self._dev(P[t + "attn1.to_q.weight"], f16),
+                                                 self._dev(P[t + "attn1.to_k.weight"], f16)], 0).contiguous()
+                w[t + "attn1.v.w"] = self._dev(P[t + "attn1.to_v.weight"], f16)
+                w[t + "attn2.q.w"] = self._dev(P[t + "attn2.to_q.weight"], f16)
+                w[t + "attn2.k.w"] = self._dev(P[t + "attn2.to_k.weight"], f16)
+                w[t + "attn2.v.w"] = self._dev(P[t + "attn2.to_v.weight"], f16)
+                for a in ("attn1", "attn2"):
+                    w[t + a + ".o.w"] = self._dev(P[t + a + ".to_out.0.weight"], f16)
+                    w[t + a + ".o.b"] = self._dev(P[t + a + ".to_out.0.bias"], f32)
+                # GEGLU (attention.py:41-51): interleave 64 'x' rows with their 64 'gate' rows per 128-wide tile
+                gw = self._dev(P[t + "ff.net.0.proj.weight"], f16)
+                gb = self._dev(P[t + "ff.net.0.proj.bias"], f32)
+                half = 4 * inner
+                assert half % 64 == 0
+                nt = half // 64
+                w[t + "ff1.w"] = torch.stack([gw[:half].reshape(nt, 64, inner), gw[half:].reshape(nt, 64, inner)], 1) \
+                    .reshape(2 * half, inner).contiguous()
+                w[t + "ff1.b"] = torch.stack([gb[:half].reshape(nt, 64), gb[half:].reshape(nt, 64)], 1).reshape(-1).contiguous()
+                w[t + "ff2.w"] = self._dev(P[t + "ff.net.2.weight"], f16)
+                w[t + "ff2.b"] = self._dev(P[t + "ff.net.2.bias"], f32)
+                for n in ("norm1", "norm2", "norm3"):
+                    w[t + n + ".g"] = self._dev(P[t + n + ".gamma"], f32)
+                    w[t + n + ".b"] = self._dev(P[t + n + ".beta"], f32)
+            elif kind == "down":
+                w[pre + "w"] = self._pack_conv(P[pre + "op.conv.weight"])
+                w[pre + "b"] = self._dev(P[pre + "op.conv.bias"], f32)
+            elif kind == "up":
+                w[pre + "w"] = self._pack_conv(P[pre + "conv.conv.weight"])
+                w[pre + "b"] = self._dev(P[pre + "conv.conv.bias"], f32)
+        w["emb.w"] = torch.cat(emb_w, 0).contiguous()
+        w["emb.b"] = torch.cat(emb_b, 0).contiguous()
+        self._emb_total = off
+        w["out.g"] = self._dev(P["out.0.gamma"], f32)
+        w["out.b"] = self._dev(P["out.0.beta"], f32)
+        w["out.w"] = self._pack_conv(P["out.2.conv.weight"], cout_pad=self.cout_pad)
+        w["out.cb"] = self._pad_vec(P["out.2.conv.bias"], self.cout_pad)
+        self.w = w
+        self._plans = {}
+        self._ctx_key = None
+        return self
+
+    def weight_bytes(self):
+        return sum(t.numel() * t.element_size() for t in self.w.values())
+
+    # ------------------------------------------------------------------ planning
+    class _Plan:
+        pass
+
+    def _plan(self, B, H, W):
+        key = (B, H, W)
+        if key in self._plans:
+            return self._plans[key]
+        if self.w is None:
+            raise MdxError("UNetModel: load_state_dict() must be called before the first forward")
+        for lvl in range(len(self.channel_mult) - 1):
+            if (H >> lvl) % 2 or (W >> lvl) % 2:
+                raise MdxError(f"UNetModel: latent {H}x{W} is not divisible by 2^{len(self.channel_mult) - 1}")
+        dev = self.device
+        w = self.w
+        P = UNetModel._Plan()
+        A = _Arena(dev)
+        main, ctxops, descs = [], [], []
+        gn_need = [0]
+        P.x_static = torch.zeros((B, self.in_channels, H, W), dtype=f32, device=dev)
+        P.t_static = torch.zeros((B,), dtype=f32, device=dev)
+        TC = self.max_context_len
+        P.B, P.H, P.W = B, H, W
+
+        def add_gemm(oplist, **kw):
+            d = ops.make_gemm_desc(**kw)
+            descs.append(d)
+            oplist.append(lambda d=d: ops.gemm_run(d))
+
+        gn_calls = []
+
+        def add_gn(x1, x2, g, b, eps, silu, out):
+            Bq, HW, C1 = x1.shape
+            C2 = 0 if x2 is None else x2.shape[2]
+            gn_need[0] = max(gn_need[0], ops.groupnorm_ws_floats(Bq, HW, C1 + C2))
+            call = dict(x1=x1, x2=x2, g=g, b=b, eps=eps, silu=silu, out=out)
+            gn_calls.append(call)
+            main.append(lambda c=call: ops.groupnorm(c["x1"], c["x2"], c["g"], c["b"], c["eps"], c["silu"], ws=P.gn_ws, out=c["out"]))
+
+        # ---- time embedding (openaimodel.py:550-551, 150-157): 4 tiny launches
+        mc, ted = self.model_channels, self.time_embed_dim
+        t_emb = torch.empty((B, mc), dtype=f32, device=dev)
+        e1 = torch.empty((B, ted), dtype=f32, device=dev)
+        emb = torch.empty((B, ted), dtype=f32, device=dev)
+        P.emb_all = torch.empty((B, self._emb_total), dtype=f32, device=dev)
+        main.append(lambda: ops.timestep_embedding(P.t_static, mc, out=t_emb))
+        main.append(lambda: ops.dense_small(t_emb, w["te0.w"], w["te0.b"], act_out=True, out=e1))
+        main.append(lambda: ops.dense_small(e1, w["te2.w"], w["te2.b"], out=emb))
+        main.append(lambda: ops.dense_small(emb, w["emb.w"], w["emb.b"], act_in=True, out=P.emb_all))
+
+        xin = A.get((B, H * W, self.cin_pad))
+        main.append(lambda: ops.nchw_to_nhwc(P.x_static, self.cin_pad, out=xin))
+
+        P.ctx_pad = None
+        ctx_kv = {}
+
+        def conv3(src, cin, cout, wt, bias, h, wd, stride=1, upsample=0, rowbias=None, residual=None, src2=None, c2=0):
+            hs, ws_ = (2 * h, 2 * wd) if upsample else (h, wd)
+            ho, wo = (hs + 2 - 3) // stride + 1, (ws_ + 2 - 3) // stride + 1
+            out = A.get((B, ho * wo, cout))
+            add_gemm(main, a=src, w=wt, N=cout, B=B, H=h, W=wd, c1=cin - c2, out=out, out_ld=cout, a2=src2, c2=c2,
+                     bias=bias, rowbias=rowbias, rowbias_ld=self._emb_total if rowbias is not None else 0,
+                     residual=residual, residual_ld=cout if residual is not None else 0, ksize=3, stride=stride,
+                     upsample=upsample)
+            return out, ho, wo
+
+        def dense(oplist, src, rows_b, tokens, cin, nout, wt, bias=None, residual=None, epilogue=ops.EPI_NONE,
+                  out=None, out_ld=None, out_mode=ops.OUT_ROWMAJOR, src2=None, c2=0, arena=True):
+            cols = nout // 2 if epilogue == ops.EPI_GEGLU else nout
+            if out is None:
+                out = A.get((rows_b, tokens, cols))
+                out_ld = cols
+            add_gemm(oplist, a=src, w=wt, N=nout, B=rows_b, H=tokens, W=1, c1=cin - c2, out=out, out_ld=out_ld,
+                     a2=src2, c2=c2, bias=bias, residual=residual, residual_ld=cols if residual is not None else 0,
+                     epilogue=epilogue, out_mode=out_mode)
+            return out
+
+        def resblock(pre, x, x2, cin, cout, h, wd):
+            """ResBlock.construct openaimodel.py:176-205; x2 = skip tensor of the (virtual) concat."""
+            c2 = 0 if x2 is None else x2.shape[2]
+            hw = h * wd
+            a = A.get((B, hw, cin))
+            add_gn(x, x2, w[pre + "in_layers_norm.g"], w[pre + "in_layers_norm.b"], 1e-5, True, a)
+            eoff = self._emb_off[pre]
+            rowbias = P.emb_all[:, eoff:eoff + cout]  # view: pointer = base + eoff, ld = emb_total
+            hbuf, _, _ = conv3(a, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd, rowbias=rowbias)
+            A.release(a)
+            a2 = A.get((B, hw, cout))
+            add_gn(hbuf, None, w[pre + "out_layers_norm.g"], w[pre + "out_layers_norm.b"], 1e-5, True, a2)
+            A.release(hbuf)
+            if cin != cout:
+                skip = dense(main, x, B, hw, cin, cout, w[pre + "skip.w"], bias=w[pre + "skip.b"], src2=x2, c2=c2)
+            else:
+                assert x2 is None
+                skip = x
+            out, _, _ = conv3(a2, cout, cout, w[pre + "conv2.w"], w[pre + "conv2.b"], h, wd, residual=skip)
+            A.release(a2)
+            if skip is not x:
+                A.release(skip)
+            return out
+
+        def transformer(pre, x, ch, heads, dh, h, wd):
+            """SpatialTransformer.construct attention.py:237-256 + BasicTransformerBlock :181-185 (NHWC == tokens)."""
+            n = h * wd
+            inner = heads * dh
+            scale = dh ** -0.5
+            t = pre + "transformer_blocks.0."
+            a = A.get((B, n, ch))
+            add_gn(x, None, w[pre + "norm.g"], w[pre + "norm.b"], 1e-6, False, a)
+            tok = dense(main, a, B, n, ch, inner, w[pre + "proj_in.w"], bias=w[pre + "proj_in.b"])
+            A.release(a)
+            # --- attn1 (self)
+            ln = A.get((B, n, inner))
+            main.append(lambda ln=ln, tok=tok: ops.layernorm(tok, w[t + "norm1.g"], w[t + "norm1.b"], 1e-5, out=ln))
+            qk = dense(main, ln, B, n, inner, 2 * inner, w[t + "attn1.qk.w"])
+            vt = A.get((B, inner, n))
+            dense(main, ln, B, n, inner, inner, w[t + "attn1.v.w"], out=vt, out_ld=n, out_mode=ops.OUT_TRANSPOSED)
+            o = ln  # reuse: ln is dead after the projections
+            main.append(lambda qk=qk, vt=vt, o=o: ops.attention(
+                qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
+                n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner))
+            tok2 = dense(main, o, B, n, inner, inner, w[t + "attn1.o.w"], bias=w[t + "attn1.o.b"], residual=tok)
+            A.release(qk); A.release(vt); A.release(tok)
+            # --- attn2 (cross): K / V^T of the context are produced by the context plan
+            main.append(lambda ln=ln, tok2=tok2: ops.layernorm(tok2, w[t + "norm2.g"], w[t + "norm2.b"], 1e-5, out=ln))
+            q2 = dense(main, ln, B, n, inner, inner, w[t + "attn2.q.w"])
+            kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
+            vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
+            ctx_kv[pre] = (kc, vtc)
+            main.append(lambda q2=q2, kc=kc, vtc=vtc, o=o: ops.attention(
+                q2.data_ptr(), kc.data_ptr(), vtc.data_ptr(), o.data_ptr(), B, heads, dh, n, P.ctx_len, scale,
+                n * inner, inner, TC * inner, inner, inner * TC, TC, n * inner, inner))
+            tok3 = dense(main, o, B, n, inner, inner, w[t + "attn2.o.w"], bias=w[t + "attn2.o.b"], residual=tok2)
+            A.release(q2); A.release(tok2)
+            # --- feed-forward (GEGLU fused in the first GEMM's epilogue)
+            main.append(lambda ln=ln, tok3=tok3: ops.layernorm(tok3, w[t + "norm3.g"], w[t + "norm3.b"], 1e-5, out=ln))
+            g = dense(main, ln, B, n, inner, 8 * inner, w[t + "ff1.w"], bias=w[t + "ff1.b"], epilogue=ops.EPI_GEGLU)
+            tok4 = dense(main, g, B, n, 4 * inner, inner, w[t + "ff2.w"], bias=w[t + "ff2.b"], residual=tok3)
+            A.release(g); A.release(tok3); A.release(ln)
+            out = dense(main, tok4, B, n, inner, ch, w[pre + "proj_out.w"], bias=w[pre + "proj_out.b"], residual=x)
+            A.release(tok4)
+            return out
+
+        # ---- context plan: to_k / to_v of attn2 for every SpatialTransformer (attention.py:119-121)
+        P.ctx_pad = torch.zeros((B, TC, self.context_dim), dtype=f16, device=dev)
+        P.ctx_len = 0
+
+        # ---- walk the UNet (openaimodel.py:556-576)
+        h, wd = H, W
+        hs = []
+        cur = None
+        for i, blk in enumerate(self.input_blocks):
+            for j, layer in enumerate(blk):
+                pre = f"input_blocks.{i}.{j}."
+                kind = layer[0]
+                if kind == "conv":
+                    cur, h, wd = conv3(xin, self.cin_pad, layer[2], w[pre + "w"], w[pre + "b"], h, wd)
+                    A.release(xin)
+                elif kind == "res":
+                    new = resblock(pre, cur, None, layer[1], layer[2], h, wd)
+                    if not any(cur is s[0] for s in hs):
+                        A.release(cur)
+                    cur = new
+                elif kind == "st":
+                    new = transformer(pre, cur, layer[1], layer[2], layer[3], h, wd)
+                    A.release(cur)
+                    cur = new
+                elif kind == "down":
+                    new, h2, w2 = conv3(cur, layer[1], layer[1], w[pre + "w"], w[pre + "b"], h, wd, stride=2)
+                    if not any(cur is s[0] for s in hs):
+                        A.release(cur)
+                    cur, h, wd = new, h2, w2
+            hs.append((cur, h, wd))
+        for j, layer in enumerate(self.middle_block):
+            pre = f"middle_block.{j}."
+            if layer[0] == "res":
+                new = resblock(pre, cur, None, layer[1], layer[2], h, wd)
+            else:
+                new = transformer(pre, cur, layer[1], layer[2], layer[3], h, wd)
+            if not any(cur is s[0] for s in hs):
+                A.release(cur)
+            cur = new
+        for i, blk in enumerate(self.output_blocks):
+            skip, sh, sw = hs.pop()
+            assert (sh, sw) == (h, wd)
+            for j, layer in enumerate(blk):
+                pre = f"output_blocks.{i}.{j}."
+                kind = layer[0]
+                if kind == "res":
+                    new = resblock(pre, cur, skip, layer[1], layer[2], h, wd)
+                    A.release(cur)
+                    A.release(skip)
+                    cur = new
+                elif kind == "st":
+                    new = transformer(pre, cur, layer[1], layer[2], layer[3], h, wd)
+                    A.release(cur)
+                    cur = new
+                elif kind == "up":
+                    new, h, wd = conv3(cur, layer[1], layer[1], w[pre + "w"], w[pre + "b"], h, wd, upsample=1)
+                    A.release(cur)
+                    cur = new
+        a = A.get((B, h * wd, mc))
+        add_gn(cur, None, w["out.g"], w["out.b"], 1e-5, True, a)
+        P.eps_nhwc = torch.empty((B, h * wd, self.cout_pad), dtype=f16, device=dev)
+        add_gemm(main, a=a, w=w["out.w"], N=self.cout_pad, B=B, H=h, W=wd, c1=mc, out=P.eps_nhwc, out_ld=self.cout_pad,
+                 bias=w["out.cb"], ksize=3)
+
+        for pre, (kc, vtc) in ctx_kv.items():
+            t = pre + "transformer_blocks.0."
+            inner = kc.shape[2]
+            add_gemm(ctxops, a=P.ctx_pad, w=w[t + "attn2.k.w"], N=inner, B=B, H=TC, W=1, c1=self.context_dim, out=kc,
+                     out_ld=inner)
+            add_gemm(ctxops, a=P.ctx_pad, w=w[t + "attn2.v.w"], N=inner, B=B, H=TC, W=1, c1=self.context_dim, out=vtc,
+                     out_ld=TC, out_mode=ops.OUT_TRANSPOSED)
+
+        # shared workspaces (sized for the hungriest op), patched into every descriptor
+        need = max([ops.gemm_workspace_bytes(d) for d in descs] + [0])
+        P.gemm_ws = torch.empty(max(need, 16) // 4, dtype=f32, device=dev)
+        for d in descs:
+            d.workspace = P.gemm_ws.data_ptr()
+            d.workspace_bytes = P.gemm_ws.numel() * 4
+        P.gn_ws = torch.empty(max(gn_need[0], 4), dtype=f32, device=dev)
+        P.main, P.ctxops, P.descs = main, ctxops, descs
+        P.arena_bytes = A.total
+        P.graph = None
+        P.graph_failed = False
+        self._plans[key] = P
+        return P
+
+    # ------------------------------------------------------------------ execution
+    def _ensure_context(self, P, context):
+        """Project the text context through every attn2.to_k / to_v once per context tensor: it is constant
+        across the sampling loop (the reference recomputes it at 16 sites x 51 calls)."""
+        key = (context.data_ptr(), context._version, tuple(context.shape), context.dtype, id(P))
+        if key == self._ctx_key:
+            return
+        Bc, T, Dc = context.shape
+        if Bc != P.B or Dc != self.context_dim:
+            raise MdxError(f"context shape {tuple(context.shape)} does not match batch {P.B} / context_dim {self.context_dim}")
+        if T > self.max_context_len:
+            raise MdxError(f"context length {T} > max_context_len={self.max_context_len}")
+        P.ctx_pad.zero_()
+        P.ctx_pad[:, :T].copy_(context)
+        P.ctx_len = T
+        for op in P.ctxops:
+            op()
+        self._ctx_key = key
+        # the attention ops read P.ctx_len at call time; a captured graph bakes it in
+        if P.graph is not None and getattr(P, "graph_ctx_len", None) != T:
+            P.graph = None
+
+    def forward_nhwc(self, x, timesteps, context):
+        """Run the UNet; returns the plan's static NHWC fp16 eps buffer [B, H*W, 8] (first 4 channels valid).
+        The buffer is overwritten by the next call."""
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            raise MdxError("UNetModel: x must be a CUDA(HIP) tensor (no CPU fallback)")
+        B, C, H, W = x.shape
+        if C != self.in_channels:
+            raise MdxError(f"UNetModel: expected {self.in_channels} input channels, got {C}")
+        P = self._plan(B, H, W)
+        self._ensure_context(P, context)
+        P.x_static.copy_(x)
+        P.t_static.copy_(timesteps.to(device=self.device, dtype=f32) if isinstance(timesteps, torch.Tensor)
+                         else torch.as_tensor(timesteps, dtype=f32, device=self.device))
+        if self.use_graph and not P.graph_failed:
+            if P.graph is None:
+                self._capture(P)
+            if P.graph is not None:
+                P.graph.replay()
+                return P.eps_nhwc
+        for op in P.main:
+            op()
+        self.last_launch_count = len(P.main)
+        return P.eps_nhwc
+
+    def _capture(self, P):
+        """Capture the whole forward as one hipGraph (kills ~450 launch gaps per call)."""
+        try:
+            for op in P.main:  # warm-up outside capture
+                op()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for op in P.main:
+                    op()
+            P.graph = g
+            P.graph_ctx_len = P.ctx_len
+        except Exception as e:  # pragma: no cover - depends on the runtime
+            P.graph = None
+            P.graph_failed = True
+            import warnings
+            warnings.warn(f"hipGraph capture failed, running eagerly: {e}")
+
+    def construct(self, x, timesteps=None, context=None, y=None):
+        """openaimodel.py:536-576.  x [N,C,H,W], timesteps [N], context [N,T,context_dim] -> eps [N,C,H,W] fp32."""
+        assert y is None, "class-conditional UNet is not part of the reference's shipped configs"
+        eps = self.forward_nhwc(x, timesteps, context)
+        B, _, H, W = x.shape
+        return ops.nhwc_to_nchw(eps, self.out_channels, H, W)
+
+    __call__ = construct
+    forward = construct

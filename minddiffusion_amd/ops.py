@@ -1,0 +1,194 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/mdx.h).  torch supplies device memory and
+the current HIP stream; all arithmetic happens in libmdx.so.  No CPU fallbacks."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, EPI_NONE, EPI_GEGLU, OUT_ROWMAJOR, OUT_TRANSPOSED  # noqa: F401
+
+f16 = torch.float16
+f32 = torch.float32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.MdxError(f"{name}: tensor must live on the GPU (no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.MdxError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.MdxError(f"{name}: tensor must be contiguous")
+
+
+def nchw_to_nhwc(x, cpad, out=None):
+    """[B,C,H,W] fp32 -> [B,H*W,cpad] fp16 (zero-padded channels)."""
+    _chk(x, f32, "x")
+    B, C, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, H * W, cpad), dtype=f16, device=x.device)
+    _lib.check(_lib.load().mdx_nchw_to_nhwc_f16(_ptr(x), _ptr(out), B, C, H, W, cpad, _stream()), "mdx_nchw_to_nhwc_f16")
+    return out
+
+
+def nhwc_to_nchw(x, C, H, W, out=None):
+    """[B,H*W,Cs] fp16 -> [B,C,H,W] fp32."""
+    _chk(x, f16, "x")
+    B, HW, Cs = x.shape
+    assert HW == H * W
+    if out is None:
+        out = torch.empty((B, C, H, W), dtype=f32, device=x.device)
+    _lib.check(_lib.load().mdx_nhwc_to_nchw_f32(_ptr(x), _ptr(out), B, C, H, W, Cs, _stream()), "mdx_nhwc_to_nchw_f32")
+    return out
+
+
+def groupnorm_ws_floats(B, HW, C, groups=32):
+    return int(_lib.load().mdx_groupnorm_ws_floats(B, HW, C, groups))
+
+
+def groupnorm(x1, x2, gamma, beta, eps, silu, ws=None, out=None, groups=32):
+    """GroupNorm(groups)(cat(x1,x2)) [+SiLU]; x* [B,HW,C*] fp16, gamma/beta fp32."""
+    _chk(x1, f16, "x1"); _chk(x2, f16, "x2"); _chk(gamma, f32, "gamma"); _chk(beta, f32, "beta")
+    B, HW, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[2]
+    C = C1 + C2
+    if ws is None:
+        ws = torch.empty(groupnorm_ws_floats(B, HW, C, groups), dtype=f32, device=x1.device)
+    if out is None:
+        out = torch.empty((B, HW, C), dtype=f16, device=x1.device)
+    _lib.check(_lib.load().mdx_groupnorm_f16(_ptr(x1), C1, _ptr(x2), C2, _ptr(gamma), _ptr(beta), _ptr(out), B, HW,
+                                             groups, float(eps), int(bool(silu)), _ptr(ws), _stream()),
+               "mdx_groupnorm_f16")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, out=None):
+    _chk(x, f16, "x"); _chk(gamma, f32, "gamma"); _chk(beta, f32, "beta")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.load().mdx_layernorm_f16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, C, float(eps), _stream()),
+               "mdx_layernorm_f16")
+    return out
+
+
+def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, rowbias=None, rowbias_ld=0,
+                   residual=None, residual_ld=0, ksize=1, stride=1, upsample=0, epilogue=EPI_NONE,
+                   out_mode=OUT_ROWMAJOR, splitk=0, workspace=None):
+    d = GemmDesc()
+    d.a = a.data_ptr()
+    d.a2 = 0 if a2 is None else a2.data_ptr()
+    d.c1, d.c2 = int(c1), int(c2)
+    d.w = w.data_ptr()
+    d.bias = 0 if bias is None else bias.data_ptr()
+    d.rowbias = 0 if rowbias is None else rowbias.data_ptr()
+    d.rowbias_ld = int(rowbias_ld)
+    d.residual = 0 if residual is None else residual.data_ptr()
+    d.residual_ld = int(residual_ld)
+    d.out = out.data_ptr()
+    d.out_ld = int(out_ld)
+    d.B, d.H, d.W, d.N = int(B), int(H), int(W), int(N)
+    d.ksize, d.stride, d.upsample = int(ksize), int(stride), int(upsample)
+    d.epilogue, d.out_mode, d.splitk = int(epilogue), int(out_mode), int(splitk)
+    d.workspace = 0 if workspace is None else workspace.data_ptr()
+    d.workspace_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    return d
+
+
+def gemm_workspace_bytes(desc):
+    return int(_lib.load().mdx_gemm_workspace_bytes(ctypes.byref(desc)))
+
+
+def gemm_run(desc):
+    _lib.check(_lib.load().mdx_gemm_f16(ctypes.byref(desc), _stream()), "mdx_gemm_f16")
+
+
+def gemm(a, w, N, B, H, W, c1, out=None, **kw):
+    """Convenience one-shot (tests): allocates output (row-major [M, out_cols]) and split-K workspace."""
+    _chk(a, f16, "a"); _chk(w, f16, "w")
+    ksize, stride, upsample = kw.get("ksize", 1), kw.get("stride", 1), kw.get("upsample", 0)
+    Hs, Ws = (2 * H, 2 * W) if upsample else (H, W)
+    pad = 1 if ksize == 3 else 0
+    Ho = (Hs + 2 * pad - ksize) // stride + 1
+    Wo = (Ws + 2 * pad - ksize) // stride + 1
+    M = B * Ho * Wo
+    epi = kw.get("epilogue", EPI_NONE)
+    out_mode = kw.get("out_mode", OUT_ROWMAJOR)
+    if out is None:
+        if out_mode == OUT_TRANSPOSED:
+            ld = kw.pop("out_ld", Ho * Wo)
+            out = torch.zeros((B, N, ld), dtype=f16, device=a.device)
+        else:
+            cols = N // 2 if epi == EPI_GEGLU else N
+            ld = kw.pop("out_ld", cols)
+            out = torch.empty((M, ld), dtype=f16, device=a.device)
+    else:
+        ld = kw.pop("out_ld")
+    d = make_gemm_desc(a, w, N, B, H, W, c1, out, ld, **kw)
+    if d.workspace == 0:
+        need = gemm_workspace_bytes(d)
+        if need:
+            ws = torch.empty(need // 4, dtype=f32, device=a.device)
+            d.workspace = ws.data_ptr()
+            d.workspace_bytes = need
+    gemm_run(d)
+    return out
+
+
+def attention(q_ptr, k_ptr, vt_ptr, o_ptr, B, heads, D, Nq, Nk, scale, q_bs, q_ld, k_bs, k_ld, vt_bs, vt_ld, o_bs, o_ld):
+    """Raw-pointer form (q/k may be column slices of one fused projection buffer); see include/mdx.h."""
+    _lib.check(_lib.load().mdx_attention_f16(ctypes.c_void_p(q_ptr), q_bs, q_ld, ctypes.c_void_p(k_ptr), k_bs, k_ld,
+                                             ctypes.c_void_p(vt_ptr), vt_bs, vt_ld, ctypes.c_void_p(o_ptr), o_bs, o_ld,
+                                             B, heads, D, Nq, Nk, float(scale), _stream()),
+               "mdx_attention_f16")
+
+
+def timestep_embedding(t, dim, max_period=10000.0, out=None):
+    _chk(t, f32, "t")
+    M = t.shape[0]
+    if out is None:
+        out = torch.empty((M, dim), dtype=f32, device=t.device)
+    _lib.check(_lib.load().mdx_timestep_embedding_f32(_ptr(t), _ptr(out), M, dim, float(max_period), _stream()),
+               "mdx_timestep_embedding_f32")
+    return out
+
+
+def dense_small(x, w, b, act_in=False, act_out=False, out=None):
+    """out[M,N] = act_out(act_in(x) @ w^T + b); x/out fp32, w fp16 [N,K]."""
+    _chk(x, f32, "x"); _chk(w, f16, "w"); _chk(b, f32, "b")
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=f32, device=x.device)
+    _lib.check(_lib.load().mdx_dense_small_f32(_ptr(x), x.stride(0), _ptr(w), _ptr(b), _ptr(out), out.stride(0), M, N, K,
+                                               int(act_in), int(act_out), _stream()), "mdx_dense_small_f32")
+    return out
+
+
+def sampler_step(x, eps_u, eps_c, eps_ld, cfg_scale, olds, coef, sqrt_at, sqrt_one_minus_at, sqrt_a_prev, dir_coef,
+                 sigma, noise, e_t_out, x_prev, pred_x0):
+    """Fused CFG + multistep mix + DDIM update (see include/mdx.h)."""
+    B, C, H, W = x.shape
+    c4 = (ctypes.c_float * 4)(*[float(v) for v in coef])
+    o = list(olds) + [None] * (3 - len(olds))
+    _lib.check(_lib.load().mdx_sampler_step_f32(
+        _ptr(x), _ptr(eps_u), _ptr(eps_c), int(eps_ld), float(cfg_scale), _ptr(o[0]), _ptr(o[1]), _ptr(o[2]),
+        ctypes.cast(c4, ctypes.c_void_p), float(sqrt_at), float(sqrt_one_minus_at), float(sqrt_a_prev), float(dir_coef),
+        float(sigma), _ptr(noise), _ptr(e_t_out), _ptr(x_prev), _ptr(pred_x0), B, C, H, W, _stream()),
+        "mdx_sampler_step_f32")
+
+
+def probe_mfma(a, b):
+    c = torch.empty((64, 16), dtype=f32, device=a.device)
+    _lib.check(_lib.load().mdx_probe_mfma_32x32x16_f16(_ptr(a), _ptr(b), _ptr(c), _stream()), "mdx_probe_mfma")
+    return c

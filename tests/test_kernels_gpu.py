@@ -1,0 +1,340 @@
+"""GPU parity tests, one kernel at a time, through the C-ABI (ctypes -> libmdx.so) against the fp32 CPU oracle.
+
+Inputs are rounded to fp16 first so both sides see identical operands; the kernels accumulate in fp32
+and store fp16, so the stated tolerances are fp16 output rounding (2^-11 relative) plus accumulation-order
+noise: rel-L2 <= 1e-3 for single kernels unless noted.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from _util import check, h16
+from oracle import ldm as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from minddiffusion_amd import ops as _ops
+    return _ops
+
+
+def dev16(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, torch.float16)
+
+
+def dev32(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, torch.float32)
+
+
+def nhwc(x):  # [B,C,H,W] -> [B,HW,C]
+    b, c, h, w = x.shape
+    return np.ascontiguousarray(x.transpose(0, 2, 3, 1).reshape(b, h * w, c))
+
+
+def from_nhwc(y, b, h, w):  # [B*HW, C] or [B,HW,C] -> [B,C,H,W]
+    y = y.reshape(b, h, w, -1)
+    return y.transpose(0, 3, 1, 2)
+
+
+def pack_conv(w):  # [Cout,Cin,kh,kw] -> [Cout, kh*kw*Cin]
+    co, ci, kh, kw = w.shape
+    return np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(co, kh * kw * ci))
+
+
+# --------------------------------------------------------------------------- hardware layout pin
+def test_mfma_32x32x16_layout(ops):
+    """Pins the fragment maps every MFMA kernel here assumes (cdna guide section 3):
+    A lane l: A[l&31][8*(l>>5)+j]; B lane l: B[8*(l>>5)+j][l&31]; C lane l reg r: C[(r&3)+8*(r>>2)+4*(l>>5)][l&31]."""
+    rng = np.random.RandomState(0)
+    A = h16(rng.standard_normal((32, 16)))
+    B = h16(rng.standard_normal((16, 32)))  # asymmetric on purpose
+    af = np.zeros((64, 8), np.float32)
+    bf = np.zeros((64, 8), np.float32)
+    for l in range(64):
+        for j in range(8):
+            af[l, j] = A[l & 31, 8 * (l >> 5) + j]
+            bf[l, j] = B[8 * (l >> 5) + j, l & 31]
+    c = ops.probe_mfma(dev16(af), dev16(bf)).cpu().numpy()
+    C = np.zeros((32, 32), np.float32)
+    for l in range(64):
+        for r in range(16):
+            C[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31] = c[l, r]
+    check("mfma_32x32x16_layout", C, A @ B, rel_l2=1e-6)
+
+
+# --------------------------------------------------------------------------- layout boundary
+def test_nchw_nhwc_roundtrip(ops):
+    x = np.random.RandomState(1).standard_normal((3, 4, 6, 10)).astype(np.float32)
+    y = ops.nchw_to_nhwc(dev32(x), 8)
+    assert y.shape == (3, 60, 8)
+    yn = y.float().cpu().numpy()
+    np.testing.assert_array_equal(yn[:, :, 4:], 0)
+    np.testing.assert_allclose(yn[:, :, :4], nhwc(h16(x)), atol=0)
+    back = ops.nhwc_to_nchw(y, 4, 6, 10).cpu().numpy()
+    np.testing.assert_array_equal(back, h16(x))
+
+
+# --------------------------------------------------------------------------- GroupNorm / LayerNorm
+@pytest.mark.parametrize("B,H,W,C1,C2,silu,eps", [
+    (2, 8, 8, 64, 0, True, 1e-5),
+    (1, 16, 16, 320, 0, True, 1e-5),
+    (2, 8, 8, 1280, 1280, True, 1e-5),      # two-source concat, C = 2560 > 256 chunk columns
+    (2, 16, 16, 640, 320, True, 1e-5),
+    (1, 5, 7, 320, 0, False, 1e-6),          # ragged pixel count, SpatialTransformer norm (no SiLU, eps 1e-6)
+    (1, 64, 64, 320, 0, True, 1e-5),
+])
+def test_groupnorm(ops, B, H, W, C1, C2, silu, eps):
+    rng = np.random.RandomState(C1 + C2 + H)
+    C = C1 + C2
+    x = h16(rng.standard_normal((B, C, H, W)) * 1.5 + 0.3)
+    g = rng.standard_normal(C).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    ref = O.group_norm(torch.tensor(x), torch.tensor(g), torch.tensor(b), eps)
+    if silu:
+        ref = O.silu(ref)
+    x1 = dev16(nhwc(x[:, :C1]))
+    x2 = dev16(nhwc(x[:, C1:])) if C2 else None
+    y = ops.groupnorm(x1, x2, dev32(g), dev32(b), eps, silu)
+    got = from_nhwc(y.float().cpu().numpy(), B, H, W)
+    check(f"groupnorm_B{B}_{H}x{W}_C{C1}+{C2}_silu{int(silu)}", got, ref, rel_l2=1e-3, max_abs=2e-2)
+
+
+@pytest.mark.parametrize("rows,C", [(7, 64), (130, 320), (64, 640), (33, 1280)])
+def test_layernorm(ops, rows, C):
+    rng = np.random.RandomState(rows)
+    x = h16(rng.standard_normal((rows, C)) * 2 + 0.5)
+    g = rng.standard_normal(C).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    ref = O.layer_norm(torch.tensor(x), torch.tensor(g), torch.tensor(b), 1e-5)
+    y = ops.layernorm(dev16(x), dev32(g), dev32(b), 1e-5)
+    check(f"layernorm_{rows}x{C}", y, ref, rel_l2=1e-3, max_abs=2e-2)
+
+
+# --------------------------------------------------------------------------- implicit GEMM: Dense
+@pytest.mark.parametrize("M,N,K,bias,res,splitk", [
+    (128, 128, 64, False, False, 1),
+    (256, 320, 320, True, True, 1),       # BN = 64 path (320 = 5 x 64)
+    (200, 136, 192, True, False, 1),      # ragged M and N tails
+    (512, 1280, 1280, True, True, 1),
+    (128, 1280, 2560, True, True, 4),     # explicit split-K
+    (64, 640, 5120, True, False, 0),      # auto split-K (small M, deep K)
+    (4096, 320, 1280, True, True, 1),
+])
+def test_gemm_dense(ops, M, N, K, bias, res, splitk):
+    rng = np.random.RandomState(M + N + K)
+    a = h16(rng.standard_normal((M, K)))
+    w = h16(rng.standard_normal((N, K)) / math.sqrt(K))
+    bv = rng.standard_normal(N).astype(np.float32) if bias else None
+    r = h16(rng.standard_normal((M, N))) if res else None
+    ref = a @ w.T
+    if bias:
+        ref = ref + bv
+    if res:
+        ref = ref + r
+    out = ops.gemm(dev16(a), dev16(w), N, 1, M, 1, K, bias=dev32(bv) if bias else None,
+                   residual=dev16(r) if res else None, residual_ld=N if res else 0, splitk=splitk)
+    check(f"gemm_dense_M{M}_N{N}_K{K}_b{int(bias)}_r{int(res)}_s{splitk}", out, ref, rel_l2=1e-3)
+
+
+def test_gemm_two_source_1x1(ops):
+    """ResBlock skip_connection on the (virtual) concat of h and the UNet skip tensor (openaimodel.py:174,568)."""
+    rng = np.random.RandomState(5)
+    B, H, W, C1, C2, N = 2, 8, 8, 128, 64, 192
+    x = h16(rng.standard_normal((B, C1 + C2, H, W)))
+    w = h16(rng.standard_normal((N, C1 + C2, 1, 1)) / 14)
+    bv = rng.standard_normal(N).astype(np.float32)
+    ref = O.conv2d(torch.tensor(x), torch.tensor(w), torch.tensor(bv), padding=0)
+    out = ops.gemm(dev16(nhwc(x[:, :C1])), dev16(pack_conv(w)), N, B, H, W, C1, a2=dev16(nhwc(x[:, C1:])), c2=C2,
+                   bias=dev32(bv))
+    check("gemm_two_source_1x1", from_nhwc(out.float().cpu().numpy(), B, H, W), ref, rel_l2=1e-3)
+
+
+# --------------------------------------------------------------------------- implicit GEMM: conv3x3
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up,splitk", [
+    (2, 8, 8, 64, 64, 1, 0, 1),
+    (1, 16, 16, 64, 128, 1, 0, 1),
+    (2, 16, 16, 128, 128, 2, 0, 1),     # Downsample (openaimodel.py:81)
+    (2, 8, 8, 128, 128, 1, 1, 1),       # Upsample: nearest-2x folded into the gather (openaimodel.py:57)
+    (1, 6, 10, 64, 72, 1, 0, 1),        # ragged spatial extent / N tail
+    (2, 8, 8, 320, 320, 1, 0, 0),       # auto split-K
+    (1, 32, 32, 320, 640, 1, 0, 1),
+    (1, 8, 8, 8, 64, 1, 0, 1),          # conv_in: Cin padded 4 -> 8, generic (non 64-aligned) K path
+    (1, 8, 8, 64, 8, 1, 0, 1),          # conv_out: Cout padded 4 -> 8
+])
+def test_gemm_conv3x3(ops, B, H, W, Cin, Cout, stride, up, splitk):
+    rng = np.random.RandomState(Cin + Cout + H + stride + up)
+    x = h16(rng.standard_normal((B, Cin, H, W)))
+    w = h16(rng.standard_normal((Cout, Cin, 3, 3)) / math.sqrt(9 * Cin))
+    bv = rng.standard_normal(Cout).astype(np.float32)
+    xin = torch.tensor(x)
+    if up:
+        xin = O.upsample_nearest2x(xin)
+    ref = O.conv2d(xin, torch.tensor(w), torch.tensor(bv), stride=stride, padding=1)
+    out = ops.gemm(dev16(nhwc(x)), dev16(pack_conv(w)), Cout, B, H, W, Cin, bias=dev32(bv), ksize=3, stride=stride,
+                   upsample=up, splitk=splitk)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    check(f"conv3x3_B{B}_{H}x{W}_{Cin}to{Cout}_s{stride}_u{up}_k{splitk}",
+          from_nhwc(out.float().cpu().numpy(), B, Ho, Wo), ref, rel_l2=1e-3)
+
+
+def test_gemm_conv_rowbias_residual(ops):
+    """conv1 of a ResBlock: + bias + per-sample time-embedding row (openaimodel.py:188-200); conv2: + skip."""
+    rng = np.random.RandomState(9)
+    B, H, W, C = 3, 8, 8, 64
+    x = h16(rng.standard_normal((B, C, H, W)))
+    w = h16(rng.standard_normal((C, C, 3, 3)) / 24)
+    bv = rng.standard_normal(C).astype(np.float32)
+    emb = rng.standard_normal((B, 200)).astype(np.float32)  # emb_all with this block at columns 72..136
+    res = h16(rng.standard_normal((B, C, H, W)))
+    ref = O.conv2d(torch.tensor(x), torch.tensor(w), torch.tensor(bv)) + torch.tensor(emb[:, 72:136])[:, :, None, None] \
+        + torch.tensor(res)
+    embd = dev32(emb)
+    out = ops.gemm(dev16(nhwc(x)), dev16(pack_conv(w)), C, B, H, W, C, bias=dev32(bv), ksize=3,
+                   rowbias=embd[:, 72:136], rowbias_ld=200, residual=dev16(nhwc(res)), residual_ld=C)
+    check("conv3x3_rowbias_residual", from_nhwc(out.float().cpu().numpy(), B, H, W), ref, rel_l2=1e-3)
+
+
+@pytest.mark.parametrize("M,C,splitk", [(256, 64, 1), (100, 320, 1), (64, 320, 2)])
+def test_gemm_geglu(ops, M, C, splitk):
+    """GEGLU (attention.py:41-51): x, gate = split(proj(x)); x * gelu_tanh(gate), fused in the epilogue."""
+    rng = np.random.RandomState(M + C)
+    a = h16(rng.standard_normal((M, C)))
+    w = h16(rng.standard_normal((8 * C, C)) / math.sqrt(C))
+    bv = rng.standard_normal(8 * C).astype(np.float32)
+    y = torch.tensor(a) @ torch.tensor(w).T + torch.tensor(bv)
+    xa, gate = y.chunk(2, dim=-1)
+    ref = xa * O.gelu_tanh(gate)
+    half = 4 * C
+    nt = half // 64
+    wp = np.stack([w[:half].reshape(nt, 64, C), w[half:].reshape(nt, 64, C)], 1).reshape(8 * C, C)
+    bp = np.stack([bv[:half].reshape(nt, 64), bv[half:].reshape(nt, 64)], 1).reshape(-1)
+    out = ops.gemm(dev16(a), dev16(wp), 8 * C, 1, M, 1, C, bias=dev32(bp), epilogue=ops.EPI_GEGLU, splitk=splitk)
+    assert out.shape == (M, 4 * C)
+    check(f"gemm_geglu_M{M}_C{C}_s{splitk}", out, ref, rel_l2=2e-3)
+
+
+@pytest.mark.parametrize("B,T,K,N,pad,splitk", [(2, 64, 128, 128, 0, 1), (2, 256, 320, 320, 0, 1), (2, 80, 64, 128, 0, 1),
+                                              (1, 64, 640, 64, 0, 2)])
+def test_gemm_transposed_store(ops, B, T, K, N, pad, splitk):
+    """V^T store for the attention kernel: out[b][n][tok]."""
+    rng = np.random.RandomState(T + N)
+    a = h16(rng.standard_normal((B * T, K)))
+    w = h16(rng.standard_normal((N, K)) / math.sqrt(K))
+    ref = (a @ w.T).reshape(B, T, N).transpose(0, 2, 1)
+    out = ops.gemm(dev16(a), dev16(w), N, B, T, 1, K, out_mode=ops.OUT_TRANSPOSED, splitk=splitk)
+    assert out.shape == (B, N, T)
+    check(f"gemm_transposed_B{B}_T{T}_K{K}_N{N}_s{splitk}", out, ref, rel_l2=1e-3)
+
+
+# --------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, heads):
+    b, n, c = q.shape
+    d = c // heads
+    qt, kt, vt = [torch.tensor(t).reshape(b, -1, heads, d).permute(0, 2, 1, 3) for t in (q, k, v)]
+    s = torch.matmul(qt, kt.transpose(2, 3)) * d ** -0.5
+    o = torch.matmul(torch.softmax(s, -1), vt)
+    return o.permute(0, 2, 1, 3).reshape(b, n, c)
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,spike", [
+    (1, 1, 64, 64, False),
+    (2, 2, 256, 256, False),
+    (1, 5, 1024, 1024, False),
+    (2, 2, 100, 77, False),      # cross-attention: 77 text tokens, ragged queries
+    (1, 1, 128, 200, False),     # key tail inside a 64-key tile
+    (1, 2, 256, 320, True),      # a late outlier key forces the online-softmax rescale branch (guide rule 26)
+])
+def test_attention(ops, B, heads, Nq, Nk, spike):
+    D = 64
+    C = heads * D
+    rng = np.random.RandomState(Nq + Nk + heads)
+    q = h16(rng.standard_normal((B, Nq, C)))
+    k = h16(rng.standard_normal((B, Nk, C)))
+    v = h16(rng.standard_normal((B, Nk, C)))
+    if spike:
+        k[:, 290] = h16(q[:, 3] * 3.0)   # key 290 (5th tile) dominates query row 3
+        k[:, 10] = h16(-q[:, 7] * 2.0)
+    ref = _attn_ref(q, k, v, heads)
+    ld = (Nk + 7) // 8 * 8
+    vt = np.zeros((B, C, ld), np.float32)
+    vt[:, :, :Nk] = v.transpose(0, 2, 1)
+    qd, kd, vtd = dev16(q), dev16(k), dev16(vt)
+    out = torch.empty((B, Nq, C), dtype=torch.float16, device=DEV)
+    ops.attention(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), out.data_ptr(), B, heads, D, Nq, Nk, D ** -0.5,
+                  Nq * C, C, Nk * C, C, C * ld, ld, Nq * C, C)
+    # P is rounded to fp16 before PV and O is stored fp16: 2e-3 relative
+    check(f"attention_B{B}_h{heads}_q{Nq}_k{Nk}_spike{int(spike)}", out, ref, rel_l2=2e-3, max_abs=2e-2)
+
+
+def test_attention_fused_qk_layout(ops):
+    """q and k as column slices of one [M, 2C] projection buffer (how the UNet calls it)."""
+    B, heads, N, D = 2, 2, 128, 64
+    C = heads * D
+    rng = np.random.RandomState(3)
+    qk = h16(rng.standard_normal((B, N, 2 * C)))
+    v = h16(rng.standard_normal((B, N, C)))
+    ref = _attn_ref(qk[:, :, :C], qk[:, :, C:], v, heads)
+    qkd = dev16(qk)
+    vtd = dev16(v.transpose(0, 2, 1))
+    out = torch.empty((B, N, C), dtype=torch.float16, device=DEV)
+    ops.attention(qkd.data_ptr(), qkd.data_ptr() + C * 2, vtd.data_ptr(), out.data_ptr(), B, heads, D, N, N, D ** -0.5,
+                  N * 2 * C, 2 * C, N * 2 * C, 2 * C, C * N, N, N * C, C)
+    check("attention_fused_qk_layout", out, ref, rel_l2=2e-3, max_abs=2e-2)
+
+
+# --------------------------------------------------------------------------- time embedding
+def test_timestep_embedding_and_dense_small(ops):
+    t = np.array([981.0, 1.0, 500.5], np.float32)
+    e = ops.timestep_embedding(dev32(t), 320)
+    ref = O.timestep_embedding(torch.tensor(t), 320)
+    check("timestep_embedding", e, ref, max_abs=2e-4)   # fp32 sin/cos of arguments up to 1e3
+    np.testing.assert_allclose(e[0, :3].cpu().numpy(), [0.6799572, -0.7984292, 0.578114], atol=2e-4)
+    rng = np.random.RandomState(0)
+    for M, N, K, ai, ao in ((3, 1280, 320, False, True), (2, 1280, 1280, False, False), (9, 2000, 1280, True, False)):
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        w = h16(rng.standard_normal((N, K)) / math.sqrt(K))
+        b = rng.standard_normal(N).astype(np.float32)
+        xin = O.silu(torch.tensor(x)) if ai else torch.tensor(x)
+        ref = xin @ torch.tensor(w).T + torch.tensor(b)
+        if ao:
+            ref = O.silu(ref)
+        out = ops.dense_small(dev32(x), dev16(w), dev32(b), act_in=ai, act_out=ao)
+        check(f"dense_small_M{M}_N{N}_K{K}", out, ref, rel_l2=2e-5)
+
+
+# --------------------------------------------------------------------------- sampler step
+@pytest.mark.parametrize("cfg,order,sigma", [(True, 0, 0.0), (False, 1, 0.0), (True, 3, 0.0), (True, 0, 0.3)])
+def test_sampler_step(ops, cfg, order, sigma):
+    rng = np.random.RandomState(order + int(cfg))
+    B, C, H, W = 2, 4, 8, 8
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    eu = h16(rng.standard_normal((B, C, H, W)))
+    ec = h16(rng.standard_normal((B, C, H, W)))
+    olds = [rng.standard_normal((B, C, H, W)).astype(np.float32) for _ in range(order)]
+    coef = {0: (1, 0, 0, 0), 1: (1.5, -0.5, 0, 0), 3: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}[order]
+    noise = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    scale = 7.5
+    a_t, a_prev = np.float32(0.3), np.float32(0.5)
+    e_t = eu + scale * (ec - eu) if cfg else ec
+    ep = coef[0] * e_t + sum(c * o for c, o in zip(coef[1:], olds))
+    px0 = (x - np.sqrt(1 - a_t) * ep) / np.sqrt(a_t)
+    xp = np.sqrt(a_prev) * px0 + np.sqrt(1 - a_prev - sigma ** 2) * ep + sigma * noise
+
+    def eps_buf(e):  # NHWC fp16 with 8-channel stride
+        buf = np.zeros((B, H * W, 8), np.float32)
+        buf[:, :, :4] = nhwc(e)
+        return dev16(buf)
+
+    xd = dev32(x)
+    e_out, x_out, p_out = torch.empty_like(xd), torch.empty_like(xd), torch.empty_like(xd)
+    ops.sampler_step(xd, eps_buf(eu) if cfg else None, eps_buf(ec), 8, scale, [dev32(o) for o in olds], coef,
+                     np.sqrt(a_t), np.sqrt(1 - a_t), np.sqrt(a_prev), np.sqrt(1 - a_prev - np.float32(sigma) ** 2),
+                     sigma, dev32(noise) if sigma else None, e_out, x_out, p_out)
+    check(f"sampler_step_cfg{int(cfg)}_o{order}_s{sigma}_x", x_out, xp, rel_l2=1e-5)
+    check(f"sampler_step_cfg{int(cfg)}_o{order}_s{sigma}_p", p_out, px0, rel_l2=1e-5)
+    check(f"sampler_step_cfg{int(cfg)}_o{order}_s{sigma}_e", e_out, e_t, rel_l2=1e-5)
