@@ -357,7 +357,12 @@ class UNetModel:
         P = UNetModel._Plan()
         A = _Arena(dev)
         main, ctxops, descs = [], [], []
+        meta = []      # parallel to `main`: {"kind", "flops", "launches"} for profiling / roofline accounting
         gn_need = [0]
+
+        def emit(fn, kind, flops=0, launches=1):
+            main.append(fn)
+            meta.append({"kind": kind, "flops": int(flops), "launches": launches})
         P.x_static = torch.zeros((B, self.in_channels, H, W), dtype=f32, device=dev)
         P.t_static = torch.zeros((B,), dtype=f32, device=dev)
         TC = self.max_context_len
@@ -366,7 +371,16 @@ class UNetModel:
         def add_gemm(oplist, **kw):
             d = ops.make_gemm_desc(**kw)
             descs.append(d)
-            oplist.append(lambda d=d: ops.gemm_run(d))
+            fn = (lambda d=d: ops.gemm_run(d))
+            if oplist is main:
+                ks, st, up = kw.get("ksize", 1), kw.get("stride", 1), kw.get("upsample", 0)
+                hs_, ws2 = (2 * kw["H"], 2 * kw["W"]) if up else (kw["H"], kw["W"])
+                pad = 1 if ks == 3 else 0
+                m_rows = kw["B"] * ((hs_ + 2 * pad - ks) // st + 1) * ((ws2 + 2 * pad - ks) // st + 1)
+                kdim = ks * ks * (kw["c1"] + kw.get("c2", 0))
+                emit(fn, "gemm", 2 * m_rows * kw["N"] * kdim, 2 if ops.gemm_workspace_bytes(d) else 1)
+            else:
+                oplist.append(fn)
 
         gn_calls = []
 
@@ -376,7 +390,8 @@ class UNetModel:
             gn_need[0] = max(gn_need[0], ops.groupnorm_ws_floats(Bq, HW, C1 + C2))
             call = dict(x1=x1, x2=x2, g=g, b=b, eps=eps, silu=silu, out=out)
             gn_calls.append(call)
-            main.append(lambda c=call: ops.groupnorm(c["x1"], c["x2"], c["g"], c["b"], c["eps"], c["silu"], ws=P.gn_ws, out=c["out"]))
+            emit(lambda c=call: ops.groupnorm(c["x1"], c["x2"], c["g"], c["b"], c["eps"], c["silu"], ws=P.gn_ws, out=c["out"]),
+                 "groupnorm", 0, 2)
 
         # ---- time embedding (openaimodel.py:550-551, 150-157): 4 tiny launches
         mc, ted = self.model_channels, self.time_embed_dim
@@ -384,13 +399,14 @@ class UNetModel:
         e1 = torch.empty((B, ted), dtype=f32, device=dev)
         emb = torch.empty((B, ted), dtype=f32, device=dev)
         P.emb_all = torch.empty((B, self._emb_total), dtype=f32, device=dev)
-        main.append(lambda: ops.timestep_embedding(P.t_static, mc, out=t_emb))
-        main.append(lambda: ops.dense_small(t_emb, w["te0.w"], w["te0.b"], act_out=True, out=e1))
-        main.append(lambda: ops.dense_small(e1, w["te2.w"], w["te2.b"], out=emb))
-        main.append(lambda: ops.dense_small(emb, w["emb.w"], w["emb.b"], act_in=True, out=P.emb_all))
+        emit(lambda: ops.timestep_embedding(P.t_static, mc, out=t_emb), "small")
+        emit(lambda: ops.dense_small(t_emb, w["te0.w"], w["te0.b"], act_out=True, out=e1), "small", 2 * B * mc * ted)
+        emit(lambda: ops.dense_small(e1, w["te2.w"], w["te2.b"], out=emb), "small", 2 * B * ted * ted)
+        emit(lambda: ops.dense_small(emb, w["emb.w"], w["emb.b"], act_in=True, out=P.emb_all), "small",
+             2 * B * ted * self._emb_total)
 
         xin = A.get((B, H * W, self.cin_pad))
-        main.append(lambda: ops.nchw_to_nhwc(P.x_static, self.cin_pad, out=xin))
+        emit(lambda: ops.nchw_to_nhwc(P.x_static, self.cin_pad, out=xin), "small")
 
         P.ctx_pad = None
         ctx_kv = {}
@@ -452,29 +468,31 @@ class UNetModel:
             A.release(a)
             # --- attn1 (self)
             ln = A.get((B, n, inner))
-            main.append(lambda ln=ln, tok=tok: ops.layernorm(tok, w[t + "norm1.g"], w[t + "norm1.b"], 1e-5, out=ln))
+            emit(lambda ln=ln, tok=tok: ops.layernorm(tok, w[t + "norm1.g"], w[t + "norm1.b"], 1e-5, out=ln), "layernorm")
             qk = dense(main, ln, B, n, inner, 2 * inner, w[t + "attn1.qk.w"])
             vt = A.get((B, inner, n))
             dense(main, ln, B, n, inner, inner, w[t + "attn1.v.w"], out=vt, out_ld=n, out_mode=ops.OUT_TRANSPOSED)
             o = ln  # reuse: ln is dead after the projections
-            main.append(lambda qk=qk, vt=vt, o=o: ops.attention(
+            emit(lambda qk=qk, vt=vt, o=o: ops.attention(
                 qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
-                n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner))
+                n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner),
+                "attention", 4 * B * heads * n * n * dh)
             tok2 = dense(main, o, B, n, inner, inner, w[t + "attn1.o.w"], bias=w[t + "attn1.o.b"], residual=tok)
             A.release(qk); A.release(vt); A.release(tok)
             # --- attn2 (cross): K / V^T of the context are produced by the context plan
-            main.append(lambda ln=ln, tok2=tok2: ops.layernorm(tok2, w[t + "norm2.g"], w[t + "norm2.b"], 1e-5, out=ln))
+            emit(lambda ln=ln, tok2=tok2: ops.layernorm(tok2, w[t + "norm2.g"], w[t + "norm2.b"], 1e-5, out=ln), "layernorm")
             q2 = dense(main, ln, B, n, inner, inner, w[t + "attn2.q.w"])
             kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
             vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
             ctx_kv[pre] = (kc, vtc)
-            main.append(lambda q2=q2, kc=kc, vtc=vtc, o=o: ops.attention(
+            emit(lambda q2=q2, kc=kc, vtc=vtc, o=o: ops.attention(
                 q2.data_ptr(), kc.data_ptr(), vtc.data_ptr(), o.data_ptr(), B, heads, dh, n, P.ctx_len, scale,
-                n * inner, inner, TC * inner, inner, inner * TC, TC, n * inner, inner))
+                n * inner, inner, TC * inner, inner, inner * TC, TC, n * inner, inner),
+                "attention", 4 * B * heads * n * 77 * dh)
             tok3 = dense(main, o, B, n, inner, inner, w[t + "attn2.o.w"], bias=w[t + "attn2.o.b"], residual=tok2)
             A.release(q2); A.release(tok2)
             # --- feed-forward (GEGLU fused in the first GEMM's epilogue)
-            main.append(lambda ln=ln, tok3=tok3: ops.layernorm(tok3, w[t + "norm3.g"], w[t + "norm3.b"], 1e-5, out=ln))
+            emit(lambda ln=ln, tok3=tok3: ops.layernorm(tok3, w[t + "norm3.g"], w[t + "norm3.b"], 1e-5, out=ln), "layernorm")
             g = dense(main, ln, B, n, inner, 8 * inner, w[t + "ff1.w"], bias=w[t + "ff1.b"], epilogue=ops.EPI_GEGLU)
             tok4 = dense(main, g, B, n, 4 * inner, inner, w[t + "ff2.w"], bias=w[t + "ff2.b"], residual=tok3)
             A.release(g); A.release(tok3); A.release(ln)
@@ -561,7 +579,8 @@ class UNetModel:
             d.workspace = P.gemm_ws.data_ptr()
             d.workspace_bytes = P.gemm_ws.numel() * 4
         P.gn_ws = torch.empty(max(gn_need[0], 4), dtype=f32, device=dev)
-        P.main, P.ctxops, P.descs = main, ctxops, descs
+        P.main, P.ctxops, P.descs, P.meta = main, ctxops, descs, meta
+        assert len(main) == len(meta)
         P.arena_bytes = A.total
         P.graph = None
         P.graph_failed = False

@@ -135,7 +135,7 @@ def gemm(a, w, N, B, H, W, c1, out=None, **kw):
     else:
         ld = kw.pop("out_ld")
     d = make_gemm_desc(a, w, N, B, H, W, c1, out, ld, **kw)
-    if d.workspace == 0:
+    if not d.workspace:
         need = gemm_workspace_bytes(d)
         if need:
             ws = torch.empty(need // 4, dtype=f32, device=a.device)

@@ -1,0 +1,76 @@
+"""DiffusionPipeline -- what the reference's txt2img.py main loop does around the sampler
+(vision/stablediffusionv2/txt2img.py:242-268; Wukong: wukong-huahua/txt2img.py:255-281):
+
+    uc = model.get_learned_conditioning(B * [""]); c = model.get_learned_conditioning(prompts)
+    shape = [4, H // 8, W // 8]
+    samples, _ = sampler.sample(S=steps, conditioning=c, batch_size=B, shape=shape, verbose=False,
+                                unconditional_guidance_scale=scale, unconditional_conditioning=uc, eta=eta, x_T=x_T)
+    x = model.decode_first_stage(samples)
+
+Text encoding and VAE decode are outside the hot path: pass precomputed
+conditioning tensors (c, uc), or attach ``model.cond_stage_model`` / ``model.first_stage_model``.
+With torch.distributed initialised the global batch is sharded across ranks (distributed.py).
+"""
+import numpy as np
+import torch
+
+from . import distributed as D
+from ._lib import MdxError
+from .ldm.models.diffusion.ddim import DDIMSampler
+from .ldm.models.diffusion.plms import PLMSSampler
+
+
+class DiffusionPipeline:
+    def __init__(self, model, sampler="ddim", device=None):
+        self.model = model
+        self.device = torch.device(device) if device is not None else model.unet.device
+        if isinstance(sampler, str):
+            if sampler not in ("ddim", "plms"):
+                raise ValueError("sampler must be 'ddim' or 'plms' (DPM-Solver++ is SURVEY 8(f) 'next')")
+            sampler = (DDIMSampler if sampler == "ddim" else PLMSSampler)(model)
+        self.sampler = sampler
+
+    def start_noise(self, batch, shape, seed):
+        """numpy RandomState(seed).randn -- the reference's own practice for reproducible x_T
+        (wukong-huahua/inpaint.py:68-70); MindSpore's StandardNormal stream is not reproducible."""
+        return torch.from_numpy(np.random.RandomState(seed).randn(batch, *shape).astype(np.float32))
+
+    def __call__(self, prompts=None, c=None, uc=None, H=512, W=512, steps=50, scale=9.0, eta=0.0, x_T=None, seed=42,
+                 decode=False, gather=False, callback=None, img_callback=None):
+        rank, n = D.world()
+        shape = [4, H // 8, W // 8]                                   # txt2img.py:253
+        if prompts is not None and rank == 0:
+            uc = self.model.get_learned_conditioning(len(prompts) * [""])   # txt2img.py:246-248
+            c = self.model.get_learned_conditioning(list(prompts))            # txt2img.py:251
+        if n > 1:
+            meta = [None]
+            if rank == 0:
+                meta = [(int(c.shape[0]), int(c.shape[1]), int(c.shape[2]))]
+            torch.distributed.broadcast_object_list(meta, src=0)
+            B, T, Dc = meta[0]
+            if rank == 0 and x_T is None:
+                x_T = self.start_noise(B, shape, seed)
+            c, uc, x_T = D.broadcast_conditioning(
+                c.to(self.device) if rank == 0 else None, uc.to(self.device) if rank == 0 else None,
+                x_T.to(self.device) if rank == 0 else None, B, (T, Dc), shape, self.device)
+        else:
+            if c is None:
+                raise MdxError("DiffusionPipeline: pass prompts (with a text encoder attached) or (c, uc) tensors")
+            B = int(c.shape[0])
+            if x_T is None:
+                x_T = self.start_noise(B, shape, seed)
+            c = c.to(self.device, torch.float16)
+            uc = None if uc is None else uc.to(self.device, torch.float16)
+            if uc is not None and uc.shape[0] == 1 and B > 1:
+                uc = uc.expand(B, -1, -1).contiguous()
+            x_T = x_T.to(self.device)
+        local_b = int(c.shape[0])
+        samples, inter = self.sampler.sample(S=steps, conditioning=c, batch_size=local_b, shape=shape, verbose=False,
+                                             unconditional_guidance_scale=scale, unconditional_conditioning=uc,
+                                             eta=eta, x_T=x_T, callback=callback, img_callback=img_callback)
+        if decode:
+            x = self.model.decode_first_stage(samples)                # txt2img.py:265-266
+            samples = torch.clamp((x + 1.0) / 2.0, 0.0, 1.0)
+        if gather and n > 1:
+            samples = D.gather_latents(samples)
+        return samples

@@ -28,10 +28,10 @@ def metrics(got, ref):
     }
 
 
-def check(name, got, ref, rel_l2=None, max_abs=None, **extra):
+def check(name, got, ref, rel_l2=None, max_abs=None, max_rel=None, **extra):
     """Log and assert.  Tolerances are stated at the call site (fp16 storage / fp32 accumulate vs fp32 oracle)."""
     m = metrics(got, ref)
-    rec = dict(name=name, **m, tol_rel_l2=rel_l2, tol_max_abs=max_abs, **extra)
+    rec = dict(name=name, **m, tol_rel_l2=rel_l2, tol_max_abs=max_abs, tol_max_rel=max_rel, **extra)
     try:
         os.makedirs(os.path.dirname(LOG), exist_ok=True)
         with open(LOG, "a") as f:
@@ -44,6 +44,9 @@ def check(name, got, ref, rel_l2=None, max_abs=None, **extra):
         assert m["rel_l2"] <= rel_l2, f"{name}: rel_l2 {m['rel_l2']:.3e} > {rel_l2:.1e} (max_abs {m['max_abs']:.3e})"
     if max_abs is not None:
         assert m["max_abs"] <= max_abs, f"{name}: max_abs {m['max_abs']:.3e} > {max_abs:.1e}"
+    if max_rel is not None:  # max |d| relative to the largest reference magnitude
+        assert m["max_abs"] <= max_rel * max(m["ref_max"], 1e-30), \
+            f"{name}: max_abs {m['max_abs']:.3e} > {max_rel:.1e} * ref_max {m['ref_max']:.3e}"
     return m
 
 

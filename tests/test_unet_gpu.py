@@ -3,7 +3,7 @@ fp32 CPU oracle on identical seeded weights and inputs.
 
 Tolerances (fp16 storage + fp32 accumulation vs an all-fp32 oracle):
   single UNet call : rel-L2 <= 5e-3 at the latent level
-  5-step trajectory: rel-L2 <= 1e-2, max|d| <= 5e-2
+  5/10-step trajectory: rel-L2 <= 1e-2, max|d| <= 1e-2 * max|ref| (synthetic weights + CFG 7.5 give |x| ~ 50)
 """
 import numpy as np
 import pytest
@@ -114,7 +114,7 @@ def test_tiny_sampler_trajectory(sampler, S, scale):
                                    callback=lambda i: calls.append(i))
     assert calls == list(range(S))
     assert len(inter["x_inter"]) == len(ref_inter["x_inter"])
-    check(f"tiny_{sampler}_S{S}_scale{scale}", got, ref, rel_l2=1e-2, max_abs=5e-2)
+    check(f"tiny_{sampler}_S{S}_scale{scale}", got, ref, rel_l2=1e-2, max_rel=1e-2)
     check(f"tiny_{sampler}_S{S}_scale{scale}_pred_x0", inter["pred_x0"][-1], ref_inter["pred_x0"][-1], rel_l2=2e-2)
 
 
