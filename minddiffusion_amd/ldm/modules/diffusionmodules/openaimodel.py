@@ -360,9 +360,9 @@ class UNetModel:
         meta = []      # parallel to `main`: {"kind", "flops", "launches"} for profiling / roofline accounting
         gn_need = [0]
 
-        def emit(fn, kind, flops=0, launches=1):
+        def emit(fn, kind, flops=0, launches=1, info=""):
             main.append(fn)
-            meta.append({"kind": kind, "flops": int(flops), "launches": launches})
+            meta.append({"kind": kind, "flops": int(flops), "launches": launches, "info": info})
         P.x_static = torch.zeros((B, self.in_channels, H, W), dtype=f32, device=dev)
         P.t_static = torch.zeros((B,), dtype=f32, device=dev)
         TC = self.max_context_len
@@ -378,7 +378,9 @@ class UNetModel:
                 pad = 1 if ks == 3 else 0
                 m_rows = kw["B"] * ((hs_ + 2 * pad - ks) // st + 1) * ((ws2 + 2 * pad - ks) // st + 1)
                 kdim = ks * ks * (kw["c1"] + kw.get("c2", 0))
-                emit(fn, "gemm", 2 * m_rows * kw["N"] * kdim, 2 if ops.gemm_workspace_bytes(d) else 1)
+                wsb = ops.gemm_workspace_bytes(d)
+                emit(fn, "gemm", 2 * m_rows * kw["N"] * kdim, 2 if wsb else 1,
+                     f"M={m_rows} N={kw['N']} K={kdim} k{ks}s{st}u{up} split={wsb // max(1, m_rows * kw['N'] * 4)}")
             else:
                 oplist.append(fn)
 
@@ -391,7 +393,7 @@ class UNetModel:
             call = dict(x1=x1, x2=x2, g=g, b=b, eps=eps, silu=silu, out=out)
             gn_calls.append(call)
             emit(lambda c=call: ops.groupnorm(c["x1"], c["x2"], c["g"], c["b"], c["eps"], c["silu"], ws=P.gn_ws, out=c["out"]),
-                 "groupnorm", 0, 2)
+                 "groupnorm", 0, 2, f"B={Bq} HW={HW} C={C1 + C2}")
 
         # ---- time embedding (openaimodel.py:550-551, 150-157): 4 tiny launches
         mc, ted = self.model_channels, self.time_embed_dim
@@ -476,7 +478,7 @@ class UNetModel:
             emit(lambda qk=qk, vt=vt, o=o: ops.attention(
                 qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
                 n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner),
-                "attention", 4 * B * heads * n * n * dh)
+                "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
             tok2 = dense(main, o, B, n, inner, inner, w[t + "attn1.o.w"], bias=w[t + "attn1.o.b"], residual=tok)
             A.release(qk); A.release(vt); A.release(tok)
             # --- attn2 (cross): K / V^T of the context are produced by the context plan
@@ -488,7 +490,7 @@ class UNetModel:
             emit(lambda q2=q2, kc=kc, vtc=vtc, o=o: ops.attention(
                 q2.data_ptr(), kc.data_ptr(), vtc.data_ptr(), o.data_ptr(), B, heads, dh, n, P.ctx_len, scale,
                 n * inner, inner, TC * inner, inner, inner * TC, TC, n * inner, inner),
-                "attention", 4 * B * heads * n * 77 * dh)
+                "attention", 4 * B * heads * n * 77 * dh, 1, f"cross B={B} h={heads} N={n} d={dh}")
             tok3 = dense(main, o, B, n, inner, inner, w[t + "attn2.o.w"], bias=w[t + "attn2.o.b"], residual=tok2)
             A.release(q2); A.release(tok2)
             # --- feed-forward (GEGLU fused in the first GEMM's epilogue)

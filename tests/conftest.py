@@ -24,3 +24,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _limit_cpu_threads():
+    """The oracle runs tiny tensors: a 128-thread pool (x xdist workers) only oversubscribes the host."""
+    try:
+        import torch
+        torch.set_num_threads(min(8, torch.get_num_threads()))
+    except Exception:  # pragma: no cover
+        pass
+    yield

@@ -138,7 +138,8 @@ def test_sd2_full_size_single_step():
     """BASELINE config 0: SDv2 UNet single denoise step, 1x4x64x64 latent, random text embedding, vs the fp32
     CPU oracle on the same seeded weights (0.8 TFLOP on the CPU: about a minute)."""
     from minddiffusion_amd.configs import SD2_UNET
-    torch.set_num_threads(max(1, torch.get_num_threads()))
+    import os
+    torch.set_num_threads(min(32, os.cpu_count() or 8))   # 0.8 TFLOP fp32 on the host
     params = O.init_params(O.SD2_UNET, seed=0)
     net = _build(dict(SD2_UNET), params, True)
     oracle = O.UNetOracle(O.SD2_UNET, params)
