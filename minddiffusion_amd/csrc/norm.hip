@@ -12,8 +12,9 @@
 
 namespace {
 
-constexpr int GN_MAX_C = 4096;
-constexpr int GN_PIX_PER_BLOCK = 64;
+constexpr int GN_MAX_C = 8192;
+constexpr int GN_MAX_NBLK = 64;      // pixel slabs per sample (bounds the partial-sum fold in gn_apply)
+constexpr int GN_TARGET_BLOCKS = 1024;
 
 struct GnParams {
     const f16* x1;
@@ -21,9 +22,11 @@ struct GnParams {
     const float* gamma;
     const float* beta;
     f16* y;
-    float* ws;  // [B][nblk][groups][2]
-    int C1, C2, C, CC1, CC;  // CCx = chunks (8 channels) per pixel
-    int B, HW, groups, cpg, nblk;
+    float* ws;  // [B][nblk][groups][2] partial {sum, sumsq}
+    int C1, C2, C, CC1, CC;  // CCx = 16-byte chunks (8 channels) per pixel
+    int B, HW, groups, cpg;
+    int nblk, pix;           // pixel slabs per sample, pixels per slab
+    int cw, ncb;             // chunk columns per block (whole groups), column blocks
     float eps;
     int silu;
 };
@@ -33,102 +36,144 @@ __device__ __forceinline__ f16x8 gn_load(const GnParams& p, int b, int pix, int 
     return *reinterpret_cast<const f16x8*>(p.x2 + ((size_t)b * p.HW + pix) * p.C2 + (col - p.CC1) * 8);
 }
 
-// grid (nblk, B); block 256.  LDS: per-(thread-row, channel) {sum, sumsq} partials [trows][C][2] fp32.
-// Deterministic: no atomics, every reduction runs in a fixed order.
+// grid (nblk, ncb, B); block 256 = tcols (= columns of this block, <= 64) x trows.
+// Every thread owns ONE chunk column (8 channels) and strides over the slab's pixels, so the per-channel
+// accumulators stay in registers; a fixed-order LDS fold then produces per-group partials
+// (deterministic: no atomics anywhere).
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnParams p) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [trows][C][2]
-    const int b = blockIdx.y;
-    const int p0 = blockIdx.x * GN_PIX_PER_BLOCK;
-    const int p1 = min(p.HW, p0 + GN_PIX_PER_BLOCK);
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [trows][cols*8][2]
+    const int b = blockIdx.z, cb = blockIdx.y;
+    const int p0 = blockIdx.x * p.pix;
+    const int p1 = min(p.HW, p0 + p.pix);
+    const int col0 = cb * p.cw;
+    const int cols = min(p.cw, p.CC - col0);
     const int tid = threadIdx.x;
-    // threads tile the (pixel, chunk-column) plane with the column FIXED per thread per pass, so
-    // the per-channel accumulators live in registers: tcols = min(CC,256) columns x trows rows.
-    const int tcols = p.CC < 256 ? p.CC : 256;
-    const int trows = 256 / tcols;
-    const int tc = tid % tcols, tr = tid / tcols;
+    const int trows = 256 / cols;
+    const int tc = tid % cols, tr = tid / cols;
+    const int chs = cols * 8;
     if (tr < trows) {
-        for (int cb = 0; cb < p.CC; cb += tcols) {
-            const int col = cb + tc;
-            if (col >= p.CC) continue;
-            float s[8], q[8];
+        float s[8], q[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-            for (int pix = p0 + tr; pix < p1; pix += trows) {
-                const f16x8 v = gn_load(p, b, pix, col);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = (float)v[e];
-                    s[e] += f;
-                    q[e] += f * f;
-                }
-            }
-            float* dst = red + ((size_t)tr * p.C + col * 8) * 2;
+        for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+        for (int pix = p0 + tr; pix < p1; pix += trows) {
+            const f16x8 v = gn_load(p, b, pix, col0 + tc);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                dst[e * 2] = s[e];
-                dst[e * 2 + 1] = q[e];
+                const float f = (float)v[e];
+                s[e] += f;
+                q[e] += f * f;
             }
+        }
+        float* dst = red + ((size_t)tr * chs + tc * 8) * 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dst[e * 2] = s[e];
+            dst[e * 2 + 1] = q[e];
         }
     }
     __syncthreads();
-    // per-group partials: one thread per group sums its cpg channels over the trows partial rows
-    if (tid < p.groups) {
+    const int ng = chs / p.cpg;          // whole groups in this column block
+    const int g0 = col0 * 8 / p.cpg;
+    if (tid < ng) {
         float s = 0.f, q = 0.f;
         for (int r = 0; r < trows; ++r)
             for (int c = tid * p.cpg; c < (tid + 1) * p.cpg; ++c) {
-                s += red[((size_t)r * p.C + c) * 2];
-                q += red[((size_t)r * p.C + c) * 2 + 1];
+                s += red[((size_t)r * chs + c) * 2];
+                q += red[((size_t)r * chs + c) * 2 + 1];
             }
-        float* o = p.ws + (((size_t)b * p.nblk + blockIdx.x) * p.groups + tid) * 2;
+        float* o = p.ws + (((size_t)b * p.nblk + blockIdx.x) * p.groups + g0 + tid) * 2;
         o[0] = s;
         o[1] = q;
     }
 }
 
-// grid (nblk, B); block 256.  LDS: scale/shift per channel [C][2].
+// grid (nblk, ncb, B); block 256.  Prologue folds the <= 64 slab partials of this block's groups with
+// 8 lanes per group (fixed shuffle order), builds per-channel scale/shift in LDS, then streams the slab.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
-    extern __shared__ __attribute__((aligned(16))) float ss[];  // [C*2] then [groups*2]
-    float* gstat = ss + p.C * 2;
-    const int b = blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) float ss[];  // [cols*8][2] scale/shift, then [32][2] group stats
+    const int b = blockIdx.z, cb = blockIdx.y;
+    const int col0 = cb * p.cw;
+    const int cols = min(p.cw, p.CC - col0);
+    const int chs = cols * 8;
+    float* gstat = ss + chs * 2;
     const int tid = threadIdx.x;
-    if (tid < p.groups) {
+    const int ng = chs / p.cpg;
+    const int g0 = col0 * 8 / p.cpg;
+    {
+        const int g = tid >> 3, j = tid & 7;
         float s = 0.f, q = 0.f;
-        const float* w = p.ws + ((size_t)b * p.nblk * p.groups + tid) * 2;
-        for (int k = 0; k < p.nblk; ++k) {
-            s += w[(size_t)k * p.groups * 2];
-            q += w[(size_t)k * p.groups * 2 + 1];
+        if (g < ng) {
+            const float* w = p.ws + ((size_t)b * p.nblk * p.groups + g0 + g) * 2;
+            for (int k = j; k < p.nblk; k += 8) {
+                s += w[(size_t)k * p.groups * 2];
+                q += w[(size_t)k * p.groups * 2 + 1];
+            }
         }
-        const float inv = 1.0f / ((float)p.cpg * (float)p.HW);
-        const float mean = s * inv;
-        float var = q * inv - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        gstat[tid * 2] = mean;
-        gstat[tid * 2 + 1] = rsqrtf(var + p.eps);
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s += __shfl_xor(s, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        if (g < ng && j == 0) {
+            const float inv = 1.0f / ((float)p.cpg * (float)p.HW);
+            const float mean = s * inv;
+            float var = q * inv - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            gstat[g * 2] = mean;
+            gstat[g * 2 + 1] = rsqrtf(var + p.eps);
+        }
     }
     __syncthreads();
-    for (int c = tid; c < p.C; c += 256) {
+    for (int c = tid; c < chs; c += 256) {
         const int g = c / p.cpg;
-        const float a = p.gamma[c] * gstat[g * 2 + 1];
+        const float a = p.gamma[col0 * 8 + c] * gstat[g * 2 + 1];
         ss[c * 2] = a;
-        ss[c * 2 + 1] = p.beta[c] - gstat[g * 2] * a;
+        ss[c * 2 + 1] = p.beta[col0 * 8 + c] - gstat[g * 2] * a;
     }
     __syncthreads();
-    const int p0 = blockIdx.x * GN_PIX_PER_BLOCK;
-    const int p1 = min(p.HW, p0 + GN_PIX_PER_BLOCK);
-    const int n = (p1 - p0) * p.CC;
-    for (int i = tid; i < n; i += 256) {
-        const int pix = p0 + i / p.CC;
-        const int col = i - (i / p.CC) * p.CC;
-        const f16x8 v = gn_load(p, b, pix, col);
+    const int p0 = blockIdx.x * p.pix;
+    const int p1 = min(p.HW, p0 + p.pix);
+    const int trows = 256 / cols;
+    const int tc = tid % cols, tr = tid / cols;
+    if (tr >= trows) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = ss[(tc * 8 + e) * 2];
+        sh[e] = ss[(tc * 8 + e) * 2 + 1];
+    }
+    for (int pix = p0 + tr; pix < p1; pix += trows) {
+        const f16x8 v = gn_load(p, b, pix, col0 + tc);
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = (float)v[e] * ss[(col * 8 + e) * 2] + ss[(col * 8 + e) * 2 + 1];
+            float f = (float)v[e] * sc[e] + sh[e];
             if (p.silu) f = silu_f(f);
             o[e] = (f16)f;
         }
-        *reinterpret_cast<f16x8*>(p.y + ((size_t)b * p.HW + pix) * p.C + col * 8) = o;
+        *reinterpret_cast<f16x8*>(p.y + ((size_t)b * p.HW + pix) * p.C + (col0 + tc) * 8) = o;
     }
+}
+
+int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+
+// Fill the launch geometry: column blocks of whole groups (<= 64 chunk columns), <= 64 pixel slabs per sample,
+// aiming at ~1024 blocks so that even the 8x8-latent levels fill the 256 CUs.
+void gn_geometry(GnParams& p) {
+    const int lcm = p.cpg / gcd_i(p.cpg, 8) * 8;   // channels spanned by a whole number of groups AND of chunks
+    const int L = lcm / 8;                          // ... in chunk columns
+    int cw = (64 / L) * L;
+    if (cw == 0) cw = L;                            // a single group wider than 64 chunks (cpg > 512): one group/block
+    if (cw > p.CC) cw = p.CC;
+    p.cw = cw;
+    p.ncb = (p.CC + cw - 1) / cw;
+    int nblk = (GN_TARGET_BLOCKS + p.ncb * p.B - 1) / (p.ncb * p.B);
+    if (nblk > GN_MAX_NBLK) nblk = GN_MAX_NBLK;
+    const int max_by_pix = (p.HW + 3) / 4;          // at least ~4 pixels per slab
+    if (nblk > max_by_pix) nblk = max_by_pix;
+    if (nblk < 1) nblk = 1;
+    p.pix = (p.HW + nblk - 1) / nblk;
+    p.nblk = (p.HW + p.pix - 1) / p.pix;
 }
 
 // LayerNorm: one wave per row, up to 8 chunks (C <= 4096) held in registers; exact two-pass statistics.
@@ -188,9 +233,9 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
 }  // namespace
 
 extern "C" size_t mdx_groupnorm_ws_floats(int B, int HW, int C, int groups) {
+    (void)HW;
     (void)C;
-    const int nblk = (HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK;
-    return (size_t)B * nblk * groups * 2;
+    return (size_t)B * GN_MAX_NBLK * groups * 2;
 }
 
 extern "C" int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,
@@ -200,9 +245,9 @@ extern "C" int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2,
     MDX_REQUIRE((C2 == 0) == (x2 == nullptr), "mdx_groupnorm_f16: x2/C2 mismatch");
     const int C = C1 + C2;
     MDX_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 % 8 == 0, "mdx_groupnorm_f16: channels must be multiples of 8");
-    MDX_REQUIRE(groups > 0 && groups <= 256 && C % groups == 0, "mdx_groupnorm_f16: C=%d not divisible by groups=%d", C, groups);
+    MDX_REQUIRE(groups > 0 && groups <= 32 && C % groups == 0, "mdx_groupnorm_f16: C=%d not divisible by groups=%d (<= 32)", C, groups);
     MDX_REQUIRE(C <= GN_MAX_C, "mdx_groupnorm_f16: C=%d exceeds %d", C, GN_MAX_C);
-    MDX_REQUIRE(B > 0 && HW > 0, "mdx_groupnorm_f16: bad extents");
+    MDX_REQUIRE(B > 0 && HW > 0 && B <= 65535, "mdx_groupnorm_f16: bad extents");
     GnParams p{};
     p.x1 = (const f16*)x1;
     p.x2 = (const f16*)x2;
@@ -219,16 +264,18 @@ extern "C" int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2,
     p.HW = HW;
     p.groups = groups;
     p.cpg = C / groups;
-    p.nblk = (HW + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK;
     p.eps = eps;
     p.silu = silu;
+    gn_geometry(p);
+    MDX_REQUIRE((p.cw * 8) % p.cpg == 0 || p.ncb == 1, "mdx_groupnorm_f16: internal geometry error");
     hipStream_t st = (hipStream_t)s;
-    dim3 grid(p.nblk, B);
-    const int tcols = p.CC < 256 ? p.CC : 256;
-    const int trows = 256 / tcols;
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), (size_t)trows * C * 2 * sizeof(float), st, p);
+    dim3 grid(p.nblk, p.ncb, B);
+    MDX_REQUIRE(p.cw <= 256, "mdx_groupnorm_f16: %d channels per group is not supported", p.cpg);
+    const int cols = p.cw;
+    // stats LDS: [trows][cols*8][2] floats with trows*cols <= 256 for every (possibly narrower, last) column block
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), (size_t)256 * 8 * 2 * sizeof(float), st, p);
     MDX_LAUNCH_CHECK("mdx_groupnorm_f16(stats)");
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), ((size_t)C * 2 + groups * 2) * sizeof(float), st, p);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), ((size_t)cols * 8 * 2 + 64) * sizeof(float), st, p);
     MDX_LAUNCH_CHECK("mdx_groupnorm_f16(apply)");
     return MDX_OK;
 }

@@ -87,6 +87,9 @@ def test_nchw_nhwc_roundtrip(ops):
     (2, 16, 16, 640, 320, True, 1e-5),
     (1, 5, 7, 320, 0, False, 1e-6),          # ragged pixel count, SpatialTransformer norm (no SiLU, eps 1e-6)
     (1, 64, 64, 320, 0, True, 1e-5),
+    (2, 8, 8, 1280, 640, True, 1e-5),        # C = 1920: 60 channels per group (15-chunk group period)
+    (1, 4, 4, 192, 0, True, 1e-5),           # GLIDE width: 6 channels per group
+    (3, 2, 2, 1280, 0, False, 1e-6),         # 4 pixels per sample
 ])
 def test_groupnorm(ops, B, H, W, C1, C2, silu, eps):
     rng = np.random.RandomState(C1 + C2 + H)
