@@ -16,7 +16,9 @@
  *    tensors exist only at the apply_model boundary (mdx_nchw_to_nhwc_f16 /
  *    mdx_nhwc_to_nchw_f32).
  *  - Weights are fp16, packed [N][K] (K contiguous): nn.Dense weight [out][in] as is;
- *    nn.Conv2d weight [out][in][kh][kw] repacked to [out][kh*kw][in].
+ *    nn.Conv2d weight [out][in][kh][kw] repacked to [out][in/64][kh*kw][64] when in % 64 == 0
+ *    (channel-chunk major, tap minor: consecutive K tiles then touch the same pixels), else to
+ *    [out][kh*kw][in] (only conv_in, in = 4 padded to 8).
  *  - Return value: 0 = ok, negative = error (MDX_E_*); mdx_last_error() returns a
  *    thread-local message.  Nothing throws or exits across the ABI.
  */
@@ -70,7 +72,7 @@ typedef struct mdx_gemm_desc {
     const void* a;        /* source 1, NHWC fp16 [B][H][W][c1] */
     const void* a2;       /* optional source 2 (channel concat), [B][H][W][c2], or NULL */
     int c1, c2;           /* Cin = c1 + c2 (each a multiple of 8) */
-    const void* w;        /* packed weights fp16 [N][ksize*ksize*Cin] */
+    const void* w;        /* packed weights fp16 [N][ksize*ksize*Cin], K order as described above */
     const float* bias;    /* [N] fp32 or NULL */
     const float* rowbias; /* [B][rowbias_ld] fp32 per-sample bias (ResBlock emb add, openaimodel.py:188-200) or NULL */
     int rowbias_ld;
@@ -141,6 +143,9 @@ int mdx_sampler_step_f32(const float* x, const void* eps_u, const void* eps_c, i
 
 /* ---- probes used by tests to pin hardware layout assumptions (not on the hot path) */
 int mdx_probe_mfma_32x32x16_f16(const void* a, const void* b, float* c, mdx_stream_t s);
+/* streaming-bandwidth probe of the HBM/L2 -> LDS DMA path (mode 0) vs plain vector loads (mode 1) */
+int mdx_probe_dma_stream(const void* src, size_t bytes_per_block, int nblocks, int waves, int per, int ns, int mode,
+                         int stride_tiles, float* sink, mdx_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,7 @@ SIGNATURES = {
                                      c_void_p, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mdx_probe_mfma_32x32x16_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdx_probe_dma_stream": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -18,6 +18,8 @@
 //    are fused there.  Small-M layers use split-K (fp32 slabs + a fused reduce/epilogue kernel).
 #include "mdx_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct GemmParams {
@@ -35,13 +37,12 @@ struct GemmParams {
     int ksize, stride, upsample, pad;
     int epilogue, out_mode;
     int ktiles, ktiles_per_split, nsplit;
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n, tiles_per_xcd, n_fastest;
     unsigned a_bytes, a2_bytes, w_bytes;
+    int bk;
 };
 
 constexpr int BM = 128;
-constexpr int BK = 64;
-constexpr int ROWB = BK * 2;  // 128 bytes per LDS row
 
 __device__ __forceinline__ f16x4 cvt4(float a, float b, float c, float d) {
     f16x4 v;
@@ -72,13 +73,20 @@ __device__ __forceinline__ void epilogue_store_row8(const GemmParams& p, float (
     *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + n) = o;
 }
 
-template <int BN, bool SWAP, bool FASTK>
+template <int BN, int BK, int NS, bool SWAP, bool FASTK>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     constexpr int TN = BN / 64;             // 32-wide MFMA tiles per wave along n
-    constexpr int A_BYTES = BM * ROWB;      // 16 KiB
+    constexpr int ROWB = BK * 2;            // bytes per LDS row (128 | 64)
+    constexpr int CPRW = BK / 8;            // 16-B chunks per row (8 | 4)
+    constexpr int RPI = 64 / CPRW;          // rows covered by one wave-wide DMA instruction (8 | 16)
+    constexpr int RP256 = 256 / ROWB;       // rows per 256-B LDS bank row (2 | 4): swizzle key = (row / RP256) % CPRW
+    constexpr int KS = BK / 16;             // MFMA k-steps per K tile
+    constexpr int A_BYTES = BM * ROWB;
     constexpr int B_BYTES = BN * ROWB;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int BJ = BN / 32;             // B-tile DMA instructions per wave
+    constexpr int AJ = BM / RPI / 4;        // A-tile DMA instructions per wave
+    constexpr int BJ = BN / RPI / 4;        // B-tile DMA instructions per wave
+    static_assert(AJ >= 1 && BJ >= 1, "tile too small for 4 loader waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -88,8 +96,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     const int hi = lane >> 5;
     const int l31 = lane & 31;
 
-    const int tile_n = blockIdx.x % p.tiles_n;
-    const int tile_m = blockIdx.x / p.tiles_n;
+    // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (per-XCD L2s are private), so give every
+    // XCD a CONTIGUOUS run of tile ids; ids run fastest along the dimension that shares the bigger operand.
+    const int tile_id = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile_id >= p.tiles_m * p.tiles_n) return;
+    int tile_m, tile_n;
+    if (p.n_fastest) {
+        tile_m = tile_id / p.tiles_n;
+        tile_n = tile_id - tile_m * p.tiles_n;
+    } else {
+        tile_n = tile_id / p.tiles_m;
+        tile_m = tile_id - tile_n * p.tiles_m;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int split = blockIdx.y;
     const int kt_begin = split * p.ktiles_per_split;
@@ -100,88 +118,114 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
 
     // ---- loader coordinates (fixed per thread across K tiles)
-    // A: wave-instruction j covers rows wave*32 + j*8 .. +7; lane -> row +(lane>>3), physical chunk lane&7
-    int a_pix[4];   // b*H*W
-    int a_y[4], a_x[4];
-    unsigned a_chunk[4];  // logical 16-B chunk (un-swizzled) this lane fetches
-    bool a_ok[4];
+    // DMA instruction j of a wave covers rows (wave*AJ + j)*RPI .. +RPI-1; lane -> row + lane/CPRW, physical chunk lane%CPRW
+    const int lrow = lane / CPRW, lchk = lane % CPRW;
+    int a_pix[AJ];            // pixel index of tap (0,0): (b*H + y0)*W + x0 (may lie outside the image)
+    int a_y[AJ], a_x[AJ];     // y0, x0 (source coordinates of tap (0,0); upsampled coordinates when p.upsample)
+    int a_b[AJ];              // b*H*W
+    unsigned a_cb[AJ];        // byte offset of this lane's logical chunk inside a row
+    unsigned a_mask[AJ];      // bit t set <=> tap t is inside the image for this row (and the row exists)
+    const int Hs = p.upsample ? 2 * p.H : p.H;  // extent the taps are clipped against
+    const int Ws = p.upsample ? 2 * p.W : p.W;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wave * 32 + j * 8 + (lane >> 3);
+    for (int j = 0; j < AJ; ++j) {
+        const int row = (wave * AJ + j) * RPI + lrow;
         const int m = m0 + row;
-        a_ok[j] = m < p.M;
-        const int mm = a_ok[j] ? m : 0;
+        const bool okm = m < p.M;
+        const int mm = okm ? m : 0;
         const int b = mm / p.HoWo;
         const int rem = mm - b * p.HoWo;
         const int yo = rem / p.Wo;
         const int xo = rem - yo * p.Wo;
-        a_pix[j] = b * p.H * p.W;
+        a_b[j] = b * p.H * p.W;
         a_y[j] = yo * p.stride - p.pad;
         a_x[j] = xo * p.stride - p.pad;
-        a_chunk[j] = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+        a_pix[j] = a_b[j] + a_y[j] * p.W + a_x[j];
+        a_cb[j] = (unsigned)((lchk ^ ((row / RP256) % CPRW)) * 16);
+        unsigned mk = 0;
+        for (int t = 0; t < p.ksize * p.ksize; ++t) {
+            const int ky = (p.ksize == 3) ? t / 3 : 0, kx = (p.ksize == 3) ? t - ky * 3 : 0;
+            const int yi = a_y[j] + ky, xi = a_x[j] + kx;
+            if (okm && yi >= 0 && yi < Hs && xi >= 0 && xi < Ws) mk |= 1u << t;
+        }
+        a_mask[j] = mk;
     }
-    unsigned b_off[BJ];  // byte offset of (n, chunk) at k0 = 0, or OOB
-    unsigned b_chunk[BJ];
+    unsigned b_off[BJ];  // byte offset of (n, logical chunk) at k = 0, or OOB
+    unsigned b_cb[BJ];
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int row = wave * (BN / 4) + j * 8 + (lane >> 3);
+        const int row = (wave * BJ + j) * RPI + lrow;
         const int n = n0 + row;
-        b_chunk[j] = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
-        b_off[j] = (n < p.N) ? (unsigned)(((size_t)n * p.K + b_chunk[j] * 8) * 2) : MDX_OOB;
+        b_cb[j] = (unsigned)((lchk ^ ((row / RP256) % CPRW)) * 16);
+        b_off[j] = (n < p.N) ? (unsigned)((size_t)n * p.K * 2 + b_cb[j]) : MDX_OOB;
     }
-    const int Hs = p.upsample ? 2 * p.H : p.H;  // extent the taps are clipped against
-    const int Ws = p.upsample ? 2 * p.W : p.W;
 
     auto stage_tile = [&](int kt, int buf) {
         char* sbase = smem + buf * STAGE;
         const int k0 = kt * BK;
         if constexpr (FASTK) {
-            // Cin % 64 == 0 (and c1 % 64 == 0): the whole K tile lies in one tap and one source.
-            const int tap = k0 / p.cin;
-            int ci0 = k0 - tap * p.cin;
+            // K is ordered [cin chunk of 64][tap][64] (weights packed to match; Cin % 64 == 0, c1 % 64 == 0), so a K
+            // tile lies in one tap and one source, and consecutive K tiles re-read the SAME pixels' cache lines
+            // shifted by one tap: the 9x im2col re-read of the activations is served by L2, not by the fabric.
+            const int taps = p.ksize * p.ksize;
+            const int g = k0 >> 6;
+            const int chunk = g / taps;
+            const int tap = g - chunk * taps;
+            int ci0 = chunk * 64 + (k0 & 63);
             const int ky = (p.ksize == 3) ? tap / 3 : 0;
             const int kx = (p.ksize == 3) ? tap - ky * 3 : 0;
             const bool second = ci0 >= p.c1;
-            const int cs = second ? p.c2 : p.c1;
+            const int cs2 = (second ? p.c2 : p.c1) * 2;
             if (second) ci0 -= p.c1;
+            if (!p.upsample) {
+                const int dpix = ky * p.W + kx;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int yi = a_y[j] + ky, xi = a_x[j] + kx;
-                const bool ok = a_ok[j] && yi >= 0 && yi < Hs && xi >= 0 && xi < Ws;
-                if (p.upsample) {
-                    yi >>= 1;
-                    xi >>= 1;
+                for (int j = 0; j < AJ; ++j) {
+                    const unsigned off = ((a_mask[j] >> tap) & 1u)
+                                             ? (unsigned)((a_pix[j] + dpix) * cs2) + (unsigned)(ci0 * 2) + a_cb[j]
+                                             : MDX_OOB;
+                    void* dst = sbase + (wave * AJ + j) * 1024;
+                    if (second)
+                        dma16(rs_a2, dst, off);
+                    else
+                        dma16(rs_a, dst, off);
                 }
-                const unsigned off =
-                    ok ? (unsigned)(((size_t)(a_pix[j] + yi * p.W + xi) * cs + ci0 + a_chunk[j] * 8) * 2) : MDX_OOB;
-                void* dst = sbase + (wave * 4 + j) * 1024;
-                if (second)
-                    dma16(rs_a2, dst, off);
-                else
-                    dma16(rs_a, dst, off);
+            } else {
+#pragma unroll
+                for (int j = 0; j < AJ; ++j) {
+                    const int yi = (a_y[j] + ky) >> 1, xi = (a_x[j] + kx) >> 1;
+                    const unsigned off = ((a_mask[j] >> tap) & 1u)
+                                             ? (unsigned)((a_b[j] + yi * p.W + xi) * cs2) + (unsigned)(ci0 * 2) + a_cb[j]
+                                             : MDX_OOB;
+                    void* dst = sbase + (wave * AJ + j) * 1024;
+                    if (second)
+                        dma16(rs_a2, dst, off);
+                    else
+                        dma16(rs_a, dst, off);
+                }
             }
         } else {
-            // generic: per-lane tap decode (single source only)
+            // generic: tap-major K, per-lane tap decode (single source only; conv_in with Cin = 8)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kk = k0 + (int)a_chunk[j] * 8;
+            for (int j = 0; j < AJ; ++j) {
+                const int kk = k0 + (int)(a_cb[j] >> 1);
                 const int tap = kk / p.cin;
                 const int ci = kk - tap * p.cin;
                 const int ky = (p.ksize == 3) ? tap / 3 : 0;
                 const int kx = (p.ksize == 3) ? tap - ky * 3 : 0;
                 int yi = a_y[j] + ky, xi = a_x[j] + kx;
-                const bool ok = a_ok[j] && kk < p.K && yi >= 0 && yi < Hs && xi >= 0 && xi < Ws;
+                const bool ok = kk < p.K && ((a_mask[j] >> tap) & 1u);
                 if (p.upsample) {
                     yi >>= 1;
                     xi >>= 1;
                 }
-                const unsigned off = ok ? (unsigned)(((size_t)(a_pix[j] + yi * p.W + xi) * p.cin + ci) * 2) : MDX_OOB;
-                dma16(rs_a, sbase + (wave * 4 + j) * 1024, off);
+                const unsigned off = ok ? (unsigned)(((size_t)(a_b[j] + yi * p.W + xi) * p.cin + ci) * 2) : MDX_OOB;
+                dma16(rs_a, sbase + (wave * AJ + j) * 1024, off);
             }
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            const bool ok = b_off[j] != MDX_OOB && (FASTK || (k0 + (int)b_chunk[j] * 8) < p.K);
+            const bool ok = b_off[j] != MDX_OOB && (FASTK || (k0 + (int)(b_cb[j] >> 1)) < p.K);
             const unsigned off = ok ? b_off[j] + (unsigned)k0 * 2 : MDX_OOB;
             dma16(rs_w, sbase + A_BYTES + (wave * BJ + j) * 1024, off);
         }
@@ -195,40 +239,66 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment read offsets: row*128 + ((2s+hi) ^ ((row>>1)&7))*16, (row>>1)&7 == (lane>>1)&7 for all our row bases
-    const int swz = (lane >> 1) & 7;
+    // fragment read offsets: row*ROWB + ((2s+hi) ^ key(row))*16; key(row) depends only on the lane for all our row bases
+    const int swz = (l31 / RP256) % CPRW;
     const int a_row_off = (wm * 64 + l31) * ROWB;
     const int b_row_off = A_BYTES + (wn * (BN / 2) + l31) * ROWB;
 
-    if (kt_begin < kt_end) {
-        stage_tile(kt_begin, 0);
-    }
-    __syncthreads();  // (compiler inserts vmcnt(0) for the pending LDS-DMA writes)
-    int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        if (kt + 1 < kt_end) stage_tile(kt + 1, buf ^ 1);
-        const char* sb = smem + buf * STAGE;
+    // ---- main loop: NS-stage LDS ring.  DMAs of the next NS-1 K tiles stay in flight ACROSS the per-tile barrier
+    // (counted s_waitcnt vmcnt + raw s_barrier: __syncthreads() would drain them), fragments for k-step s+1 are
+    // fetched from LDS while the MFMAs of k-step s run.
+    //   iteration t:  wait(tile t landed for this wave) -> s_barrier (=> landed for all waves, and every wave is
+    //                 done reading stage (t-1)%NS) -> issue tile t+NS-1 into stage (t-1)%NS -> compute tile t.
+    constexpr int LPT = AJ + BJ;  // DMA instructions per wave per K tile
+    const int nt = kt_end - kt_begin;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int coff = (((2 * s + hi) ^ swz) << 4);
-            f16x8 af[2], bf[TN];
+    for (int i = 0; i < NS - 1; ++i)
+        if (i < nt) stage_tile(kt_begin + i, i);
+    int rd = 0;            // stage holding tile t
+    int wr = NS - 1;       // stage that tile t+NS-1 goes to
+    for (int t = 0; t < nt; ++t) {
+        // tiles t .. min(t+NS-2, nt-1) are outstanding; allow all but the oldest to stay in flight
+        const int ahead = min(NS - 2, nt - 1 - t);
+        if (NS >= 5 && ahead >= 3)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+        else if (NS >= 4 && ahead == 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (NS >= 3 && ahead == 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NS - 1 < nt) stage_tile(kt_begin + t + NS - 1, wr);
+        const char* sb = smem + rd * STAGE;
+        f16x8 af[2][2], bf[2][TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + coff);
+        for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + ((hi ^ swz) << 4));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + coff);
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + ((hi ^ swz) << 4));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s < KS - 1) {
+                const int coff = (((2 * (s + 1) + hi) ^ swz) << 4);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[nxt][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + coff);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + coff);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if constexpr (SWAP)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
                     else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();
-        buf ^= 1;
+        rd = (rd + 1 == NS) ? 0 : rd + 1;
+        wr = (wr + 1 == NS) ? 0 : wr + 1;
     }
+    __syncthreads();  // all waves done with the ring before the epilogue reuses it
 
     // ------------------------------------------------------------------ epilogue
     if constexpr (!SWAP) {
@@ -457,7 +527,6 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     p.a_bytes = (unsigned)ab;
     p.a2_bytes = (unsigned)a2b;
     p.w_bytes = (unsigned)wb;
-    p.ktiles = (p.K + BK - 1) / BK;
     return MDX_OK;
 }
 
@@ -468,22 +537,79 @@ int pick_bn(const GemmParams& p) {
     return (p.N % 128 > 64) ? 128 : 64;
 }
 
+struct GemmCfg {
+    int bn, bk, ns;
+};
+
+// Tile configuration.  Experiments: MDX_GEMM_CFG="bk,ns" overrides (bk in {32,64}, ns in {2,3,4}).
+GemmCfg pick_cfg(const GemmParams& p) {
+    GemmCfg c;
+    c.bn = pick_bn(p);
+    c.bk = 64;
+    c.ns = 2;   // ring depth is finalised in mdx_gemm_f16 once the grid size is known
+    static const char* env = getenv("MDX_GEMM_CFG");
+    if (env) {
+        int bk = 0, ns = 0;
+        if (sscanf(env, "%d,%d", &bk, &ns) == 2 && (bk == 32 || bk == 64) && ns >= 2 && ns <= 5) {
+            c.bk = bk;
+            c.ns = ns;
+        }
+    }
+    return c;
+}
+
+// Split-K heuristic, from the measured sweep (profiles/r01_gemm_splitk_sweep.txt): one 128-row tile pulls only
+// ~50 GB/s through the DMA path, so small grids are spread over ~1.4 blocks per CU by splitting K; above ~176 tiles
+// the fp32 slab round trip costs more than it buys.
 int auto_split(const GemmParams& p, int bn) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + bn - 1) / bn);
-    int ns = 256 / tiles;               // aim for >= ~1 block per CU
-    const int maxk = p.ktiles / 4;      // keep >= 4 K tiles (256 k) per split
+    int ns = (352 + tiles / 2) / tiles;
+    const int maxk = (p.K / 64) / 4;    // keep >= 256 k per split
     if (ns > maxk) ns = maxk;
-    if (ns > 32) ns = 32;
+    if (ns > 16) ns = 16;
     return ns < 1 ? 1 : ns;
 }
 
-template <int BN, bool SWAP>
-void launch_gemm(const GemmParams& p, bool fastk, dim3 grid, hipStream_t st) {
-    const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
-    if (fastk)
-        hipLaunchKernelGGL((gemm_kernel<BN, SWAP, true>), grid, dim3(256), lds, st, p);
-    else
-        hipLaunchKernelGGL((gemm_kernel<BN, SWAP, false>), grid, dim3(256), lds, st, p);
+template <int BN, int BK, int NS, bool SWAP, bool FASTK>
+void launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
+    constexpr size_t ring = (size_t)NS * (BM + BN) * BK * 2;
+    constexpr size_t epi = (size_t)(BM > BN ? BM : BN) * ((BM > BN ? BN : BM) + 8) * 2 + 4096;  // staged C tile
+    constexpr size_t lds = ring > epi ? ring : epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BN, BK, NS, SWAP, FASTK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<BN, BK, NS, SWAP, FASTK>), grid, dim3(256), lds, st, p);
+}
+
+template <int BN, int BK, int NS>
+void launch_cfg(const GemmParams& p, bool swap, bool fastk, dim3 grid, hipStream_t st) {
+    if (swap) {
+        if (fastk)
+            launch_one<BN, BK, NS, true, true>(p, grid, st);
+        else
+            launch_one<BN, BK, NS, true, false>(p, grid, st);
+    } else {
+        if (fastk)
+            launch_one<BN, BK, NS, false, true>(p, grid, st);
+        else
+            launch_one<BN, BK, NS, false, false>(p, grid, st);
+    }
+}
+
+template <int BN>
+bool launch_bn(const GemmCfg& c, const GemmParams& p, bool swap, bool fastk, dim3 grid, hipStream_t st) {
+    if (c.bk == 64 && c.ns == 2) launch_cfg<BN, 64, 2>(p, swap, fastk, grid, st);
+    else if (c.bk == 64 && c.ns == 3) launch_cfg<BN, 64, 3>(p, swap, fastk, grid, st);
+    else if (c.bk == 64 && c.ns == 4) launch_cfg<BN, 64, 4>(p, swap, fastk, grid, st);
+    else if (c.bk == 64 && c.ns == 5) launch_cfg<BN, 64, 5>(p, swap, fastk, grid, st);
+    else if (c.bk == 32 && c.ns == 2) launch_cfg<BN, 32, 2>(p, swap, fastk, grid, st);
+    else if (c.bk == 32 && c.ns == 3) launch_cfg<BN, 32, 3>(p, swap, fastk, grid, st);
+    else if (c.bk == 32 && c.ns == 4) launch_cfg<BN, 32, 4>(p, swap, fastk, grid, st);
+    else return false;
+    return true;
 }
 
 }  // namespace
@@ -491,8 +617,8 @@ void launch_gemm(const GemmParams& p, bool fastk, dim3 grid, hipStream_t st) {
 extern "C" size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d) {
     GemmParams p{};
     if (fill_params(d, p) != MDX_OK) return 0;
-    const int bn = pick_bn(p);
-    const int ns = d->splitk > 0 ? d->splitk : auto_split(p, bn);
+    const GemmCfg c = pick_cfg(p);
+    const int ns = d->splitk > 0 ? d->splitk : auto_split(p, c.bn);
     return ns > 1 ? (size_t)ns * p.M * p.N * sizeof(float) : 0;
 }
 
@@ -510,7 +636,10 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     int rc = fill_params(d, p);
     if (rc != MDX_OK) return rc;
     hipStream_t st = (hipStream_t)s;
-    const int bn = pick_bn(p);
+    const GemmCfg c = pick_cfg(p);
+    const int bn = c.bn;
+    p.bk = c.bk;
+    p.ktiles = (p.K + c.bk - 1) / c.bk;
     int ns = d->splitk > 0 ? d->splitk : auto_split(p, bn);
     if (ns > p.ktiles) ns = p.ktiles;
     if (ns > 1) {
@@ -533,19 +662,20 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     p.tiles_n = (p.N + bn - 1) / bn;
     const bool fastk = (p.cin % 64 == 0) && (p.c2 == 0 || p.c1 % 64 == 0);
     MDX_REQUIRE(fastk || p.c2 == 0, "mdx_gemm_f16: two-source input needs c1 %% 64 == 0 and Cin %% 64 == 0");
-    dim3 grid(p.tiles_m * p.tiles_n, ns);
-    const bool swap = (ns == 1) && (p.out_mode == MDX_OUT_ROWMAJOR);
-    if (bn == 128) {
-        if (swap)
-            launch_gemm<128, true>(p, fastk, grid, st);
-        else
-            launch_gemm<128, false>(p, fastk, grid, st);
-    } else {
-        if (swap)
-            launch_gemm<64, true>(p, fastk, grid, st);
-        else
-            launch_gemm<64, false>(p, fastk, grid, st);
+    const int ntiles = p.tiles_m * p.tiles_n;
+    p.tiles_per_xcd = (ntiles + 7) / 8;
+    // share the bigger operand inside an XCD: unique activation bytes vs weight bytes
+    p.n_fastest = ((size_t)p.M * p.cin >= (size_t)p.N * p.K) ? 1 : 0;
+    dim3 grid(8 * p.tiles_per_xcd, ns);
+    GemmCfg cc = c;
+    if (!getenv("MDX_GEMM_CFG")) {
+        // <= 1 block per CU: LDS is not what limits residency, so spend it on a deeper DMA ring (measured +15-20 %
+        // on the split-K'd small-M layers); otherwise 2 stages keep 2-3 blocks resident per CU.
+        cc.ns = (ntiles * ns <= 256) ? 3 : 2;
     }
+    const bool swap = (ns == 1) && (p.out_mode == MDX_OUT_ROWMAJOR);
+    const bool ok = (bn == 128) ? launch_bn<128>(cc, p, swap, fastk, grid, st) : launch_bn<64>(cc, p, swap, fastk, grid, st);
+    MDX_REQUIRE(ok, "mdx_gemm_f16: unsupported tile configuration bk=%d ns=%d", c.bk, c.ns);
     MDX_LAUNCH_CHECK("mdx_gemm_f16");
     if (ns > 1) {
         const int ncols = p.epilogue == MDX_EPI_GEGLU ? p.N / 2 : p.N;

@@ -259,3 +259,74 @@ extern "C" int mdx_probe_mfma_32x32x16_f16(const void* a, const void* b, float* 
     MDX_LAUNCH_CHECK("mdx_probe_mfma_32x32x16_f16");
     return MDX_OK;
 }
+
+// ------------------------------------------------------------------ DMA / load streaming probe (tools/dma_probe.py)
+// Measures what ONE workgroup per CU can pull through `buffer_load ... lds` (mode 0) or through plain
+// global_load_dwordx4 into registers (mode 1): tiles of 1 KiB per wave-instruction, `per` instructions per wave per
+// tile, NS tiles in flight.  Not on the hot path.
+namespace {
+template <int NS>
+__global__ __launch_bounds__(512) void dma_probe_kernel(const char* src, size_t bytes_per_block, int per, int mode,
+                                                        int stride_tiles, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const size_t tile_bytes = (size_t)nw * per * 1024;
+    const int nt = (int)(bytes_per_block / tile_bytes);
+    const char* base = src + (size_t)blockIdx.x * bytes_per_block;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, (unsigned)bytes_per_block);
+    float acc = 0.f;
+    if (mode == 0) {
+        auto issue = [&](int t, int stage) {
+            for (int j = 0; j < per; ++j) {
+                const unsigned off = (unsigned)((size_t)(t * stride_tiles % nt) * tile_bytes + ((wave * per + j) * 64 + lane) * 16);
+                dma16(rs, smem + (size_t)stage * tile_bytes + (wave * per + j) * 1024, off);
+            }
+        };
+        for (int i = 0; i < NS - 1 && i < nt; ++i) issue(i, i);
+        int wr = NS - 1;
+        for (int t = 0; t < nt; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // conservative: drain own DMAs (depth comes from other waves/tiles)
+            __builtin_amdgcn_s_barrier();
+            if (t + NS - 1 < nt) issue(t + NS - 1, wr);
+            wr = (wr + 1 == NS) ? 0 : wr + 1;
+        }
+        acc = ((float*)smem)[threadIdx.x];
+    } else {
+        const f32x4* g = reinterpret_cast<const f32x4*>(base);
+        f32x4 v[8];
+        for (int t = 0; t < nt; ++t) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < per) v[j] = g[((size_t)(t * stride_tiles % nt) * tile_bytes + ((wave * per + j) * 64 + lane) * 16) / 16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < per) acc += v[j][0] + v[j][3];
+        }
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+}  // namespace
+
+extern "C" int mdx_probe_dma_stream(const void* src, size_t bytes_per_block, int nblocks, int waves, int per, int ns,
+                                    int mode, int stride_tiles, float* sink, mdx_stream_t s) {
+    MDX_REQUIRE(src && sink && nblocks > 0 && waves >= 1 && waves <= 8 && per >= 1 && per <= 8 && ns >= 2 && ns <= 4,
+                "mdx_probe_dma_stream: bad arguments");
+    const size_t lds = (size_t)ns * waves * per * 1024;
+    MDX_REQUIRE(lds <= 160 * 1024, "mdx_probe_dma_stream: ring too large");
+    hipStream_t st = (hipStream_t)s;
+#define MDX_PROBE_LAUNCH(NSV)                                                                                        \
+    {                                                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dma_probe_kernel<NSV>),                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                           \
+        hipLaunchKernelGGL(dma_probe_kernel<NSV>, dim3(nblocks), dim3(waves * 64), lds, st, (const char*)src,        \
+                           bytes_per_block, per, mode, stride_tiles, sink);                                          \
+    }
+    if (ns == 2) MDX_PROBE_LAUNCH(2)
+    else if (ns == 3) MDX_PROBE_LAUNCH(3)
+    else MDX_PROBE_LAUNCH(4)
+#undef MDX_PROBE_LAUNCH
+    MDX_LAUNCH_CHECK("mdx_probe_dma_stream");
+    return MDX_OK;
+}

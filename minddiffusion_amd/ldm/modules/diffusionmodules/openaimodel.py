@@ -227,12 +227,18 @@ class UNetModel:
         return t.to(device=self.device, dtype=dtype).contiguous()
 
     def _pack_conv(self, wt, cin_pad=None, cout_pad=None):
-        """[Cout,Cin,kh,kw] -> fp16 [Cout_pad][kh*kw*Cin_pad] (tap-major, cin-minor)."""
+        """[Cout,Cin,kh,kw] -> fp16 [Cout_pad][K] in the K order mdx_gemm_f16 expects (include/mdx.h):
+        [cin/64][kh*kw][64] when Cin % 64 == 0, else tap-major [kh*kw][Cin_pad]."""
         wt = wt if isinstance(wt, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(wt))
         wt = wt.to(self.device, f32)
         co, ci, kh, kw = wt.shape
         cip = cin_pad or ci
         cop = cout_pad or co
+        if cip % 64 == 0:
+            assert cip == ci
+            p = torch.zeros((cop, ci // 64, kh * kw, 64), dtype=f32, device=self.device)
+            p[:co] = wt.reshape(co, ci // 64, 64, kh * kw).permute(0, 1, 3, 2)
+            return p.reshape(cop, kh * kw * ci).to(f16).contiguous()
         p = torch.zeros((cop, kh * kw, cip), dtype=f32, device=self.device)
         p[:co, :, :ci] = wt.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
         return p.reshape(cop, kh * kw * cip).to(f16).contiguous()

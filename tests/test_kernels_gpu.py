@@ -41,8 +41,10 @@ def from_nhwc(y, b, h, w):  # [B*HW, C] or [B,HW,C] -> [B,C,H,W]
     return y.transpose(0, 3, 1, 2)
 
 
-def pack_conv(w):  # [Cout,Cin,kh,kw] -> [Cout, kh*kw*Cin]
+def pack_conv(w):  # [Cout,Cin,kh,kw] -> [Cout, K] in the kernel's K order (include/mdx.h)
     co, ci, kh, kw = w.shape
+    if ci % 64 == 0:   # [cin/64][tap][64]
+        return np.ascontiguousarray(w.reshape(co, ci // 64, 64, kh * kw).transpose(0, 1, 3, 2).reshape(co, kh * kw * ci))
     return np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(co, kh * kw * ci))
 
 

@@ -41,13 +41,14 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--only", default="")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--splits", default="0", help="comma list of split-K values to sweep (0 = auto)")
     args = ap.parse_args()
     from minddiffusion_amd import ops
     dev = torch.device("cuda:0")
     res = []
     for B in [int(b) for b in args.batches.split(",")]:
         for name, H, W, cin, cout, ks, epi in SHAPES_B1ROW:
-            if args.only and args.only not in name:
+            if args.only and not any(o in name for o in args.only.split(",")):
                 continue
             K = ks * ks * cin
             M = B * H * W
@@ -58,29 +59,33 @@ def main():
             bias = torch.randn(cout, device=dev)
             ncols = cout // 2 if epi else cout
             out = torch.empty(M, ncols, device=dev, dtype=torch.float16)
-            descs = [ops.make_gemm_desc(a, w, cout, B, H, W, cin, out, ncols, bias=bias, ksize=ks, epilogue=epi) for w in ws]
-            need = ops.gemm_workspace_bytes(descs[0])
-            wsp = torch.empty(max(need, 16) // 4, device=dev, dtype=torch.float32)
-            for d in descs:
-                d.workspace = wsp.data_ptr()
-                d.workspace_bytes = wsp.numel() * 4
-            for d in descs[:2]:
-                ops.gemm_run(d)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for i in range(args.iters):
-                ops.gemm_run(descs[i % ncopy])
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / args.iters
-            flops = 2.0 * M * cout * K
-            rec = dict(name=name, B=B, M=M, N=cout, K=K, us=round(us, 2), tflops=round(flops / us / 1e6, 1),
-                       w_gbs=round(wbytes / us / 1e3, 1), split=need // max(1, M * cout * 4))
-            res.append(rec)
-            print(f"B={B:2d} {name:18s} M={M:6d} N={cout:5d} K={K:5d} split={rec['split']:2d} {us:9.2f} us "
-                  f"{rec['tflops']:7.1f} TF/s  weights {rec['w_gbs']:7.1f} GB/s", flush=True)
-            del ws, descs, a, out
+            for sk in [int(x) for x in args.splits.split(",")]:
+                if sk > 1 and K // 64 < sk:
+                    continue
+                descs = [ops.make_gemm_desc(a, w, cout, B, H, W, cin, out, ncols, bias=bias, ksize=ks, epilogue=epi,
+                                            splitk=sk) for w in ws]
+                need = ops.gemm_workspace_bytes(descs[0])
+                wsp = torch.empty(max(need, 16) // 4, device=dev, dtype=torch.float32)
+                for d in descs:
+                    d.workspace = wsp.data_ptr()
+                    d.workspace_bytes = wsp.numel() * 4
+                for d in descs[:2]:
+                    ops.gemm_run(d)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(args.iters):
+                    ops.gemm_run(descs[i % ncopy])
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / args.iters
+                flops = 2.0 * M * cout * K
+                rec = dict(name=name, B=B, M=M, N=cout, K=K, us=round(us, 2), tflops=round(flops / us / 1e6, 1),
+                           w_gbs=round(wbytes / us / 1e3, 1), split=need // max(1, M * cout * 4))
+                res.append(rec)
+                print(f"B={B:2d} {name:18s} M={M:6d} N={cout:5d} K={K:5d} split={rec['split']:2d} {us:9.2f} us "
+                      f"{rec['tflops']:7.1f} TF/s  weights {rec['w_gbs']:7.1f} GB/s", flush=True)
+            del ws, a, out
     if args.out:
         json.dump(res, open(args.out, "w"))
 
