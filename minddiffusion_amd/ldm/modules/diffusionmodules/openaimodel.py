@@ -39,6 +39,7 @@ class _Arena:
     def __init__(self, device):
         self.device = device
         self.free = {}
+        self.bases = []   # every allocation, kept alive for the plan's lifetime: GEMM descriptors hold raw pointers
         self.total = 0
 
     def get(self, shape, dtype=f16):
@@ -49,6 +50,7 @@ class _Arena:
             base = lst.pop()
         else:
             base = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.bases.append(base)
             self.total += nbytes
         t = base[: n * torch.empty((), dtype=dtype).element_size()].view(dtype).view(*shape)
         t._mdx_base = base
@@ -590,6 +592,7 @@ class UNetModel:
         P.main, P.ctxops, P.descs, P.meta = main, ctxops, descs, meta
         assert len(main) == len(meta)
         P.arena_bytes = A.total
+        P.arena = A   # owns the activation buffers (descriptors only hold raw device pointers)
         P.graph = None
         P.graph_failed = False
         self._plans[key] = P

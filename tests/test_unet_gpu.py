@@ -148,3 +148,25 @@ def test_sd2_full_size_single_step():
     ref = oracle(x, torch.tensor([981.0]), ctx)
     got = net(torch.tensor(x, device=DEV), torch.tensor([981.0], device=DEV), torch.tensor(ctx, device=DEV))
     check("sd2_full_single_step_B1_64x64", got, ref, rel_l2=5e-3, max_abs=5e-2)
+
+
+def test_plan_buffers_survive_allocator_churn():
+    """Regression: GEMM descriptors hold raw device pointers, so the plan must own its activation buffers
+    (they used to be freed with the planning arena and recycled by the caching allocator)."""
+    import gc
+    cfg = _tiny_cfg()
+    params = O.init_params(_oracle_cfg(cfg), seed=6)
+    net = _build(cfg, params, True)
+    oracle = O.UNetOracle(_oracle_cfg(cfg), params)
+    x, ctx = _inputs(2, 16, 16, 9, cfg["context_dim"], seed=11)
+    xd, td, cd = torch.tensor(x, device=DEV), torch.full((2,), 301.0, device=DEV), torch.tensor(ctx, device=DEV)
+    ref = oracle(x, torch.full((2,), 301.0), ctx)
+    first = net(xd, td, cd)
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 20,), float(i), device=DEV) for i in range(64)]   # recycle whatever was freed
+    del junk
+    torch.cuda.empty_cache()
+    again = net(xd, td, cd)
+    assert torch.equal(first, again)
+    check("tiny_unet_after_allocator_churn", again, ref, rel_l2=5e-3, max_abs=5e-2)
