@@ -15,10 +15,14 @@
  *  - Activations are NHWC ("token-major") fp16: [B][H*W][C]; the reference's NCHW fp32
  *    tensors exist only at the apply_model boundary (mdx_nchw_to_nhwc_f16 /
  *    mdx_nhwc_to_nchw_f32).
- *  - Weights are fp16, packed [N][K] (K contiguous): nn.Dense weight [out][in] as is;
- *    nn.Conv2d weight [out][in][kh][kw] repacked to [out][in/64][kh*kw][64] when in % 64 == 0
- *    (channel-chunk major, tap minor: consecutive K tiles then touch the same pixels), else to
- *    [out][kh*kw][in] (only conv_in, in = 4 padded to 8).
+ *  - Weights are fp16 in a kernel-native packed format (minddiffusion_amd/ops.py: pack_gemm_weight /
+ *    pack_conv_weight produce it; it is the only format mdx_gemm_f16 accepts):
+ *      1. K order: nn.Dense weight [out][in] as is; nn.Conv2d weight [out][in][kh][kw] becomes
+ *         [out][in/64][kh*kw][64] when in % 64 == 0 (channel-chunk major, tap minor: consecutive K tiles touch
+ *         the same pixels), else [out][kh*kw][in] (only conv_in, in = 4 padded to 8);
+ *      2. N and K zero-padded to multiples of 64 and stored tile-major, [N/64][K/64][64 rows][8 chunks][8 halves],
+ *         with the 16-byte chunk at position q of row r holding logical chunk q ^ ((r >> 1) & 7) (the LDS
+ *         bank-conflict swizzle, applied once offline), so each DMA instruction reads 1 KiB of contiguous HBM.
  *  - Return value: 0 = ok, negative = error (MDX_E_*); mdx_last_error() returns a
  *    thread-local message.  Nothing throws or exits across the ABI.
  */
@@ -72,7 +76,7 @@ typedef struct mdx_gemm_desc {
     const void* a;        /* source 1, NHWC fp16 [B][H][W][c1] */
     const void* a2;       /* optional source 2 (channel concat), [B][H][W][c2], or NULL */
     int c1, c2;           /* Cin = c1 + c2 (each a multiple of 8) */
-    const void* w;        /* packed weights fp16 [N][ksize*ksize*Cin], K order as described above */
+    const void* w;        /* packed weights (format above), logical shape [N][ksize*ksize*Cin] */
     const float* bias;    /* [N] fp32 or NULL */
     const float* rowbias; /* [B][rowbias_ld] fp32 per-sample bias (ResBlock emb add, openaimodel.py:188-200) or NULL */
     int rowbias_ld;

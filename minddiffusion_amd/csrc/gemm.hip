@@ -38,6 +38,7 @@ struct GemmParams {
     int epilogue, out_mode;
     int ktiles, ktiles_per_split, nsplit;
     int tiles_m, tiles_n, tiles_per_xcd, n_fastest;
+    int kt64;   // 64-wide K tiles in the packed weight storage
     unsigned a_bytes, a2_bytes, w_bytes;
     int bk;
 };
@@ -150,14 +151,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         }
         a_mask[j] = mk;
     }
-    unsigned b_off[BJ];  // byte offset of (n, logical chunk) at k = 0, or OOB
-    unsigned b_cb[BJ];
+    // B (weights): stored tile-major and PRE-SWIZZLED on the host -- [N/64 panels][K/64 tiles][64 rows][8 chunks][8]
+    // with chunk position q holding logical chunk q ^ ((row>>1)&7) -- so every DMA instruction reads 1 KiB of
+    // CONTIGUOUS memory (no L2 channel camping on the K*2-byte row stride, sequential HBM streaming along K).
+    static_assert(BK == 64, "weight storage is tiled for BK = 64");
+    unsigned b_off[BJ];  // byte offset of this lane's 16 B inside K tile 0
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int row = (wave * BJ + j) * RPI + lrow;
-        const int n = n0 + row;
-        b_cb[j] = (unsigned)((lchk ^ ((row / RP256) % CPRW)) * 16);
-        b_off[j] = (n < p.N) ? (unsigned)((size_t)n * p.K * 2 + b_cb[j]) : MDX_OOB;
+        const int row = (wave * BJ + j) * RPI + lrow;   // 0 .. BN-1
+        const int panel = (n0 >> 6) + (row >> 6);
+        b_off[j] = (unsigned)(((size_t)panel * p.kt64) * 8192 + ((row & 63) * 8 + lchk) * 16);
     }
 
     auto stage_tile = [&](int kt, int buf) {
@@ -224,11 +227,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const bool ok = b_off[j] != MDX_OOB && (FASTK || (k0 + (int)(b_cb[j] >> 1)) < p.K);
-            const unsigned off = ok ? b_off[j] + (unsigned)k0 * 2 : MDX_OOB;
-            dma16(rs_w, sbase + A_BYTES + (wave * BJ + j) * 1024, off);
-        }
+        for (int j = 0; j < BJ; ++j)
+            dma16(rs_w, sbase + A_BYTES + (wave * BJ + j) * 1024, b_off[j] + (unsigned)kt * 8192);
     };
 
     f32x16 acc[2][TN];
@@ -521,7 +521,8 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     if (p.residual) MDX_REQUIRE(p.residual_ld % 8 == 0, "mdx_gemm_f16: residual_ld must be a multiple of 8");
     MDX_REQUIRE(p.out_ld % 8 == 0, "mdx_gemm_f16: out_ld must be a multiple of 8");
     const size_t ab = (size_t)d->B * d->H * d->W * d->c1 * 2, a2b = (size_t)d->B * d->H * d->W * d->c2 * 2;
-    const size_t wb = (size_t)p.N * p.K * 2;
+    p.kt64 = (p.K + 63) / 64;
+    const size_t wb = (size_t)((p.N + 63) / 64) * p.kt64 * 8192;   // padded, tile-major storage
     MDX_REQUIRE(ab <= 0x80000000ull && a2b <= 0x80000000ull && wb <= 0x80000000ull,
                 "mdx_gemm_f16: operand larger than 2 GiB is not addressable by one buffer descriptor");
     p.a_bytes = (unsigned)ab;
@@ -550,7 +551,7 @@ GemmCfg pick_cfg(const GemmParams& p) {
     static const char* env = getenv("MDX_GEMM_CFG");
     if (env) {
         int bk = 0, ns = 0;
-        if (sscanf(env, "%d,%d", &bk, &ns) == 2 && (bk == 32 || bk == 64) && ns >= 2 && ns <= 5) {
+        if (sscanf(env, "%d,%d", &bk, &ns) == 2 && bk == 64 && ns >= 2 && ns <= 5) {
             c.bk = bk;
             c.ns = ns;
         }
@@ -605,9 +606,6 @@ bool launch_bn(const GemmCfg& c, const GemmParams& p, bool swap, bool fastk, dim
     else if (c.bk == 64 && c.ns == 3) launch_cfg<BN, 64, 3>(p, swap, fastk, grid, st);
     else if (c.bk == 64 && c.ns == 4) launch_cfg<BN, 64, 4>(p, swap, fastk, grid, st);
     else if (c.bk == 64 && c.ns == 5) launch_cfg<BN, 64, 5>(p, swap, fastk, grid, st);
-    else if (c.bk == 32 && c.ns == 2) launch_cfg<BN, 32, 2>(p, swap, fastk, grid, st);
-    else if (c.bk == 32 && c.ns == 3) launch_cfg<BN, 32, 3>(p, swap, fastk, grid, st);
-    else if (c.bk == 32 && c.ns == 4) launch_cfg<BN, 32, 4>(p, swap, fastk, grid, st);
     else return false;
     return true;
 }

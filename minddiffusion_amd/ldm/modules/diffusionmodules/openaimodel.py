@@ -229,21 +229,13 @@ class UNetModel:
         return t.to(device=self.device, dtype=dtype).contiguous()
 
     def _pack_conv(self, wt, cin_pad=None, cout_pad=None):
-        """[Cout,Cin,kh,kw] -> fp16 [Cout_pad][K] in the K order mdx_gemm_f16 expects (include/mdx.h):
-        [cin/64][kh*kw][64] when Cin % 64 == 0, else tap-major [kh*kw][Cin_pad]."""
+        """[Cout,Cin,kh,kw] -> the packed GEMM weight storage (ops.pack_conv_weight, include/mdx.h)."""
         wt = wt if isinstance(wt, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(wt))
-        wt = wt.to(self.device, f32)
-        co, ci, kh, kw = wt.shape
-        cip = cin_pad or ci
-        cop = cout_pad or co
-        if cip % 64 == 0:
-            assert cip == ci
-            p = torch.zeros((cop, ci // 64, kh * kw, 64), dtype=f32, device=self.device)
-            p[:co] = wt.reshape(co, ci // 64, 64, kh * kw).permute(0, 1, 3, 2)
-            return p.reshape(cop, kh * kw * ci).to(f16).contiguous()
-        p = torch.zeros((cop, kh * kw, cip), dtype=f32, device=self.device)
-        p[:co, :, :ci] = wt.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
-        return p.reshape(cop, kh * kw * cip).to(f16).contiguous()
+        return ops.pack_conv_weight(wt.to(self.device), cin_pad, cout_pad)
+
+    def _pack_dense(self, wt):
+        """nn.Dense weight [out,in] -> packed GEMM weight storage."""
+        return ops.pack_gemm_weight(self._dev(wt, f16))
 
     def _pad_vec(self, v, n):
         v = self._dev(v, f32)
@@ -299,18 +291,18 @@ class UNetModel:
                 w[pre + "norm.b"] = self._dev(P[pre + "norm.beta"], f32)
                 for n in ("proj_in", "proj_out"):
                     wt = self._dev(P[pre + n + ".weight"], f16)
-                    w[pre + n + ".w"] = wt.reshape(wt.shape[0], wt.shape[1]).contiguous()  # 1x1 conv == Dense in NHWC
+                    w[pre + n + ".w"] = self._pack_dense(wt.reshape(wt.shape[0], wt.shape[1]))  # 1x1 conv == Dense in NHWC
                     w[pre + n + ".b"] = self._dev(P[pre + n + ".bias"], f32)
                 t = pre + "transformer_blocks.0."
                 # self-attention: fused [q | k] projection, separate (transposed-store) v projection
-                w[t + "attn1.qk.w"] = torch.cat([self._dev(P[t + "attn1.to_q.weight"], f16),
-                                                 self._dev(P[t + "attn1.to_k.weight"], f16)], 0).contiguous()
-                w[t + "attn1.v.w"] = self._dev(P[t + "attn1.to_v.weight"], f16)
-                w[t + "attn2.q.w"] = self._dev(P[t + "attn2.to_q.weight"], f16)
-                w[t + "attn2.k.w"] = self._dev(P[t + "attn2.to_k.weight"], f16)
-                w[t + "attn2.v.w"] = self._dev(P[t + "attn2.to_v.weight"], f16)
+                w[t + "attn1.qk.w"] = self._pack_dense(torch.cat([self._dev(P[t + "attn1.to_q.weight"], f16),
+                                                                  self._dev(P[t + "attn1.to_k.weight"], f16)], 0))
+                w[t + "attn1.v.w"] = self._pack_dense(P[t + "attn1.to_v.weight"])
+                w[t + "attn2.q.w"] = self._pack_dense(P[t + "attn2.to_q.weight"])
+                w[t + "attn2.k.w"] = self._pack_dense(P[t + "attn2.to_k.weight"])
+                w[t + "attn2.v.w"] = self._pack_dense(P[t + "attn2.to_v.weight"])
                 for a in ("attn1", "attn2"):
-                    w[t + a + ".o.w"] = self._dev(P[t + a + ".to_out.0.weight"], f16)
+                    w[t + a + ".o.w"] = self._pack_dense(P[t + a + ".to_out.0.weight"])
                     w[t + a + ".o.b"] = self._dev(P[t + a + ".to_out.0.bias"], f32)
                 # GEGLU (attention.py:41-51): interleave 64 'x' rows with their 64 'gate' rows per 128-wide tile
                 gw = self._dev(P[t + "ff.net.0.proj.weight"], f16)
@@ -318,10 +310,11 @@ class UNetModel:
                 half = 4 * inner
                 assert half % 64 == 0
                 nt = half // 64
-                w[t + "ff1.w"] = torch.stack([gw[:half].reshape(nt, 64, inner), gw[half:].reshape(nt, 64, inner)], 1) \
-                    .reshape(2 * half, inner).contiguous()
+                w[t + "ff1.w"] = self._pack_dense(
+                    torch.stack([gw[:half].reshape(nt, 64, inner), gw[half:].reshape(nt, 64, inner)], 1)
+                    .reshape(2 * half, inner))
                 w[t + "ff1.b"] = torch.stack([gb[:half].reshape(nt, 64), gb[half:].reshape(nt, 64)], 1).reshape(-1).contiguous()
-                w[t + "ff2.w"] = self._dev(P[t + "ff.net.2.weight"], f16)
+                w[t + "ff2.w"] = self._pack_dense(P[t + "ff.net.2.weight"])
                 w[t + "ff2.b"] = self._dev(P[t + "ff.net.2.bias"], f32)
                 for n in ("norm1", "norm2", "norm3"):
                     w[t + n + ".g"] = self._dev(P[t + n + ".gamma"], f32)

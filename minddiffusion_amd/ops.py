@@ -82,6 +82,44 @@ def layernorm(x, gamma, beta, eps, out=None):
     return out
 
 
+def pack_gemm_weight(w2d):
+    """[N, K] weight (K already in the kernel's K order) -> the packed fp16 storage mdx_gemm_f16 reads
+    (include/mdx.h): N, K zero-padded to multiples of 64, tile-major [N/64][K/64][64][8 chunks][8], chunks
+    pre-swizzled (position q of row r holds logical chunk q ^ ((r >> 1) & 7)).  Pure data movement, done once
+    at weight-load time."""
+    N, K = w2d.shape
+    dev = w2d.device
+    Np, Kp = (N + 63) // 64 * 64, (K + 63) // 64 * 64
+    wp = torch.zeros((Np, Kp), dtype=f16, device=dev)
+    wp[:N, :K] = w2d
+    t = wp.view(Np // 64, 64, Kp // 64, 8, 8).permute(0, 2, 1, 3, 4)          # [panel, ktile, row, chunk, 8]
+    r = torch.arange(64, device=dev)
+    src = torch.arange(8, device=dev)[None, :] ^ ((r >> 1) & 7)[:, None]       # [row, position] -> logical chunk
+    idx = src[None, None, :, :, None].expand(Np // 64, Kp // 64, 64, 8, 8)
+    return torch.gather(t, 3, idx).contiguous().view(-1)
+
+
+def conv_weight_k_order(w4d, cin_pad=None, cout_pad=None):
+    """[Cout, Cin, kh, kw] -> [Cout_pad, K] in the kernel's K order: [cin/64][kh*kw][64] when Cin % 64 == 0
+    (channel-chunk major, tap minor), else tap-major [kh*kw][Cin_pad]."""
+    w4d = w4d.to(torch.float32)
+    co, ci, kh, kw = w4d.shape
+    cip = cin_pad or ci
+    cop = cout_pad or co
+    if cip % 64 == 0:
+        assert cip == ci
+        p = torch.zeros((cop, ci // 64, kh * kw, 64), dtype=torch.float32, device=w4d.device)
+        p[:co] = w4d.reshape(co, ci // 64, 64, kh * kw).permute(0, 1, 3, 2)
+        return p.reshape(cop, kh * kw * ci)
+    p = torch.zeros((cop, kh * kw, cip), dtype=torch.float32, device=w4d.device)
+    p[:co, :, :ci] = w4d.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
+    return p.reshape(cop, kh * kw * cip)
+
+
+def pack_conv_weight(w4d, cin_pad=None, cout_pad=None):
+    return pack_gemm_weight(conv_weight_k_order(w4d, cin_pad, cout_pad))
+
+
 def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, rowbias=None, rowbias_ld=0,
                    residual=None, residual_ld=0, ksize=1, stride=1, upsample=0, epilogue=EPI_NONE,
                    out_mode=OUT_ROWMAJOR, splitk=0, workspace=None):

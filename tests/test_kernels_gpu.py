@@ -41,11 +41,14 @@ def from_nhwc(y, b, h, w):  # [B*HW, C] or [B,HW,C] -> [B,C,H,W]
     return y.transpose(0, 3, 1, 2)
 
 
-def pack_conv(w):  # [Cout,Cin,kh,kw] -> [Cout, K] in the kernel's K order (include/mdx.h)
-    co, ci, kh, kw = w.shape
-    if ci % 64 == 0:   # [cin/64][tap][64]
-        return np.ascontiguousarray(w.reshape(co, ci // 64, 64, kh * kw).transpose(0, 1, 3, 2).reshape(co, kh * kw * ci))
-    return np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(co, kh * kw * ci))
+def pack_conv(w):  # [Cout,Cin,kh,kw] numpy -> packed device weight (the only format mdx_gemm_f16 reads)
+    from minddiffusion_amd import ops as _ops
+    return _ops.pack_conv_weight(torch.from_numpy(np.ascontiguousarray(w)).to(DEV))
+
+
+def pack_dense(w):  # [N,K] numpy -> packed device weight
+    from minddiffusion_amd import ops as _ops
+    return _ops.pack_gemm_weight(dev16(w))
 
 
 # --------------------------------------------------------------------------- hardware layout pin
@@ -141,7 +144,7 @@ def test_gemm_dense(ops, M, N, K, bias, res, splitk):
         ref = ref + bv
     if res:
         ref = ref + r
-    out = ops.gemm(dev16(a), dev16(w), N, 1, M, 1, K, bias=dev32(bv) if bias else None,
+    out = ops.gemm(dev16(a), pack_dense(w), N, 1, M, 1, K, bias=dev32(bv) if bias else None,
                    residual=dev16(r) if res else None, residual_ld=N if res else 0, splitk=splitk)
     check(f"gemm_dense_M{M}_N{N}_K{K}_b{int(bias)}_r{int(res)}_s{splitk}", out, ref, rel_l2=1e-3)
 
@@ -154,7 +157,7 @@ def test_gemm_two_source_1x1(ops):
     w = h16(rng.standard_normal((N, C1 + C2, 1, 1)) / 14)
     bv = rng.standard_normal(N).astype(np.float32)
     ref = O.conv2d(torch.tensor(x), torch.tensor(w), torch.tensor(bv), padding=0)
-    out = ops.gemm(dev16(nhwc(x[:, :C1])), dev16(pack_conv(w)), N, B, H, W, C1, a2=dev16(nhwc(x[:, C1:])), c2=C2,
+    out = ops.gemm(dev16(nhwc(x[:, :C1])), pack_conv(w), N, B, H, W, C1, a2=dev16(nhwc(x[:, C1:])), c2=C2,
                    bias=dev32(bv))
     check("gemm_two_source_1x1", from_nhwc(out.float().cpu().numpy(), B, H, W), ref, rel_l2=1e-3)
 
@@ -180,7 +183,7 @@ def test_gemm_conv3x3(ops, B, H, W, Cin, Cout, stride, up, splitk):
     if up:
         xin = O.upsample_nearest2x(xin)
     ref = O.conv2d(xin, torch.tensor(w), torch.tensor(bv), stride=stride, padding=1)
-    out = ops.gemm(dev16(nhwc(x)), dev16(pack_conv(w)), Cout, B, H, W, Cin, bias=dev32(bv), ksize=3, stride=stride,
+    out = ops.gemm(dev16(nhwc(x)), pack_conv(w), Cout, B, H, W, Cin, bias=dev32(bv), ksize=3, stride=stride,
                    upsample=up, splitk=splitk)
     Ho, Wo = ref.shape[2], ref.shape[3]
     check(f"conv3x3_B{B}_{H}x{W}_{Cin}to{Cout}_s{stride}_u{up}_k{splitk}",
@@ -199,7 +202,7 @@ def test_gemm_conv_rowbias_residual(ops):
     ref = O.conv2d(torch.tensor(x), torch.tensor(w), torch.tensor(bv)) + torch.tensor(emb[:, 72:136])[:, :, None, None] \
         + torch.tensor(res)
     embd = dev32(emb)
-    out = ops.gemm(dev16(nhwc(x)), dev16(pack_conv(w)), C, B, H, W, C, bias=dev32(bv), ksize=3,
+    out = ops.gemm(dev16(nhwc(x)), pack_conv(w), C, B, H, W, C, bias=dev32(bv), ksize=3,
                    rowbias=embd[:, 72:136], rowbias_ld=200, residual=dev16(nhwc(res)), residual_ld=C)
     check("conv3x3_rowbias_residual", from_nhwc(out.float().cpu().numpy(), B, H, W), ref, rel_l2=1e-3)
 
@@ -218,7 +221,7 @@ def test_gemm_geglu(ops, M, C, splitk):
     nt = half // 64
     wp = np.stack([w[:half].reshape(nt, 64, C), w[half:].reshape(nt, 64, C)], 1).reshape(8 * C, C)
     bp = np.stack([bv[:half].reshape(nt, 64), bv[half:].reshape(nt, 64)], 1).reshape(-1)
-    out = ops.gemm(dev16(a), dev16(wp), 8 * C, 1, M, 1, C, bias=dev32(bp), epilogue=ops.EPI_GEGLU, splitk=splitk)
+    out = ops.gemm(dev16(a), pack_dense(wp), 8 * C, 1, M, 1, C, bias=dev32(bp), epilogue=ops.EPI_GEGLU, splitk=splitk)
     assert out.shape == (M, 4 * C)
     check(f"gemm_geglu_M{M}_C{C}_s{splitk}", out, ref, rel_l2=2e-3)
 
@@ -231,7 +234,7 @@ def test_gemm_transposed_store(ops, B, T, K, N, pad, splitk):
     a = h16(rng.standard_normal((B * T, K)))
     w = h16(rng.standard_normal((N, K)) / math.sqrt(K))
     ref = (a @ w.T).reshape(B, T, N).transpose(0, 2, 1)
-    out = ops.gemm(dev16(a), dev16(w), N, B, T, 1, K, out_mode=ops.OUT_TRANSPOSED, splitk=splitk)
+    out = ops.gemm(dev16(a), pack_dense(w), N, B, T, 1, K, out_mode=ops.OUT_TRANSPOSED, splitk=splitk)
     assert out.shape == (B, N, T)
     check(f"gemm_transposed_B{B}_T{T}_K{K}_N{N}_s{splitk}", out, ref, rel_l2=1e-3)
 

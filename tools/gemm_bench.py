@@ -55,7 +55,7 @@ def main():
             a = torch.randn(B, H * W, cin, device=dev, dtype=torch.float16)
             wbytes = cout * K * 2
             ncopy = max(1, min(16, (400 << 20) // wbytes + 1))
-            ws = [torch.randn(cout, K, device=dev, dtype=torch.float16) * (K ** -0.5) for _ in range(ncopy)]
+            ws = [ops.pack_gemm_weight(torch.randn(cout, K, device=dev, dtype=torch.float16) * (K ** -0.5)) for _ in range(ncopy)]
             bias = torch.randn(cout, device=dev)
             ncols = cout // 2 if epi else cout
             out = torch.empty(M, ncols, device=dev, dtype=torch.float16)
