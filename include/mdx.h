@@ -114,7 +114,8 @@ int mdx_gemm_check(const mdx_gemm_desc* d);
  * k  : fp16, element (b, j, h*D + d) at k[b*k_bs + j*k_ld + h*D + d]
  * vt : fp16 TRANSPOSED values, element (b, h*D + d, j) at vt[b*vt_bs + (h*D+d)*vt_ld + j];
  *      columns Nk..vt_ld-1 must be finite (zero-filled by the caller)
- * o  : fp16, same addressing as q with o_bs/o_ld.   D in {64}. */
+ * o  : fp16, same addressing as q with o_bs/o_ld.   D in {40, 64, 80, 160}
+ *      (SDv2 / GLIDE: 64; Wukong-Huahua num_heads=8: 40 / 80 / 160, WK/configs/v1-inference-chinese.yaml:31). */
 int mdx_attention_f16(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld, const void* vt,
                       long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads, int D, int Nq, int Nk,
                       float scale, mdx_stream_t s);

@@ -19,3 +19,8 @@ SD2_LDM = dict(linear_start=0.00085, linear_end=0.0120, timesteps=1000, scale_fa
 TINY_UNET = dict(image_size=8, in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[2, 1],
                  num_res_blocks=1, channel_mult=[1, 2], num_head_channels=64, use_spatial_transformer=True,
                  use_linear_in_transformer=True, transformer_depth=1, context_dim=64, legacy=False)
+
+# Wukong-style small UNet for tests: 8 heads => head dims 40 / 80 (the full model adds 160), conv proj_in/out
+SMALL_WUKONG_UNET = dict(image_size=8, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[2, 1],
+                         num_res_blocks=1, channel_mult=[1, 2], num_heads=8, use_spatial_transformer=True,
+                         transformer_depth=1, context_dim=96, legacy=False)

@@ -12,6 +12,7 @@
 //                              accumulator registers (the C layout of S^T IS the B layout of PV
 //                              under the key permutation kappa(c,hi,j) = 16c + 4hi + (j&3) + 8(j>>2);
 //                              the same permutation is applied to the V^T reads) -- no cross-lane moves.
+// Head dims 40 / 64 / 80 / 160 (SDv2: 64; Wukong-Huahua: 8 heads => 40 / 80 / 160; GLIDE: 64).
 // V must be supplied TRANSPOSED ([b][h*D+d][key]); the projection GEMM writes it that way
 // (MDX_OUT_TRANSPOSED), which keeps every LDS read of this kernel wide and conflict-light.
 #include "mdx_common.h"
@@ -34,13 +35,19 @@ constexpr int BQ = 128;
 constexpr int BKV = 64;
 
 template <int D>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
-    static_assert(D == 64, "head dim 64 only in this instantiation");
-    constexpr int KS = D / 16;        // k-steps of QK^T
-    constexpr int DT = D / 32;        // 32-row d tiles of O^T
-    constexpr int ROWB = 128;         // LDS row bytes (64 f16)
-    constexpr int K_BYTES = BKV * ROWB;   // 8 KiB : [key][d]
-    constexpr int V_BYTES = D * ROWB;     // 8 KiB : [d][key]
+__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const AttnParams p) {
+    static_assert(D % 8 == 0 && D <= 160, "head dim must be a multiple of 8, <= 160");
+    constexpr int KS = (D + 15) / 16;          // k-steps of QK^T (contraction over d, zero-padded to 16)
+    constexpr int DT = (D + 31) / 32;          // 32-row d tiles of O^T
+    constexpr int KCH = (2 * KS <= 8) ? 8 : (2 * KS <= 16 ? 16 : 32);   // 16-B chunks per K row in LDS
+    constexpr int K_ROWB = KCH * 16;           // 128 | 256 | 512 bytes
+    constexpr int K_RPI = 64 / KCH;            // K rows covered by one DMA instruction (8 | 4 | 2)
+    constexpr int K_DMA = BKV / K_RPI / 4;     // K DMA instructions per wave per tile
+    constexpr int K_BYTES = BKV * K_ROWB;      // [key][d]
+    constexpr int V_ROWB = 128;                // [d][64 keys]
+    constexpr int V_ROWS = DT * 32;
+    constexpr int V_DMA = (V_ROWS / 8 + 3) / 4;   // V DMA instructions per wave per tile (8 rows each)
+    constexpr int V_BYTES = V_ROWS * V_ROWB;
     constexpr int STAGE = K_BYTES + V_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -55,14 +62,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(kb, p.k_bytes);
     const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(vb, p.vt_bytes);
 
-    // ---- Q fragments (B operand): lane (q = l31, hi) holds Q[q][16s + 8hi .. +7]
+    // ---- Q fragments (B operand): lane (q = l31, hi) holds Q[q][16s + 8hi .. +7] (zero beyond D / Nq)
     f16x8 qf[KS];
     {
         const int qi = q0 + l31;
         const f16* qp = p.q + (size_t)b * p.q_bs + (size_t)qi * p.q_ld + h * D + hi * 8;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            if (qi < p.Nq)
+            if (qi < p.Nq && s * 16 + hi * 8 < D)
                 qf[s] = *reinterpret_cast<const f16x8*>(qp + s * 16);
             else
 #pragma unroll
@@ -70,26 +77,30 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         }
     }
 
-    // ---- DMA coordinates: per stage 8 K instructions + 8 V instructions of 8 rows each; 2+2 per wave
-    const int drow = lane >> 3;  // row within the 8-row DMA group
+    // K rows: physical chunk q of row r holds logical chunk q ^ key(r); key chosen so that the 16 rows of a
+    // ds_read_b128 lane group land on 16 distinct 16-B slots of the 256-B bank row.
+    auto kkey = [](int row) { return KCH == 8 ? ((row >> 1) & 7) : (row & 15); };
     auto stage_tile = [&](int t, int buf) {
         char* sb = smem + buf * STAGE;
         const int key0 = t * BKV;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = (wave * 2 + j) * 8 + drow;           // key row within the tile
-            const unsigned chunk = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+        for (int j = 0; j < K_DMA; ++j) {
+            const int row = (wave * K_DMA + j) * K_RPI + lane / KCH;   // key row within the tile
+            const int chunk = (lane % KCH) ^ kkey(row);               // logical chunk this lane fetches
             const int key = key0 + row;
-            const unsigned off = (key < p.Nk) ? (unsigned)(((size_t)key * p.k_ld + chunk * 8) * 2) : MDX_OOB;
-            dma16(rs_k, sb + (wave * 2 + j) * 1024, off);
+            const unsigned off = (key < p.Nk && chunk * 8 < D) ? (unsigned)(((size_t)key * p.k_ld + chunk * 8) * 2) : MDX_OOB;
+            dma16(rs_k, sb + (wave * K_DMA + j) * 1024, off);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = (wave * 2 + j) * 8 + drow;           // d row
-            const unsigned chunk = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
-            const int kc = key0 + (int)chunk * 8;                  // first key of this 16-B chunk
-            const unsigned off = (kc < p.vt_ld) ? (unsigned)(((size_t)row * p.vt_ld + kc) * 2) : MDX_OOB;
-            dma16(rs_v, sb + K_BYTES + (wave * 2 + j) * 1024, off);
+        for (int j = 0; j < V_DMA; ++j) {
+            const int inst = wave * V_DMA + j;
+            if (inst * 8 < V_ROWS) {
+                const int row = inst * 8 + (lane >> 3);               // d row
+                const unsigned chunk = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+                const int kc = key0 + (int)chunk * 8;                  // first key of this 16-B chunk
+                const unsigned off = (row < D && kc < p.vt_ld) ? (unsigned)(((size_t)row * p.vt_ld + kc) * 2) : MDX_OOB;
+                dma16(rs_v, sb + K_BYTES + inst * 1024, off);
+            }
         }
     };
 
@@ -101,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     float m_run = -INFINITY;  // running max of raw scores (same value in lanes l and l^32)
     float l_run = 0.f;        // lane-partial running sum
 
-    const int swz = (lane >> 1) & 7;
+    const int vswz = (lane >> 1) & 7;
     const int ntiles = (p.Nk + BKV - 1) / BKV;
     stage_tile(0, 0);
     __syncthreads();
@@ -117,9 +128,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_s[kt][r] = 0.f;
+            const int krow = kt * 32 + l31;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + (kt * 32 + l31) * ROWB + (((2 * s + hi) ^ swz) << 4));
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + krow * K_ROWB + (((2 * s + hi) ^ kkey(krow)) << 4));
                 acc_s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], acc_s[kt], 0, 0, 0);
             }
         }
@@ -166,9 +178,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                const char* vr = sv + (d * 32 + l31) * ROWB + 8 * hi;
-                const f16x4 lo = *reinterpret_cast<const f16x4*>(vr + (((2 * c) ^ swz) << 4));
-                const f16x4 hi4 = *reinterpret_cast<const f16x4*>(vr + (((2 * c + 1) ^ swz) << 4));
+                const char* vr = sv + (d * 32 + l31) * V_ROWB + 8 * hi;
+                const f16x4 lo = *reinterpret_cast<const f16x4*>(vr + (((2 * c) ^ vswz) << 4));
+                const f16x4 hi4 = *reinterpret_cast<const f16x4*>(vr + (((2 * c + 1) ^ vswz) << 4));
                 f16x8 vf;
                 vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                 vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
@@ -179,10 +191,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         buf ^= 1;
     }
 
-    // ---- finalize: O /= l ; stage [q][d] per wave in LDS, then 128-B row stores
+    // ---- finalize: O /= l ; stage [q][d] per wave in LDS, then full-row stores
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    constexpr int OLD = D + 8;
+    constexpr int OLD = DT * 32 + 8;
     f16* og = reinterpret_cast<f16*>(smem) + wave * 32 * OLD;
 #pragma unroll
     for (int d = 0; d < DT; ++d)
@@ -194,10 +206,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
             *reinterpret_cast<f16x4*>(&og[l31 * OLD + d * 32 + 8 * g + 4 * hi]) = v;
         }
     __syncthreads();
-#pragma unroll
-    for (int pass = 0; pass < (32 * D / 8) / 64; ++pass) {
-        const int row = pass * (64 / (D / 8)) + lane / (D / 8);
-        const int chunk = lane % (D / 8);
+    constexpr int CPR = D / 8;   // 16-B chunks per output row
+    for (int idx = lane; idx < 32 * CPR; idx += 64) {
+        const int row = idx / CPR, chunk = idx - row * CPR;
         const int qi = q0 + row;
         if (qi < p.Nq) {
             const f16x8 v = *reinterpret_cast<const f16x8*>(&og[row * OLD + chunk * 8]);
@@ -206,13 +217,29 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     }
 }
 
+template <int D>
+void launch_attn(const AttnParams& p, dim3 grid, hipStream_t st) {
+    constexpr int KS = (D + 15) / 16, DT = (D + 31) / 32;
+    constexpr int KCH = (2 * KS <= 8) ? 8 : (2 * KS <= 16 ? 16 : 32);
+    constexpr size_t stage = (size_t)BKV * KCH * 16 + (size_t)DT * 32 * 128;
+    constexpr size_t ostage = (size_t)4 * 32 * (DT * 32 + 8) * 2;
+    constexpr size_t lds = (2 * stage > ostage ? 2 * stage : ostage);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_kernel<D>, grid, dim3(256), lds, st, p);
+}
+
 }  // namespace
 
 extern "C" int mdx_attention_f16(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld,
                                  const void* vt, long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads,
                                  int D, int Nq, int Nk, float scale, mdx_stream_t s) {
     MDX_REQUIRE(q && k && vt && o, "mdx_attention_f16: null pointer");
-    MDX_REQUIRE(D == 64, "mdx_attention_f16: head dim %d not supported (64 only)", D);
+    MDX_REQUIRE(D == 40 || D == 64 || D == 80 || D == 160, "mdx_attention_f16: head dim %d not supported (40/64/80/160)", D);
     MDX_REQUIRE(B > 0 && heads > 0 && Nq > 0 && Nk > 0, "mdx_attention_f16: bad extents");
     MDX_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vt_ld % 8 == 0 && o_ld % 8 == 0, "mdx_attention_f16: strides must be multiples of 8");
     MDX_REQUIRE(vt_ld >= Nk, "mdx_attention_f16: vt_ld < Nk");
@@ -231,8 +258,13 @@ extern "C" int mdx_attention_f16(const void* q, long q_bs, int q_ld, const void*
     p.k_bytes = (unsigned)kbytes;
     p.vt_bytes = (unsigned)vbytes;
     dim3 grid((Nq + BQ - 1) / BQ, heads, B);
-    const size_t lds = 2 * (size_t)(BKV * 128 + D * 128);
-    hipLaunchKernelGGL(attn_kernel<64>, grid, dim3(256), lds, (hipStream_t)s, p);
+    hipStream_t st = (hipStream_t)s;
+    switch (D) {
+        case 40: launch_attn<40>(p, grid, st); break;
+        case 64: launch_attn<64>(p, grid, st); break;
+        case 80: launch_attn<80>(p, grid, st); break;
+        default: launch_attn<160>(p, grid, st); break;
+    }
     MDX_LAUNCH_CHECK("mdx_attention_f16");
     return MDX_OK;
 }

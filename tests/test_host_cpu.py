@@ -57,7 +57,7 @@ def test_argument_validation_without_gpu():
     d.c1, d.B, d.H, d.W, d.N, d.ksize, d.stride, d.out_ld = 12, 1, 4, 4, 64, 3, 1, 64
     assert lib.mdx_gemm_f16(ctypes.byref(d), None) == -1
     assert b"multiples of 8" in lib.mdx_last_error()
-    assert lib.mdx_attention_f16(16, 0, 64, 16, 0, 64, 16, 0, 64, 16, 0, 64, 1, 1, 40, 8, 8, 1.0, None) == -1
+    assert lib.mdx_attention_f16(16, 0, 64, 16, 0, 64, 16, 0, 64, 16, 0, 64, 1, 1, 48, 8, 8, 1.0, None) == -1
     assert b"head dim" in lib.mdx_last_error()
     assert lib.mdx_groupnorm_ws_floats(2, 4096, 320, 32) == 2 * 64 * 32 * 2
 

@@ -249,23 +249,28 @@ def _attn_ref(q, k, v, heads):
     return o.permute(0, 2, 1, 3).reshape(b, n, c)
 
 
-@pytest.mark.parametrize("B,heads,Nq,Nk,spike", [
-    (1, 1, 64, 64, False),
-    (2, 2, 256, 256, False),
-    (1, 5, 1024, 1024, False),
-    (2, 2, 100, 77, False),      # cross-attention: 77 text tokens, ragged queries
-    (1, 1, 128, 200, False),     # key tail inside a 64-key tile
-    (1, 2, 256, 320, True),      # a late outlier key forces the online-softmax rescale branch (guide rule 26)
+@pytest.mark.parametrize("B,heads,Nq,Nk,spike,D", [
+    (1, 1, 64, 64, False, 64),
+    (2, 2, 256, 256, False, 64),
+    (1, 5, 1024, 1024, False, 64),
+    (2, 2, 100, 77, False, 64),      # cross-attention: 77 text tokens, ragged queries
+    (1, 1, 128, 200, False, 64),     # key tail inside a 64-key tile
+    (1, 2, 256, 320, True, 64),      # a late outlier key forces the online-softmax rescale branch (guide rule 26)
+    (2, 8, 256, 256, False, 40),     # Wukong-Huahua: num_heads=8 => d = 320/8
+    (1, 8, 100, 77, False, 40),
+    (2, 8, 256, 256, True, 80),      # d = 640/8
+    (1, 8, 128, 77, False, 80),
+    (1, 8, 256, 256, True, 160),     # d = 1280/8
+    (2, 8, 64, 77, False, 160),
 ])
-def test_attention(ops, B, heads, Nq, Nk, spike):
-    D = 64
+def test_attention(ops, B, heads, Nq, Nk, spike, D):
     C = heads * D
-    rng = np.random.RandomState(Nq + Nk + heads)
+    rng = np.random.RandomState(Nq + Nk + heads + D)
     q = h16(rng.standard_normal((B, Nq, C)))
     k = h16(rng.standard_normal((B, Nk, C)))
     v = h16(rng.standard_normal((B, Nk, C)))
     if spike:
-        k[:, 290] = h16(q[:, 3] * 3.0)   # key 290 (5th tile) dominates query row 3
+        k[:, Nk - 30] = h16(q[:, 3] * 3.0)   # a key in the last tile dominates query row 3
         k[:, 10] = h16(-q[:, 7] * 2.0)
     ref = _attn_ref(q, k, v, heads)
     ld = (Nk + 7) // 8 * 8
@@ -276,7 +281,7 @@ def test_attention(ops, B, heads, Nq, Nk, spike):
     ops.attention(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), out.data_ptr(), B, heads, D, Nq, Nk, D ** -0.5,
                   Nq * C, C, Nk * C, C, C * ld, ld, Nq * C, C)
     # P is rounded to fp16 before PV and O is stored fp16: 2e-3 relative
-    check(f"attention_B{B}_h{heads}_q{Nq}_k{Nk}_spike{int(spike)}", out, ref, rel_l2=2e-3, max_abs=2e-2)
+    check(f"attention_B{B}_h{heads}_q{Nq}_k{Nk}_d{D}_spike{int(spike)}", out, ref, rel_l2=2e-3, max_abs=2e-2)
 
 
 def test_attention_fused_qk_layout(ops):
