@@ -43,7 +43,6 @@ struct GemmParams {
     int bk;
 };
 
-constexpr int BM = 128;
 
 __device__ __forceinline__ f16x4 cvt4(float a, float b, float c, float d) {
     f16x4 v;
@@ -74,8 +73,9 @@ __device__ __forceinline__ void epilogue_store_row8(const GemmParams& p, float (
     *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + n) = o;
 }
 
-template <int BN, int BK, int NS, bool SWAP, bool FASTK>
+template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+    constexpr int TM = BM / 64;             // 32-row MFMA tiles per wave along m (waves are 2 x 2)
     constexpr int TN = BN / 64;             // 32-wide MFMA tiles per wave along n
     constexpr int ROWB = BK * 2;            // bytes per LDS row (128 | 64)
     constexpr int CPRW = BK / 8;            // 16-B chunks per row (8 | 4)
@@ -231,9 +231,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             dma16(rs_w, sbase + A_BYTES + (wave * BJ + j) * 1024, b_off[j] + (unsigned)kt * 8192);
     };
 
-    f32x16 acc[2][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 
     // fragment read offsets: row*ROWB + ((2s+hi) ^ key(row))*16; key(row) depends only on the lane for all our row bases
     const int swz = (l31 / RP256) % CPRW;
-    const int a_row_off = (wm * 64 + l31) * ROWB;
+    const int a_row_off = (wm * (BM / 2) + l31) * ROWB;
     const int b_row_off = A_BYTES + (wn * (BN / 2) + l31) * ROWB;
 
     // ---- main loop: NS-stage LDS ring.  DMAs of the next NS-1 K tiles stay in flight ACROSS the per-tile barrier
@@ -270,9 +270,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         __builtin_amdgcn_s_barrier();
         if (t + NS - 1 < nt) stage_tile(kt_begin + t + NS - 1, wr);
         const char* sb = smem + rd * STAGE;
-        f16x8 af[2][2], bf[2][TN];
+        f16x8 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + ((hi ^ swz) << 4));
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + ((hi ^ swz) << 4));
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + ((hi ^ swz) << 4));
 #pragma unroll
@@ -281,12 +281,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             if (s < KS - 1) {
                 const int coff = (((2 * (s + 1) + hi) ^ swz) << 4);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[nxt][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + coff);
+                for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + coff);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + coff);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if constexpr (SWAP)
@@ -306,13 +306,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             // split-K partial: C layout (col = lane&31 -> n, rows -> m), 128-B row segments per store
             float* wsz = p.ws + (size_t)split * p.M * p.N;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n = n0 + wn * (BN / 2) + j * 32 + l31;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                         if (m < p.M && n < p.N) wsz[(size_t)m * p.N + n] = acc[i][j][r];
                     }
                 }
@@ -322,23 +322,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         constexpr int TLD = BM + 8;
         f16* stg = reinterpret_cast<f16*>(smem);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n_l = wn * (BN / 2) + j * 32 + l31;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int m_l = wm * 64 + i * 32 + 8 * g + 4 * hi;
+                    const int m_l = wm * (BM / 2) + i * 32 + 8 * g + 4 * hi;
                     *reinterpret_cast<f16x4*>(&stg[n_l * TLD + m_l]) =
                         cvt4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
                 }
             }
         __syncthreads();
-        const int chunk = tid & 15, r0 = tid >> 4;
+        constexpr int CPT = BM / 8;        // 16-B chunks per staged n-row
+        constexpr int RPT = 256 / CPT;     // n-rows per pass
+        const int chunk = tid % CPT, r0 = tid / CPT;
         const int m = m0 + chunk * 8;
 #pragma unroll
-        for (int pass = 0; pass < BN / 16; ++pass) {
-            const int nrow = r0 + pass * 16;
+        for (int pass = 0; pass < BN / RPT; ++pass) {
+            const int nrow = r0 + pass * RPT;
             const int n = n0 + nrow;
             if (n < p.N && m < p.M) {
                 f16x8 v = *reinterpret_cast<const f16x8*>(&stg[nrow * TLD + chunk * 8]);
@@ -357,10 +359,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         constexpr int SLD = BN + 8;
         f16* stg = reinterpret_cast<f16*>(smem);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int m_l = wm * 64 + i * 32 + l31;
+                const int m_l = wm * (BM / 2) + i * 32 + l31;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n_l = wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                     bg[e] = (p.bias && pn < p.N) ? p.bias[pn + 64 + e] : 0.f;
                 }
 #pragma unroll
-                for (int pass = 0; pass < 4; ++pass) {
+                for (int pass = 0; pass < BM / 32; ++pass) {
                     const int row = r0 + pass * 32;
                     const int m = m0 + row;
                     if (m < p.M && pn < p.N) {
@@ -539,15 +541,18 @@ int pick_bn(const GemmParams& p) {
 }
 
 struct GemmCfg {
-    int bn, bk, ns;
+    int bm, bn, bk, ns;
 };
 
 // Tile configuration.  Experiments: MDX_GEMM_CFG="bk,ns" overrides (bk in {32,64}, ns in {2,3,4}).
 GemmCfg pick_cfg(const GemmParams& p) {
     GemmCfg c;
+    c.bm = 128;
     c.bn = pick_bn(p);
     c.bk = 64;
     c.ns = 2;   // ring depth is finalised in mdx_gemm_f16 once the grid size is known
+    static const char* envbm = getenv("MDX_GEMM_BM");
+    if (envbm && atoi(envbm) == 64) c.bm = 64;
     static const char* env = getenv("MDX_GEMM_CFG");
     if (env) {
         int bk = 0, ns = 0;
@@ -562,8 +567,8 @@ GemmCfg pick_cfg(const GemmParams& p) {
 // Split-K heuristic, from the measured sweep (profiles/r01_gemm_splitk_sweep.txt): one 128-row tile pulls only
 // ~50 GB/s through the DMA path, so small grids are spread over ~1.4 blocks per CU by splitting K; above ~176 tiles
 // the fp32 slab round trip costs more than it buys.
-int auto_split(const GemmParams& p, int bn) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + bn - 1) / bn);
+int auto_split(const GemmParams& p, int bm, int bn) {
+    const int tiles = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
     int ns = (352 + tiles / 2) / tiles;
     const int maxk = (p.K / 64) / 4;    // keep >= 256 k per split
     if (ns > maxk) ns = maxk;
@@ -571,41 +576,41 @@ int auto_split(const GemmParams& p, int bn) {
     return ns < 1 ? 1 : ns;
 }
 
-template <int BN, int BK, int NS, bool SWAP, bool FASTK>
+template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK>
 void launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t ring = (size_t)NS * (BM + BN) * BK * 2;
     constexpr size_t epi = (size_t)(BM > BN ? BM : BN) * ((BM > BN ? BN : BM) + 8) * 2 + 4096;  // staged C tile
     constexpr size_t lds = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BN, BK, NS, SWAP, FASTK>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, BK, NS, SWAP, FASTK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BN, BK, NS, SWAP, FASTK>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, NS, SWAP, FASTK>), grid, dim3(256), lds, st, p);
 }
 
-template <int BN, int BK, int NS>
+template <int BM, int BN, int BK, int NS>
 void launch_cfg(const GemmParams& p, bool swap, bool fastk, dim3 grid, hipStream_t st) {
     if (swap) {
         if (fastk)
-            launch_one<BN, BK, NS, true, true>(p, grid, st);
+            launch_one<BM, BN, BK, NS, true, true>(p, grid, st);
         else
-            launch_one<BN, BK, NS, true, false>(p, grid, st);
+            launch_one<BM, BN, BK, NS, true, false>(p, grid, st);
     } else {
         if (fastk)
-            launch_one<BN, BK, NS, false, true>(p, grid, st);
+            launch_one<BM, BN, BK, NS, false, true>(p, grid, st);
         else
-            launch_one<BN, BK, NS, false, false>(p, grid, st);
+            launch_one<BM, BN, BK, NS, false, false>(p, grid, st);
     }
 }
 
-template <int BN>
+template <int BM, int BN>
 bool launch_bn(const GemmCfg& c, const GemmParams& p, bool swap, bool fastk, dim3 grid, hipStream_t st) {
-    if (c.bk == 64 && c.ns == 2) launch_cfg<BN, 64, 2>(p, swap, fastk, grid, st);
-    else if (c.bk == 64 && c.ns == 3) launch_cfg<BN, 64, 3>(p, swap, fastk, grid, st);
-    else if (c.bk == 64 && c.ns == 4) launch_cfg<BN, 64, 4>(p, swap, fastk, grid, st);
-    else if (c.bk == 64 && c.ns == 5) launch_cfg<BN, 64, 5>(p, swap, fastk, grid, st);
+    if (c.bk == 64 && c.ns == 2) launch_cfg<BM, BN, 64, 2>(p, swap, fastk, grid, st);
+    else if (c.bk == 64 && c.ns == 3) launch_cfg<BM, BN, 64, 3>(p, swap, fastk, grid, st);
+    else if (BM == 128 && c.bk == 64 && c.ns == 4) launch_cfg<128, BN, 64, 4>(p, swap, fastk, grid, st);
+    else if (BM == 128 && c.bk == 64 && c.ns == 5) launch_cfg<128, BN, 64, 5>(p, swap, fastk, grid, st);
     else return false;
     return true;
 }
@@ -616,7 +621,7 @@ extern "C" size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d) {
     GemmParams p{};
     if (fill_params(d, p) != MDX_OK) return 0;
     const GemmCfg c = pick_cfg(p);
-    const int ns = d->splitk > 0 ? d->splitk : auto_split(p, c.bn);
+    const int ns = d->splitk > 0 ? d->splitk : auto_split(p, c.bm, c.bn);
     return ns > 1 ? (size_t)ns * p.M * p.N * sizeof(float) : 0;
 }
 
@@ -638,7 +643,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     const int bn = c.bn;
     p.bk = c.bk;
     p.ktiles = (p.K + c.bk - 1) / c.bk;
-    int ns = d->splitk > 0 ? d->splitk : auto_split(p, bn);
+    int ns = d->splitk > 0 ? d->splitk : auto_split(p, c.bm, bn);
     if (ns > p.ktiles) ns = p.ktiles;
     if (ns > 1) {
         // shrink to what the caller's workspace can hold
@@ -656,7 +661,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     p.ktiles_per_split = (p.ktiles + ns - 1) / ns;
     p.nsplit = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;  // no empty splits
     ns = p.nsplit;
-    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_m = (p.M + c.bm - 1) / c.bm;
     p.tiles_n = (p.N + bn - 1) / bn;
     const bool fastk = (p.cin % 64 == 0) && (p.c2 == 0 || p.c1 % 64 == 0);
     MDX_REQUIRE(fastk || p.c2 == 0, "mdx_gemm_f16: two-source input needs c1 %% 64 == 0 and Cin %% 64 == 0");
@@ -672,7 +677,11 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         cc.ns = (ntiles * ns <= 256) ? 3 : 2;
     }
     const bool swap = (ns == 1) && (p.out_mode == MDX_OUT_ROWMAJOR);
-    const bool ok = (bn == 128) ? launch_bn<128>(cc, p, swap, fastk, grid, st) : launch_bn<64>(cc, p, swap, fastk, grid, st);
+    bool ok;
+    if (cc.bm == 64)
+        ok = (bn == 128) ? launch_bn<64, 128>(cc, p, swap, fastk, grid, st) : launch_bn<64, 64>(cc, p, swap, fastk, grid, st);
+    else
+        ok = (bn == 128) ? launch_bn<128, 128>(cc, p, swap, fastk, grid, st) : launch_bn<128, 64>(cc, p, swap, fastk, grid, st);
     MDX_REQUIRE(ok, "mdx_gemm_f16: unsupported tile configuration bk=%d ns=%d", c.bk, c.ns);
     MDX_LAUNCH_CHECK("mdx_gemm_f16");
     if (ns > 1) {
