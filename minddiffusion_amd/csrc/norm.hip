@@ -72,18 +72,40 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnParams p) {
         }
     }
     __syncthreads();
+    // fold the trows partial rows per channel (all threads), then each group's cpg channels with 8 lanes per group
+    // and a fixed-order shuffle tree: deterministic, and no thread walks more than cpg/8 + trows values serially.
+    float* csum = red + (size_t)256 * 8 * 2;   // [chs][2]
+    for (int c = tid; c < chs; c += 256) {
+        float s = 0.f, q = 0.f;
+        for (int r = 0; r < trows; ++r) {
+            s += red[((size_t)r * chs + c) * 2];
+            q += red[((size_t)r * chs + c) * 2 + 1];
+        }
+        csum[c * 2] = s;
+        csum[c * 2 + 1] = q;
+    }
+    __syncthreads();
     const int ng = chs / p.cpg;          // whole groups in this column block
     const int g0 = col0 * 8 / p.cpg;
-    if (tid < ng) {
+    {
+        const int g = tid >> 3, j = tid & 7;
         float s = 0.f, q = 0.f;
-        for (int r = 0; r < trows; ++r)
-            for (int c = tid * p.cpg; c < (tid + 1) * p.cpg; ++c) {
-                s += red[((size_t)r * chs + c) * 2];
-                q += red[((size_t)r * chs + c) * 2 + 1];
+        if (g < ng) {
+            for (int c = g * p.cpg + j; c < (g + 1) * p.cpg; c += 8) {
+                s += csum[c * 2];
+                q += csum[c * 2 + 1];
             }
-        float* o = p.ws + (((size_t)b * p.nblk + blockIdx.x) * p.groups + g0 + tid) * 2;
-        o[0] = s;
-        o[1] = q;
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s += __shfl_xor(s, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        if (g < ng && j == 0) {
+            float* o = p.ws + (((size_t)b * p.nblk + blockIdx.x) * p.groups + g0 + g) * 2;
+            o[0] = s;
+            o[1] = q;
+        }
     }
 }
 
@@ -270,10 +292,10 @@ extern "C" int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2,
     MDX_REQUIRE((p.cw * 8) % p.cpg == 0 || p.ncb == 1, "mdx_groupnorm_f16: internal geometry error");
     hipStream_t st = (hipStream_t)s;
     dim3 grid(p.nblk, p.ncb, B);
-    MDX_REQUIRE(p.cw <= 256, "mdx_groupnorm_f16: %d channels per group is not supported", p.cpg);
+    MDX_REQUIRE(p.cw <= 64, "mdx_groupnorm_f16: %d channels per group is not supported", p.cpg);
     const int cols = p.cw;
     // stats LDS: [trows][cols*8][2] floats with trows*cols <= 256 for every (possibly narrower, last) column block
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), (size_t)256 * 8 * 2 * sizeof(float), st, p);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), ((size_t)256 * 8 * 2 + 512 * 2) * sizeof(float), st, p);
     MDX_LAUNCH_CHECK("mdx_groupnorm_f16(stats)");
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), ((size_t)cols * 8 * 2 + 64) * sizeof(float), st, p);
     MDX_LAUNCH_CHECK("mdx_groupnorm_f16(apply)");
