@@ -62,6 +62,12 @@ size_t mdx_groupnorm_ws_floats(int B, int HW, int C, int groups);
 int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
                       void* y, int B, int HW, int groups, float eps, int silu, float* ws, mdx_stream_t s);
 
+/* Same with the FiLM modulation of GLIDE's ResBlock (Taichu-GLIDE/.../unet.py:203-208):
+ *   y = silu?( GN(x) * (1 + scale[b][c]) + shift[b][c] ),  scale/shift fp32 rows of stride mod_ld. */
+int mdx_groupnorm_scaleshift_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,
+                                 const float* beta, const float* scale, const float* shift, int mod_ld, void* y,
+                                 int B, int HW, int groups, float eps, int silu, float* ws, mdx_stream_t s);
+
 /* ---- nn.LayerNorm([C], eps) (attention.py:176-178): rows x C fp16 -> fp16, fp32 statistics. */
 int mdx_layernorm_f16(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps,
                       mdx_stream_t s);
@@ -94,11 +100,14 @@ typedef struct mdx_gemm_desc {
     int splitk;           /* 0 = auto, >=1 = number of K splits */
     void* workspace;      /* fp32 split-K slabs (may be NULL when splitk <= 1) */
     size_t workspace_bytes;
+    long out_bs;          /* row-major only: element stride between samples (0 = dense); lets a projection write
+                             into a token sub-range of a larger [B][tokens][C] buffer (GLIDE text|image keys) */
 } mdx_gemm_desc;
 
 #define MDX_EPI_NONE 0
 #define MDX_EPI_GEGLU 1 /* out[m][j] = a * gelu_tanh(g); packed so that each 128-wide N tile = 64 'a' | 64 'gate' cols
                            (attention.py:41-51) */
+#define MDX_EPI_GELU 2  /* out = gelu_tanh(acc + bias)  (GLIDE text-transformer MLP, xf.py:52-59) */
 #define MDX_OUT_ROWMAJOR 0   /* out[m * out_ld + n] */
 #define MDX_OUT_TRANSPOSED 1 /* out[(b * N + n) * out_ld + tok]: V^T for mdx_attention_f16 */
 
@@ -145,6 +154,31 @@ int mdx_sampler_step_f32(const float* x, const void* eps_u, const void* eps_c, i
                          float sqrt_at, float sqrt_one_minus_at, float sqrt_a_prev, float dir_coef, float sigma,
                          const float* noise, float* e_t_out, float* x_prev, float* pred_x0, int B, int C, int H,
                          int W, mdx_stream_t s);
+
+/* ---- GLIDE (Taichu-GLIDE/model/glide_text2im) specifics --------------------------------------------------
+ * AvgPool2d(2,2) / ResizeNearestNeighbor x2 of a ResBlock's skip path (unet.py:46-49,74,180-185); NHWC fp16. */
+int mdx_avgpool2x2_f16(const void* x, void* y, int B, int H, int W, int C, mdx_stream_t s);
+int mdx_upsample_nearest2x_f16(const void* x, void* y, int B, int H, int W, int C, mdx_stream_t s);
+/* token + positional embedding with padding replacement (text2im_model.py:88-92):
+ * out[b][t][:] = mask[b][t] ? tok_emb[tokens[b][t]] + pos[t] : pad[t];  fp16 tables, int32 tokens/mask. */
+int mdx_glide_text_embed_f16(const int* tokens, const int* mask, const void* tok_emb, const void* pos,
+                             const void* pad, void* out, int B, int T, int width, int n_vocab, mdx_stream_t s);
+/* super-res UNet input (text2im_model.py:214-216 + gaussian_diffusion.py:307-313):
+ * out NHWC fp16 [B][S*S][8] = [x (3ch) | legacy-bilinear(round((low+1)*127.5)/127.5-1, s->S) (3ch) | 0 0];
+ * x [B][3][S][S] fp32, low [B][3][s][s] fp32. */
+int mdx_glide_superres_input_f16(const float* x, const float* low, void* out, int B, int S, int s_low,
+                                 mdx_stream_t s);
+/* one fused sampler update (guider.py:73-86, gaussian_diffusion.py:79-142, 229-254):
+ *   eps = out_u ? out_u[:3] + scale*(out_c[:3] - out_u[:3]) : out_c[:3];  v = out_c[3:6]
+ *   logvar = (v+1)/2*log_beta + (1-(v+1)/2)*post_logvar;  x0 = clip(sqrt_recip*x - sqrt_recipm1*eps, -1, 1)
+ *   mode 0 (ancestral): x_next = coef1*x0 + coef2*x + noise_scale*exp(logvar/2)*noise   (noise_scale = 0 at t = 0)
+ *   mode 1 (DDIM eta=0): eps' = (sqrt_recip*x - x0)/sqrt_recipm1; x_next = sqrt_ab_prev*x0 + sqrt(1-ab_prev)*eps'
+ * out_c/out_u: UNet outputs NHWC fp16 [B][HW][ld] (6 channels used); x, noise, x_next, pred_x0: NCHW fp32 [B][3][H][W].
+ * coef: HOST pointer to 8 floats {log_beta, post_logvar, sqrt_recip, sqrt_recipm1, coef1, coef2, sqrt_ab_prev,
+ * sqrt_one_minus_ab_prev}. */
+int mdx_glide_step_f32(const float* x, const void* out_c, const void* out_u, int ld, float guidance_scale,
+                       const float* coef8, int mode, float noise_scale, const float* noise, float* x_next,
+                       float* pred_x0, int B, int H, int W, mdx_stream_t s);
 
 /* ---- probes used by tests to pin hardware layout assumptions (not on the hot path) */
 int mdx_probe_mfma_32x32x16_f16(const void* a, const void* b, float* c, mdx_stream_t s);

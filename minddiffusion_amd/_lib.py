@@ -28,10 +28,11 @@ class GemmDesc(ctypes.Structure):
         ("ksize", c_int), ("stride", c_int), ("upsample", c_int),
         ("epilogue", c_int), ("out_mode", c_int), ("splitk", c_int),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("out_bs", c_long),
     ]
 
 
-EPI_NONE, EPI_GEGLU = 0, 1
+EPI_NONE, EPI_GEGLU, EPI_GELU = 0, 1, 2
 OUT_ROWMAJOR, OUT_TRANSPOSED = 0, 1
 
 # name -> (restype, argtypes); also the list the CPU test checks against include/mdx.h
@@ -43,6 +44,8 @@ SIGNATURES = {
     "mdx_groupnorm_ws_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mdx_groupnorm_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_int, c_float, c_int, c_void_p, c_void_p]),
+    "mdx_groupnorm_scaleshift_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_int, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdx_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "mdx_gemm_f16": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
     "mdx_gemm_workspace_bytes": (c_size_t, [ctypes.POINTER(GemmDesc)]),
@@ -55,6 +58,13 @@ SIGNATURES = {
     "mdx_sampler_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdx_avgpool2x2_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdx_upsample_nearest2x_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mdx_glide_text_embed_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                         c_int, c_int, c_void_p]),
+    "mdx_glide_superres_input_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mdx_glide_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_float, c_void_p,
+                                   c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mdx_probe_mfma_32x32x16_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdx_probe_dma_stream": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }

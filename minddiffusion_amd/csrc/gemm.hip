@@ -33,6 +33,7 @@ struct GemmParams {
     float* ws;
     int c1, c2, cin;
     int rowbias_ld, residual_ld, out_ld;
+    long out_bs;   // element stride between samples of a row-major output (0 = dense [M][out_ld])
     int B, H, W, Ho, Wo, HoWo, M, N, K;
     int ksize, stride, upsample, pad;
     int epilogue, out_mode;
@@ -70,7 +71,12 @@ __device__ __forceinline__ void epilogue_store_row8(const GemmParams& p, float (
     f16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (f16)f[e];
-    *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + n) = o;
+    size_t row = (size_t)m * p.out_ld;
+    if (p.out_bs) {
+        const int b = m / p.HoWo;
+        row = (size_t)b * p.out_bs + (size_t)(m - b * p.HoWo) * p.out_ld;
+    }
+    *reinterpret_cast<f16x8*>(p.out + row + n) = o;
 }
 
 template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK>
@@ -415,6 +421,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                     float f[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = (float)v[e] + bb[e];
+                    if (p.epilogue == MDX_EPI_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = gelu_tanh_f(f[e]);
+                    }
                     epilogue_store_row8(p, f, m, n);
                 }
             }
@@ -458,6 +468,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
                 const float4 s0 = s[0], s1 = s[1];
                 f[0] += s0.x; f[1] += s0.y; f[2] += s0.z; f[3] += s0.w; f[4] += s1.x; f[5] += s1.y; f[6] += s1.z; f[7] += s1.w;
             }
+            if (p.epilogue == MDX_EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = gelu_tanh_f(f[e]);
+            }
         }
         if (p.out_mode == MDX_OUT_TRANSPOSED) {
             const int b = m / p.HoWo;
@@ -493,6 +507,7 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     p.rowbias_ld = d->rowbias_ld;
     p.residual_ld = d->residual_ld;
     p.out_ld = d->out_ld;
+    p.out_bs = d->out_bs;
     p.B = d->B;
     p.H = d->H;
     p.W = d->W;
@@ -509,7 +524,7 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     p.K = d->ksize * d->ksize * p.cin;
     p.epilogue = d->epilogue;
     p.out_mode = d->out_mode;
-    MDX_REQUIRE(p.epilogue == MDX_EPI_NONE || p.epilogue == MDX_EPI_GEGLU, "mdx_gemm_f16: bad epilogue");
+    MDX_REQUIRE(p.epilogue == MDX_EPI_NONE || p.epilogue == MDX_EPI_GEGLU || p.epilogue == MDX_EPI_GELU, "mdx_gemm_f16: bad epilogue");
     MDX_REQUIRE(p.out_mode == MDX_OUT_ROWMAJOR || p.out_mode == MDX_OUT_TRANSPOSED, "mdx_gemm_f16: bad out_mode");
     if (p.epilogue == MDX_EPI_GEGLU) {
         MDX_REQUIRE(p.N % 128 == 0, "mdx_gemm_f16: GEGLU needs N %% 128 == 0");
@@ -521,7 +536,8 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     }
     if (p.rowbias) MDX_REQUIRE(p.rowbias_ld % 4 == 0, "mdx_gemm_f16: rowbias_ld must be a multiple of 4");
     if (p.residual) MDX_REQUIRE(p.residual_ld % 8 == 0, "mdx_gemm_f16: residual_ld must be a multiple of 8");
-    MDX_REQUIRE(p.out_ld % 8 == 0, "mdx_gemm_f16: out_ld must be a multiple of 8");
+    MDX_REQUIRE(p.out_ld % 8 == 0 && p.out_bs % 8 == 0 && p.out_bs >= 0, "mdx_gemm_f16: out_ld / out_bs must be multiples of 8");
+    MDX_REQUIRE(!(p.out_bs && p.out_mode == MDX_OUT_TRANSPOSED), "mdx_gemm_f16: out_bs applies to row-major output only");
     const size_t ab = (size_t)d->B * d->H * d->W * d->c1 * 2, a2b = (size_t)d->B * d->H * d->W * d->c2 * 2;
     p.kt64 = (p.K + 63) / 64;
     const size_t wb = (size_t)((p.N + 63) / 64) * p.kt64 * 8192;   // padded, tile-major storage

@@ -29,6 +29,9 @@ struct GnParams {
     int cw, ncb;             // chunk columns per block (whole groups), column blocks
     float eps;
     int silu;
+    const float* scale;   // optional FiLM modulation rows [B][mod_ld] (GLIDE ResBlock): y = GN(x)*(1+scale)+shift
+    const float* shift;
+    int mod_ld;
 };
 
 __device__ __forceinline__ f16x8 gn_load(const GnParams& p, int b, int pix, int col) {
@@ -148,9 +151,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
     __syncthreads();
     for (int c = tid; c < chs; c += 256) {
         const int g = c / p.cpg;
-        const float a = p.gamma[col0 * 8 + c] * gstat[g * 2 + 1];
+        float a = p.gamma[col0 * 8 + c] * gstat[g * 2 + 1];
+        float sh = p.beta[col0 * 8 + c] - gstat[g * 2] * a;
+        if (p.scale) {   // (x_hat*gamma + beta) * (1 + scale) + shift
+            const float m1 = 1.0f + p.scale[(size_t)b * p.mod_ld + col0 * 8 + c];
+            a *= m1;
+            sh = sh * m1 + p.shift[(size_t)b * p.mod_ld + col0 * 8 + c];
+        }
         ss[c * 2] = a;
-        ss[c * 2 + 1] = p.beta[col0 * 8 + c] - gstat[g * 2] * a;
+        ss[c * 2 + 1] = sh;
     }
     __syncthreads();
     const int p0 = blockIdx.x * p.pix;
@@ -260,16 +269,18 @@ extern "C" size_t mdx_groupnorm_ws_floats(int B, int HW, int C, int groups) {
     return (size_t)B * GN_MAX_NBLK * groups * 2;
 }
 
-extern "C" int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,
-                                 const float* beta, void* y, int B, int HW, int groups, float eps, int silu,
-                                 float* ws, mdx_stream_t s) {
+static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
+                          const float* scale, const float* shift, int mod_ld, void* y, int B, int HW, int groups,
+                          float eps, int silu, float* ws, mdx_stream_t s) {
     MDX_REQUIRE(x1 && gamma && beta && y && ws, "mdx_groupnorm_f16: null pointer");
     MDX_REQUIRE((C2 == 0) == (x2 == nullptr), "mdx_groupnorm_f16: x2/C2 mismatch");
+    MDX_REQUIRE((scale == nullptr) == (shift == nullptr), "mdx_groupnorm_scaleshift_f16: scale/shift mismatch");
     const int C = C1 + C2;
     MDX_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 % 8 == 0, "mdx_groupnorm_f16: channels must be multiples of 8");
     MDX_REQUIRE(groups > 0 && groups <= 32 && C % groups == 0, "mdx_groupnorm_f16: C=%d not divisible by groups=%d (<= 32)", C, groups);
     MDX_REQUIRE(C <= GN_MAX_C, "mdx_groupnorm_f16: C=%d exceeds %d", C, GN_MAX_C);
     MDX_REQUIRE(B > 0 && HW > 0 && B <= 65535, "mdx_groupnorm_f16: bad extents");
+    MDX_REQUIRE(!scale || mod_ld >= C, "mdx_groupnorm_scaleshift_f16: mod_ld < C");
     GnParams p{};
     p.x1 = (const f16*)x1;
     p.x2 = (const f16*)x2;
@@ -288,6 +299,9 @@ extern "C" int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2,
     p.cpg = C / groups;
     p.eps = eps;
     p.silu = silu;
+    p.scale = scale;
+    p.shift = shift;
+    p.mod_ld = mod_ld;
     gn_geometry(p);
     MDX_REQUIRE((p.cw * 8) % p.cpg == 0 || p.ncb == 1, "mdx_groupnorm_f16: internal geometry error");
     hipStream_t st = (hipStream_t)s;
@@ -300,6 +314,20 @@ extern "C" int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2,
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), ((size_t)cols * 8 * 2 + 64) * sizeof(float), st, p);
     MDX_LAUNCH_CHECK("mdx_groupnorm_f16(apply)");
     return MDX_OK;
+}
+
+extern "C" int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,
+                                 const float* beta, void* y, int B, int HW, int groups, float eps, int silu,
+                                 float* ws, mdx_stream_t s) {
+    return groupnorm_impl(x1, C1, x2, C2, gamma, beta, nullptr, nullptr, 0, y, B, HW, groups, eps, silu, ws, s);
+}
+
+extern "C" int mdx_groupnorm_scaleshift_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,
+                                            const float* beta, const float* scale, const float* shift, int mod_ld,
+                                            void* y, int B, int HW, int groups, float eps, int silu, float* ws,
+                                            mdx_stream_t s) {
+    MDX_REQUIRE(scale && shift, "mdx_groupnorm_scaleshift_f16: null modulation pointer");
+    return groupnorm_impl(x1, C1, x2, C2, gamma, beta, scale, shift, mod_ld, y, B, HW, groups, eps, silu, ws, s);
 }
 
 extern "C" int mdx_layernorm_f16(const void* x, const float* gamma, const float* beta, void* y, int rows, int C,

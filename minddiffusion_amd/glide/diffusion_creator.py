@@ -1,0 +1,147 @@
+"""init_diffusion_model / init_super_res_model -- mirrors of the reference's diffusion_creator.py:27-61, returning
+callables with the reference's call surface (main_funcs.py:40-41, 66):
+
+    sample, pred_xstart = diffusion_model(x=, timesteps=, token=, mask=, random_token=, random_mask=)
+    sample, pred_xstart = super_res_model(x=, timesteps=, token=, mask=, samples=)
+
+Each call = one UNet evaluation (a replayed hipGraph, with the text transformer inside) + ONE fused sampler kernel
+(mdx_glide_step_f32) replacing SamplingWithGuidance/Guider (guider.py:20-103), PMeanVariance
+(gaussian_diffusion.py:229-313) and PSample / DDimSample (:65-142).
+
+Batch convention: the reference runs the base model on 2P rows and discards rows P..2P
+(src/txt2img.py:120).  Here only the P kept trajectories are computed; the UNet still sees 2P rows
+([x ; x] with [prompt ; random-token] text) and the returned tensors have 2P rows with the second half a copy of the
+first, so `[:pics_generated]` slicing by the caller is unchanged.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from .gaussian_computation import alpha_calculator, get_named_beta_schedule, space_timesteps
+from .model.text2im_model import SuperResText2ImUNet, Text2ImUNet
+
+_MODEL_KEYS = ("text_ctx", "xf_width", "xf_layers", "xf_heads", "xf_final_ln", "n_vocab", "xf_padding",
+               "num_res_blocks", "attention_resolutions", "dropout", "channel_mult", "use_fp16", "num_heads",
+               "num_head_channels", "num_heads_upsample", "use_scale_shift_norm", "resblock_updown", "cache_text_emb")
+
+
+def create_model(**options):
+    """model_creator.py:20-75."""
+    kw = {k: options[k] for k in _MODEL_KEYS}
+    return Text2ImUNet(in_channels=3, model_channels=options["num_channels"], out_channels=6,
+                       device=options.get("device", "cuda:0"), **kw)
+
+
+def create_upsample_model(**options):
+    """model_creator.py:78-135."""
+    kw = {k: options[k] for k in _MODEL_KEYS}
+    return SuperResText2ImUNet(image_size=options["image_size"], in_channels=6, model_channels=options["num_channels"],
+                               out_channels=6, low_size=options.get("low_size", 64),
+                               device=options.get("device", "cuda:0"), **kw)
+
+
+def space_diffusion_from_base(use_timesteps, alphas_cumprod):
+    """diffusion_creator.py:96-106."""
+    timestep_map, new_betas, last = [], [], 1.0
+    for i, a in enumerate(alphas_cumprod):
+        if i in use_timesteps:
+            new_betas.append(1 - a / last)
+            last = a
+            timestep_map.append(i)
+    return timestep_map, np.array(new_betas)
+
+
+class _Schedule:
+    """The tables PMeanVariance.__init__ builds (gaussian_diffusion.py:196-226): betas cast to fp32 first."""
+
+    def __init__(self, noise_schedule, diffusion_steps, timestep_respacing):
+        base = get_named_beta_schedule(noise_schedule, diffusion_steps)
+        use = space_timesteps(diffusion_steps, timestep_respacing or [diffusion_steps])
+        tmap, nb = space_diffusion_from_base(use, alpha_calculator(base))
+        self.timestep_map = np.asarray(tmap, dtype=np.int64)
+        betas = np.array(nb, dtype=np.float32)
+        self.num_timesteps = int(betas.shape[0])
+        ac = np.cumprod(1.0 - betas, axis=0)
+        ac_prev = np.append(1.0, ac[:-1])
+        pv = betas * (1.0 - ac_prev) / (1.0 - ac)
+        f = lambda a: np.asarray(a, dtype=np.float32)
+        self.alphas_cumprod_prev = f(ac_prev)
+        self.log_betas = f(np.log(betas))
+        self.post_logvar = f(np.log(np.append(pv[1], pv[1:])))
+        self.sqrt_recip = f(np.sqrt(1.0 / ac))
+        self.sqrt_recipm1 = f(np.sqrt(1.0 / ac - 1))
+        self.coef1 = f(betas * np.sqrt(ac_prev) / (1.0 - ac))
+        self.coef2 = f((1.0 - ac_prev) * np.sqrt(1.0 - betas) / (1.0 - ac))
+
+    def coef8(self, i):
+        ab_prev = float(self.alphas_cumprod_prev[i])
+        return (self.log_betas[i], self.post_logvar[i], self.sqrt_recip[i], self.sqrt_recipm1[i], self.coef1[i],
+                self.coef2[i], np.sqrt(np.float32(ab_prev)), np.sqrt(np.float32(1.0) - np.float32(ab_prev)))
+
+
+class GenerativePSampleDiffusionModel:
+    """gaussian_diffusion.py:36-49: ancestral sampling step with classifier-free guidance."""
+
+    def __init__(self, model, schedule, guidance_scale, shape):
+        self.model = model
+        self.schedule = schedule
+        self.guidance_scale = float(guidance_scale)
+        self.shape = tuple(shape)
+        self.pics_generated = shape[0] // 2
+        self.num_timesteps = schedule.num_timesteps
+        self.generator = None
+
+    def __call__(self, x, timesteps, token, mask, random_token=None, random_mask=None, is_train=False, noise=None):
+        P = self.pics_generated
+        dev = self.model.device
+        i = int(torch.as_tensor(timesteps).reshape(-1)[0])
+        xs = x[:P].contiguous()
+        tok = torch.as_tensor(token)[:P].to(dev, torch.int32)
+        msk = torch.as_tensor(mask)[:P].to(dev, torch.int32)
+        rt = torch.as_tensor(random_token).to(dev, torch.int32).reshape(1, -1).expand(P, -1)   # guider.py:46-47
+        rm = torch.as_tensor(random_mask).to(dev, torch.int32).reshape(1, -1).expand(P, -1)
+        t = torch.full((2 * P,), float(self.schedule.timestep_map[i]), device=dev)
+        out = self.model.forward_nhwc(torch.cat([xs, xs], 0), t, torch.cat([tok, rt], 0), torch.cat([msk, rm], 0))
+        if noise is None and i != 0:
+            noise = torch.randn(xs.shape, device=dev, dtype=torch.float32, generator=self.generator)
+        sample, pred = torch.empty_like(xs), torch.empty_like(xs)
+        ops.glide_step(xs, out[:P], out[P:], out.shape[-1], self.guidance_scale, self.schedule.coef8(i), 0,
+                       0.0 if i == 0 else 1.0, None if i == 0 else noise[:P].contiguous(), sample, pred)
+        return torch.cat([sample, sample], 0), torch.cat([pred, pred], 0)
+
+
+class DDimSampleDiffusionModel:
+    """gaussian_diffusion.py:51-62: DDIM (eta = 0) step of the super-resolution model."""
+
+    def __init__(self, model, schedule, shape):
+        self.model = model
+        self.schedule = schedule
+        self.shape = tuple(shape)
+        self.num_timesteps = schedule.num_timesteps
+
+    def __call__(self, x, timesteps, token, mask, samples, is_train=False):
+        dev = self.model.device
+        i = int(torch.as_tensor(timesteps).reshape(-1)[0])
+        P = x.shape[0]
+        t = torch.full((P,), float(self.schedule.timestep_map[i]), device=dev)
+        out = self.model.forward_nhwc(x, t, torch.as_tensor(token)[:P], torch.as_tensor(mask)[:P],
+                                      low_res=samples[:P].to(dev, torch.float32).contiguous())
+        sample, pred = torch.empty_like(x), torch.empty_like(x)
+        ops.glide_step(x.contiguous(), out, None, out.shape[-1], 1.0, self.schedule.coef8(i), 1, 0.0, None, sample, pred)
+        return sample, pred
+
+
+def init_diffusion_model(options, guidance_scale, shape, ckpt_path=None, params=None):
+    model = create_model(**options)
+    if params is not None:
+        model.load_state_dict(params)
+    sch = _Schedule(options["noise_schedule"], options["diffusion_steps"], options["timestep_respacing"])
+    return GenerativePSampleDiffusionModel(model, sch, guidance_scale, shape)
+
+
+def init_super_res_model(options, shape, ckpt_path=None, params=None):
+    model = create_upsample_model(**options)
+    if params is not None:
+        model.load_state_dict(params)
+    sch = _Schedule(options["noise_schedule"], options["diffusion_steps"], options["timestep_respacing"])
+    return DDimSampleDiffusionModel(model, sch, shape)

@@ -1,0 +1,563 @@
+"""Text2ImUNet / SuperResText2ImUNet -- MI355X-native mirrors of the reference's
+Taichu-GLIDE/model/glide_text2im/model/text2im_model.py:25-238 (with unet.py:89-573, xf.py:36-154,
+simple_nn.py:38-169 underneath).
+
+Same constructor keywords as the reference's `create_model` / `create_upsample_model` call sites
+(model_creator.py:51-75, 110-135) and the same call: ``net(x, timesteps, tokens, mask)`` /
+``net(x, timesteps, low_res, tokens, mask)`` -> [N, 6, H, W].  Parameters load by the reference's Cell attribute
+names (`load_state_dict`).  Execution is planned once per (N, H, W) into a flat list of C-ABI kernel calls
+(NHWC fp16 activations, one hipGraph) exactly like the LDM UNet (ldm/modules/diffusionmodules/openaimodel.py):
+
+  * ResBlock (unet.py:178-218): GN+SiLU -> [nearest-2x folded into the conv gather | AvgPool kernel] -> conv3x3;
+    FiLM `GN(h)*(1+scale)+shift` + SiLU is ONE GroupNorm launch (mdx_groupnorm_scaleshift_f16); all ResBlocks'
+    emb_layers run as one small-M GEMV; conv2 fuses bias + skip add.
+  * AttentionBlock (unet.py:254-310): the legacy per-head [q|k|v] rows of `qkv` / [k|v] rows of `encoder_kv` are
+    re-ordered at load time into plain q / k / v projections; text keys and image keys are written by their GEMMs
+    straight into one [ctx+T] key buffer (row-major K, transposed V) so the flash-attention kernel sees a single
+    key range; scale ch^-1/4 on q and k == ch^-1/2 on the logits.
+  * the 16-layer text transformer runs INSIDE every step, as in the reference (the unconditional prompt is redrawn
+    each step, main_funcs.py:37); its MLP uses the tanh-GELU GEMM epilogue.
+"""
+import math
+
+import numpy as np
+import torch
+
+from ... import ops
+from ..._lib import MdxError
+from ...ldm.modules.diffusionmodules.openaimodel import _Arena, _round_up
+
+f16, f32 = torch.float16, torch.float32
+XF_LN_EPS = 1e-7   # MindSpore nn.LayerNorm default epsilon (xf.py:26-33 passes none)
+
+
+class Text2ImUNet:
+    super_res = False
+
+    def __init__(self, text_ctx, xf_width, xf_layers, xf_heads, xf_final_ln, n_vocab, in_channels=3,
+                 model_channels=192, out_channels=6, num_res_blocks=3, attention_resolutions=(2, 4, 8), dropout=0.0,
+                 channel_mult=(1, 2, 3, 4), use_fp16=True, num_heads=1, num_head_channels=64, num_heads_upsample=-1,
+                 use_scale_shift_norm=True, resblock_updown=True, cache_text_emb=False, xf_padding=True, dtype=None,
+                 image_size=None, device="cuda:0", **unused):
+        if not (use_scale_shift_norm and resblock_updown and xf_final_ln and xf_padding):
+            raise NotImplementedError("only the reference's shipped GLIDE options are supported "
+                                      "(use_scale_shift_norm, resblock_updown, xf_final_ln, xf_padding = True)")
+        if num_head_channels != 64 or xf_width // xf_heads != 64:
+            raise NotImplementedError("attention head width must be 64 (default_options.py:24,33)")
+        self.text_ctx, self.xf_width, self.xf_layers, self.xf_heads = text_ctx, xf_width, xf_layers, xf_heads
+        self.n_vocab = n_vocab
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = tuple(attention_resolutions)
+        self.channel_mult = tuple(channel_mult)
+        self.num_head_channels = num_head_channels
+        self.image_size = image_size
+        self.device = torch.device(device)
+        self.time_embed_dim = 4 * model_channels
+        self.cin_pad = _round_up(in_channels, 8)
+        self.cout_pad = _round_up(out_channels, 8)
+        self.input_blocks, self.middle_block, self.output_blocks = self._structure()
+        self.w = None
+        self._plans = {}
+        self.use_graph = True
+
+    # ------------------------------------------------------------------ structure (unet.py:398-534)
+    def _structure(self):
+        mc, cm = self.model_channels, self.channel_mult
+        ch = int(cm[0] * mc)
+        inb = [[("conv", self.in_channels, ch)]]
+        chans = [ch]
+        ds = 1
+        for level, mult in enumerate(cm):
+            for _ in range(self.num_res_blocks):
+                layers = [("res", ch, int(mult * mc), "")]
+                ch = int(mult * mc)
+                if ds in self.attention_resolutions:
+                    layers.append(("attn", ch, ch // self.num_head_channels))
+                inb.append(layers)
+                chans.append(ch)
+            if level != len(cm) - 1:
+                inb.append([("res", ch, ch, "down")])
+                chans.append(ch)
+                ds *= 2
+        mid = [("res", ch, ch, ""), ("attn", ch, ch // self.num_head_channels), ("res", ch, ch, "")]
+        outb = []
+        for level, mult in list(enumerate(cm))[::-1]:
+            for i in range(self.num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [("res", ch + ich, int(mc * mult), "")]
+                ch = int(mc * mult)
+                if ds in self.attention_resolutions:
+                    layers.append(("attn", ch, ch // self.num_head_channels))
+                if level and i == self.num_res_blocks:
+                    layers.append(("res", ch, ch, "up"))
+                    ds //= 2
+                outb.append(layers)
+        return inb, mid, outb
+
+    def _named_layers(self):
+        for i, blk in enumerate(self.input_blocks):
+            for j, layer in enumerate(blk):
+                yield f"input_blocks.{i}.{j}.", layer
+        for j, layer in enumerate(self.middle_block):
+            yield f"middle_block.{j}.", layer
+        for i, blk in enumerate(self.output_blocks):
+            for j, layer in enumerate(blk):
+                yield f"output_blocks.{i}.{j}.", layer
+
+    def parameter_shapes(self):
+        mc, ted, xw = self.model_channels, self.time_embed_dim, self.xf_width
+        s = {"time_embed.0.weight": (ted, mc), "time_embed.0.bias": (ted,),
+             "time_embed.2.weight": (ted, ted), "time_embed.2.bias": (ted,)}
+        for pre, layer in self._named_layers():
+            if layer[0] == "conv":
+                s[pre + "conv.weight"] = (layer[2], layer[1], 3, 3)
+                s[pre + "conv.bias"] = (layer[2],)
+            elif layer[0] == "res":
+                cin, cout = layer[1], layer[2]
+                s[pre + "in_layers_0.gamma"] = (cin,)
+                s[pre + "in_layers_0.beta"] = (cin,)
+                s[pre + "in_layers_2.conv.weight"] = (cout, cin, 3, 3)
+                s[pre + "in_layers_2.conv.bias"] = (cout,)
+                s[pre + "emb_layers.1.weight"] = (2 * cout, ted)
+                s[pre + "emb_layers.1.bias"] = (2 * cout,)
+                s[pre + "out_layers_0.gamma"] = (cout,)
+                s[pre + "out_layers_0.beta"] = (cout,)
+                s[pre + "out_layers_3.conv.weight"] = (cout, cout, 3, 3)
+                s[pre + "out_layers_3.conv.bias"] = (cout,)
+                if cin != cout:
+                    s[pre + "skip_connection.conv.weight"] = (cout, cin, 1, 1)
+                    s[pre + "skip_connection.conv.bias"] = (cout,)
+            else:
+                c = layer[1]
+                s[pre + "norm.gamma"] = (c,)
+                s[pre + "norm.beta"] = (c,)
+                s[pre + "qkv.conv.weight"] = (3 * c, c, 1)
+                s[pre + "qkv.conv.bias"] = (3 * c,)
+                s[pre + "encoder_kv.conv.weight"] = (2 * c, xw, 1)
+                s[pre + "encoder_kv.conv.bias"] = (2 * c,)
+                s[pre + "proj_out.conv.weight"] = (c, c, 1)
+                s[pre + "proj_out.conv.bias"] = (c,)
+        ch0 = int(self.channel_mult[0] * mc)
+        s["out.0.gamma"] = (ch0,)
+        s["out.0.beta"] = (ch0,)
+        s["out2.conv.weight"] = (self.out_channels, ch0, 3, 3)
+        s["out2.conv.bias"] = (self.out_channels,)
+        for l in range(self.xf_layers):
+            t = f"transformer.resblocks.{l}."
+            s[t + "ln_1.gamma"] = (xw,); s[t + "ln_1.beta"] = (xw,)
+            s[t + "attn.c_qkv.weight"] = (3 * xw, xw); s[t + "attn.c_qkv.bias"] = (3 * xw,)
+            s[t + "attn.c_proj.weight"] = (xw, xw); s[t + "attn.c_proj.bias"] = (xw,)
+            s[t + "ln_2.gamma"] = (xw,); s[t + "ln_2.beta"] = (xw,)
+            s[t + "mlp.c_fc.weight"] = (4 * xw, xw); s[t + "mlp.c_fc.bias"] = (4 * xw,)
+            s[t + "mlp.c_proj.weight"] = (xw, 4 * xw); s[t + "mlp.c_proj.bias"] = (xw,)
+        s["final_ln.gamma"] = (xw,); s["final_ln.beta"] = (xw,)
+        s["token_embedding.embedding_table"] = (self.n_vocab, xw)
+        s["positional_embedding"] = (self.text_ctx, xw)
+        s["padding_embedding"] = (self.text_ctx, xw)
+        s["transformer_proj.weight"] = (ted, xw); s["transformer_proj.bias"] = (ted,)
+        return s
+
+    # ------------------------------------------------------------------ weights
+    def _dev(self, a, dtype):
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def _conv(self, wt, cin_pad=None, cout_pad=None):
+        return ops.pack_conv_weight(self._dev(wt, f32), cin_pad, cout_pad)
+
+    def _dense(self, wt):
+        return ops.pack_gemm_weight(self._dev(wt, f16))
+
+    def load_state_dict(self, params, strict=True):
+        shapes = self.parameter_shapes()
+        missing = [k for k in shapes if k not in params]
+        if strict and missing:
+            raise KeyError(f"missing parameters: {missing[:5]} ... ({len(missing)} total)")
+        for k, shp in shapes.items():
+            if tuple(params[k].shape) != tuple(shp):
+                raise ValueError(f"{k}: expected shape {shp}, got {tuple(params[k].shape)}")
+        P, w = params, {}
+        ted = self.time_embed_dim
+        w["te0.w"] = self._dev(P["time_embed.0.weight"], f16)
+        w["te0.b"] = self._dev(P["time_embed.0.bias"], f32)
+        # emb = time_embed.2(e1) + transformer_proj(xf_out[:, -1])  (text2im_model.py:102-105) as ONE small GEMV
+        # over the concatenated input [e1 | last token]
+        w["te2proj.w"] = torch.cat([self._dev(P["time_embed.2.weight"], f16),
+                                    self._dev(P["transformer_proj.weight"], f16)], 1).contiguous()
+        w["te2proj.b"] = (self._dev(P["time_embed.2.bias"], f32) + self._dev(P["transformer_proj.bias"], f32)).contiguous()
+        emb_w, emb_b, self._emb_off, off = [], [], {}, 0
+        for pre, layer in self._named_layers():
+            if layer[0] == "conv":
+                w[pre + "w"] = self._conv(P[pre + "conv.weight"], cin_pad=self.cin_pad)
+                w[pre + "b"] = self._dev(P[pre + "conv.bias"], f32)
+            elif layer[0] == "res":
+                cin, cout = layer[1], layer[2]
+                w[pre + "n1.g"] = self._dev(P[pre + "in_layers_0.gamma"], f32)
+                w[pre + "n1.b"] = self._dev(P[pre + "in_layers_0.beta"], f32)
+                w[pre + "n2.g"] = self._dev(P[pre + "out_layers_0.gamma"], f32)
+                w[pre + "n2.b"] = self._dev(P[pre + "out_layers_0.beta"], f32)
+                w[pre + "conv1.w"] = self._conv(P[pre + "in_layers_2.conv.weight"])
+                w[pre + "conv1.b"] = self._dev(P[pre + "in_layers_2.conv.bias"], f32)
+                w[pre + "conv2.w"] = self._conv(P[pre + "out_layers_3.conv.weight"])
+                w[pre + "conv2.b"] = self._dev(P[pre + "out_layers_3.conv.bias"], f32)
+                if cin != cout:
+                    w[pre + "skip.w"] = self._conv(P[pre + "skip_connection.conv.weight"])
+                    w[pre + "skip.b"] = self._dev(P[pre + "skip_connection.conv.bias"], f32)
+                emb_w.append(self._dev(P[pre + "emb_layers.1.weight"], f16))
+                emb_b.append(self._dev(P[pre + "emb_layers.1.bias"], f32))
+                self._emb_off[pre] = off
+                off += 2 * cout
+            else:
+                c, heads = layer[1], layer[2]
+                w[pre + "norm.g"] = self._dev(P[pre + "norm.gamma"], f32)
+                w[pre + "norm.b"] = self._dev(P[pre + "norm.beta"], f32)
+                # legacy order (unet.py:293-295): rows of head h are [q(64) | k(64) | v(64)]
+                qkv = self._dev(P[pre + "qkv.conv.weight"], f16).reshape(heads, 3, 64, c)
+                qb = self._dev(P[pre + "qkv.conv.bias"], f32).reshape(heads, 3, 64)
+                for idx, nm in enumerate("qkv"):
+                    w[pre + nm + ".w"] = self._dense(qkv[:, idx].reshape(c, c))
+                    w[pre + nm + ".b"] = qb[:, idx].reshape(c).contiguous()
+                ekv = self._dev(P[pre + "encoder_kv.conv.weight"], f16).reshape(heads, 2, 64, self.xf_width)
+                eb = self._dev(P[pre + "encoder_kv.conv.bias"], f32).reshape(heads, 2, 64)
+                for idx, nm in enumerate(("ek", "ev")):
+                    w[pre + nm + ".w"] = self._dense(ekv[:, idx].reshape(c, self.xf_width))
+                    w[pre + nm + ".b"] = eb[:, idx].reshape(c).contiguous()
+                w[pre + "proj.w"] = self._dense(self._dev(P[pre + "proj_out.conv.weight"], f16).reshape(c, c))
+                w[pre + "proj.b"] = self._dev(P[pre + "proj_out.conv.bias"], f32)
+        w["emb.w"] = torch.cat(emb_w, 0).contiguous()
+        w["emb.b"] = torch.cat(emb_b, 0).contiguous()
+        self._emb_total = off
+        w["out.g"] = self._dev(P["out.0.gamma"], f32)
+        w["out.b"] = self._dev(P["out.0.beta"], f32)
+        w["out2.w"] = self._conv(P["out2.conv.weight"], cout_pad=self.cout_pad)
+        ob = torch.zeros(self.cout_pad, dtype=f32, device=self.device)
+        ob[: self.out_channels] = self._dev(P["out2.conv.bias"], f32)
+        w["out2.b"] = ob
+        xw, xh = self.xf_width, self.xf_heads
+        for l in range(self.xf_layers):
+            t = f"transformer.resblocks.{l}."
+            for n in ("ln_1", "ln_2"):
+                w[t + n + ".g"] = self._dev(P[t + n + ".gamma"], f32)
+                w[t + n + ".b"] = self._dev(P[t + n + ".beta"], f32)
+            # xf.py:79-81: qkv.view(b, ctx, heads, 3*64) then split -> rows of head h are [q | k | v]
+            cq = self._dev(P[t + "attn.c_qkv.weight"], f16).reshape(xh, 3, 64, xw)
+            cb = self._dev(P[t + "attn.c_qkv.bias"], f32).reshape(xh, 3, 64)
+            w[t + "qk.w"] = self._dense(torch.cat([cq[:, 0].reshape(xw, xw), cq[:, 1].reshape(xw, xw)], 0))
+            w[t + "qk.b"] = torch.cat([cb[:, 0].reshape(xw), cb[:, 1].reshape(xw)], 0).contiguous()
+            w[t + "v.w"] = self._dense(cq[:, 2].reshape(xw, xw))
+            w[t + "v.b"] = cb[:, 2].reshape(xw).contiguous()
+            w[t + "proj.w"] = self._dense(P[t + "attn.c_proj.weight"])
+            w[t + "proj.b"] = self._dev(P[t + "attn.c_proj.bias"], f32)
+            w[t + "fc.w"] = self._dense(P[t + "mlp.c_fc.weight"])
+            w[t + "fc.b"] = self._dev(P[t + "mlp.c_fc.bias"], f32)
+            w[t + "fc2.w"] = self._dense(P[t + "mlp.c_proj.weight"])
+            w[t + "fc2.b"] = self._dev(P[t + "mlp.c_proj.bias"], f32)
+        w["final_ln.g"] = self._dev(P["final_ln.gamma"], f32)
+        w["final_ln.b"] = self._dev(P["final_ln.beta"], f32)
+        w["tok"] = self._dev(P["token_embedding.embedding_table"], f16)
+        w["pos"] = self._dev(P["positional_embedding"], f16)
+        w["pad"] = self._dev(P["padding_embedding"], f16)
+        self.w = w
+        self._plans = {}
+        return self
+
+    # ------------------------------------------------------------------ planning
+    class _Plan:
+        pass
+
+    def _plan(self, B, H, W):
+        key = (B, H, W)
+        if key in self._plans:
+            return self._plans[key]
+        if self.w is None:
+            raise MdxError("load_state_dict() must be called before the first forward")
+        n_down = len(self.channel_mult) - 1
+        if H % (1 << n_down) or W % (1 << n_down):
+            raise MdxError(f"image {H}x{W} is not divisible by 2^{n_down}")
+        dev, w = self.device, self.w
+        P = Text2ImUNet._Plan()
+        A = _Arena(dev)
+        main, meta, descs = [], [], []
+        gn_need = [4]
+        ctx, xw, xh = self.text_ctx, self.xf_width, self.xf_heads
+        mc, ted = self.model_channels, self.time_embed_dim
+        P.B, P.H, P.W = B, H, W
+        P.x_static = torch.zeros((B, 3, H, W), dtype=f32, device=dev)
+        P.low_static = None
+        P.t_static = torch.zeros((B,), dtype=f32, device=dev)
+        P.tok_static = torch.zeros((B, ctx), dtype=torch.int32, device=dev)
+        P.mask_static = torch.ones((B, ctx), dtype=torch.int32, device=dev)
+
+        def emit(fn, kind, flops=0, launches=1, info=""):
+            main.append(fn)
+            meta.append({"kind": kind, "flops": int(flops), "launches": launches, "info": info})
+
+        def gemm(**kw):
+            d = ops.make_gemm_desc(**kw)
+            descs.append(d)
+            ks, st, up = kw.get("ksize", 1), kw.get("stride", 1), kw.get("upsample", 0)
+            hs_, ws2 = (2 * kw["H"], 2 * kw["W"]) if up else (kw["H"], kw["W"])
+            pad = 1 if ks == 3 else 0
+            m_rows = kw["B"] * ((hs_ + 2 * pad - ks) // st + 1) * ((ws2 + 2 * pad - ks) // st + 1)
+            kdim = ks * ks * (kw["c1"] + kw.get("c2", 0))
+            wsb = ops.gemm_workspace_bytes(d)
+            emit(lambda d=d: ops.gemm_run(d), "gemm", 2 * m_rows * kw["N"] * kdim, 2 if wsb else 1,
+                 f"M={m_rows} N={kw['N']} K={kdim} k{ks}")
+
+        def gn(x1, x2, g, b, silu, out, scale=None, shift=None):
+            Bq, HW, C1 = x1.shape
+            C = C1 + (0 if x2 is None else x2.shape[2])
+            gn_need[0] = max(gn_need[0], ops.groupnorm_ws_floats(Bq, HW, C))
+            if scale is None:
+                emit(lambda: ops.groupnorm(x1, x2, g, b, 1e-5, silu, ws=P.gn_ws, out=out), "groupnorm", 0, 2)
+            else:
+                emit(lambda: ops.groupnorm_scaleshift(x1, x2, g, b, scale, shift, self._emb_total, 1e-5, silu,
+                                                      ws=P.gn_ws, out=out), "groupnorm", 0, 2)
+
+        def dense(src, rows_b, tokens, cin, nout, wt, bias=None, residual=None, epilogue=ops.EPI_NONE, out=None,
+                  out_ld=None, out_mode=ops.OUT_ROWMAJOR, out_bs=0, src2=None, c2=0):
+            if out is None:
+                out = A.get((rows_b, tokens, nout))
+                out_ld = nout
+            gemm(a=src, w=wt, N=nout, B=rows_b, H=tokens, W=1, c1=cin - c2, out=out, out_ld=out_ld, a2=src2, c2=c2,
+                 bias=bias, residual=residual, residual_ld=nout if residual is not None else 0, epilogue=epilogue,
+                 out_mode=out_mode, out_bs=out_bs)
+            return out
+
+        def conv3(src, cin, cout, wt, bias, h, wd, upsample=0, residual=None):
+            ho, wo = (2 * h, 2 * wd) if upsample else (h, wd)
+            out = A.get((B, ho * wo, cout))
+            gemm(a=src, w=wt, N=cout, B=B, H=h, W=wd, c1=cin, out=out, out_ld=cout, bias=bias, residual=residual,
+                 residual_ld=cout if residual is not None else 0, ksize=3, upsample=upsample)
+            return out, ho, wo
+
+        # ---- text transformer (text2im_model.py:88-99, xf.py:36-154): every step, on all B rows
+        x_tok = A.get((B, ctx, xw))
+        emit(lambda: ops.glide_text_embed(P.tok_static, P.mask_static, w["tok"], w["pos"], w["pad"], out=x_tok), "small")
+        ln = A.get((B, ctx, xw))
+        for l in range(self.xf_layers):
+            t = f"transformer.resblocks.{l}."
+            emit(lambda t=t, x_tok=x_tok: ops.layernorm(x_tok, w[t + "ln_1.g"], w[t + "ln_1.b"], XF_LN_EPS, out=ln), "layernorm")
+            qk = dense(ln, B, ctx, xw, 2 * xw, w[t + "qk.w"], bias=w[t + "qk.b"])
+            vt = A.get((B, xw, ctx))
+            dense(ln, B, ctx, xw, xw, w[t + "v.w"], bias=w[t + "v.b"], out=vt, out_ld=ctx, out_mode=ops.OUT_TRANSPOSED)
+            ao = A.get((B, ctx, xw))
+            emit(lambda qk=qk, vt=vt, ao=ao: ops.attention(
+                qk.data_ptr(), qk.data_ptr() + xw * 2, vt.data_ptr(), ao.data_ptr(), B, xh, 64, ctx, ctx, 64 ** -0.5,
+                ctx * 2 * xw, 2 * xw, ctx * 2 * xw, 2 * xw, xw * ctx, ctx, ctx * xw, xw),
+                "attention", 4 * B * xh * ctx * ctx * 64)
+            x2 = dense(ao, B, ctx, xw, xw, w[t + "proj.w"], bias=w[t + "proj.b"], residual=x_tok)
+            A.release(qk); A.release(vt); A.release(ao); A.release(x_tok)
+            emit(lambda t=t, x2=x2: ops.layernorm(x2, w[t + "ln_2.g"], w[t + "ln_2.b"], XF_LN_EPS, out=ln), "layernorm")
+            hfc = dense(ln, B, ctx, xw, 4 * xw, w[t + "fc.w"], bias=w[t + "fc.b"], epilogue=ops.EPI_GELU)
+            x_tok = dense(hfc, B, ctx, 4 * xw, xw, w[t + "fc2.w"], bias=w[t + "fc2.b"], residual=x2)
+            A.release(hfc); A.release(x2)
+        xf_out = A.get((B, ctx, xw))     # kept for every AttentionBlock's encoder_kv
+        emit(lambda x_tok=x_tok: ops.layernorm(x_tok, w["final_ln.g"], w["final_ln.b"], XF_LN_EPS, out=xf_out), "layernorm")
+        A.release(ln)
+
+        # ---- time embedding + xf_proj (text2im_model.py:102-105), then all emb_layers (unet.py:163-170) at once
+        t_emb = torch.empty((B, mc), dtype=f32, device=dev)
+        cat_in = torch.empty((B, ted + xw), dtype=f32, device=dev)      # [silu-free e1 | last text token]
+        emb = torch.empty((B, ted), dtype=f32, device=dev)
+        P.emb_all = torch.empty((B, self._emb_total), dtype=f32, device=dev)
+        emit(lambda: ops.timestep_embedding(P.t_static, mc, out=t_emb), "small")
+        emit(lambda: ops.dense_small(t_emb, w["te0.w"], w["te0.b"], act_out=True, out=cat_in[:, :ted]), "small")
+        emit(lambda: cat_in[:, ted:].copy_(xf_out[:, -1]), "small")     # dtype-converting copy (plumbing)
+        emit(lambda: ops.dense_small(cat_in, w["te2proj.w"], w["te2proj.b"], out=emb), "small")
+        emit(lambda: ops.dense_small(emb, w["emb.w"], w["emb.b"], act_in=True, out=P.emb_all), "small")
+
+        def resblock(pre, x, x2, cin, cout, mode, h, wd):
+            """unet.py:178-218 (scale-shift norm; up/down act on BOTH h and x)."""
+            hw = h * wd
+            a = A.get((B, hw, cin))
+            gn(x, x2, w[pre + "n1.g"], w[pre + "n1.b"], True, a)
+            if mode == "up":
+                assert x2 is None and cin == cout
+                hbuf, ho, wo = conv3(a, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd, upsample=1)
+                xs = A.get((B, ho * wo, cin))
+                emit(lambda x=x, xs=xs: ops.upsample_nearest2x(x, B, h, wd, cin, out=xs), "small")
+            elif mode == "down":
+                assert x2 is None and cin == cout
+                ap = A.get((B, hw // 4, cin))
+                emit(lambda a=a, ap=ap: ops.avgpool2x2(a, B, h, wd, cin, out=ap), "small")
+                hbuf, ho, wo = conv3(ap, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h // 2, wd // 2)
+                A.release(ap)
+                xs = A.get((B, hw // 4, cin))
+                emit(lambda x=x, xs=xs: ops.avgpool2x2(x, B, h, wd, cin, out=xs), "small")
+            else:
+                hbuf, ho, wo = conv3(a, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd)
+                xs = x
+            A.release(a)
+            eoff = self._emb_off[pre]
+            a2 = A.get((B, ho * wo, cout))
+            gn(hbuf, None, w[pre + "n2.g"], w[pre + "n2.b"], True, a2,
+               scale=P.emb_all[:, eoff:eoff + cout], shift=P.emb_all[:, eoff + cout:eoff + 2 * cout])
+            A.release(hbuf)
+            if cin != cout:
+                c2 = 0 if x2 is None else x2.shape[2]
+                skip = dense(x, B, hw, cin, cout, w[pre + "skip.w"], bias=w[pre + "skip.b"], src2=x2, c2=c2)
+            else:
+                assert x2 is None
+                skip = xs
+            out, _, _ = conv3(a2, cout, cout, w[pre + "conv2.w"], w[pre + "conv2.b"], ho, wo, residual=skip)
+            A.release(a2)
+            if skip is not x:
+                A.release(skip)
+            return out, ho, wo
+
+        def attnblock(pre, x, c, heads, h, wd):
+            """unet.py:254-310: q from the image, keys/values = [text (ctx) | image (T)]."""
+            T = h * wd
+            nk = ctx + T
+            a = A.get((B, T, c))
+            gn(x, None, w[pre + "norm.g"], w[pre + "norm.b"], False, a)
+            q = dense(a, B, T, c, c, w[pre + "q.w"], bias=w[pre + "q.b"])
+            kbuf = A.get((B, nk, c))
+            vtb = A.get((B, c, nk))
+            dense(a, B, T, c, c, w[pre + "k.w"], bias=w[pre + "k.b"], out=kbuf[:, ctx:], out_ld=c, out_bs=nk * c)
+            dense(a, B, T, c, c, w[pre + "v.w"], bias=w[pre + "v.b"], out=vtb[:, :, ctx:], out_ld=nk,
+                  out_mode=ops.OUT_TRANSPOSED)
+            dense(xf_out, B, ctx, xw, c, w[pre + "ek.w"], bias=w[pre + "ek.b"], out=kbuf, out_ld=c, out_bs=nk * c)
+            dense(xf_out, B, ctx, xw, c, w[pre + "ev.w"], bias=w[pre + "ev.b"], out=vtb, out_ld=nk,
+                  out_mode=ops.OUT_TRANSPOSED)
+            o = a   # the normed input is dead after the projections
+            emit(lambda q=q, kbuf=kbuf, vtb=vtb, o=o: ops.attention(
+                q.data_ptr(), kbuf.data_ptr(), vtb.data_ptr(), o.data_ptr(), B, heads, 64, T, nk, 64 ** -0.5,
+                T * c, c, nk * c, c, c * nk, nk, T * c, c), "attention", 4 * B * heads * T * nk * 64)
+            out = dense(o, B, T, c, c, w[pre + "proj.w"], bias=w[pre + "proj.b"], residual=x)
+            A.release(q); A.release(kbuf); A.release(vtb); A.release(a)
+            return out
+
+        # ---- UNet walk (text2im_model.py:106-123)
+        xin = A.get((B, H * W, self.cin_pad))
+        if self.super_res:
+            s_low = self.low_size
+            P.low_static = torch.zeros((B, 3, s_low, s_low), dtype=f32, device=dev)
+            emit(lambda: ops.glide_superres_input(P.x_static, P.low_static, out=xin), "small")
+        else:
+            emit(lambda: ops.nchw_to_nhwc(P.x_static, self.cin_pad, out=xin), "small")
+        h, wd = H, W
+        hs, cur = [], None
+        for i, blk in enumerate(self.input_blocks):
+            for j, layer in enumerate(blk):
+                pre = f"input_blocks.{i}.{j}."
+                if layer[0] == "conv":
+                    cur, h, wd = conv3(xin, self.cin_pad, layer[2], w[pre + "w"], w[pre + "b"], h, wd)
+                    A.release(xin)
+                elif layer[0] == "res":
+                    new, h2, w2 = resblock(pre, cur, None, layer[1], layer[2], layer[3], h, wd)
+                    if not any(cur is s_[0] for s_ in hs):
+                        A.release(cur)
+                    cur, h, wd = new, h2, w2
+                else:
+                    new = attnblock(pre, cur, layer[1], layer[2], h, wd)
+                    A.release(cur)
+                    cur = new
+            hs.append((cur, h, wd))
+        for j, layer in enumerate(self.middle_block):
+            pre = f"middle_block.{j}."
+            if layer[0] == "res":
+                new, _, _ = resblock(pre, cur, None, layer[1], layer[2], layer[3], h, wd)
+            else:
+                new = attnblock(pre, cur, layer[1], layer[2], h, wd)
+            if not any(cur is s_[0] for s_ in hs):
+                A.release(cur)
+            cur = new
+        for i, blk in enumerate(self.output_blocks):
+            skip, sh, sw = hs.pop()
+            assert (sh, sw) == (h, wd)
+            for j, layer in enumerate(blk):
+                pre = f"output_blocks.{i}.{j}."
+                if layer[0] == "res" and j == 0:
+                    new, _, _ = resblock(pre, cur, skip, layer[1], layer[2], layer[3], h, wd)
+                    A.release(cur); A.release(skip)
+                    cur = new
+                elif layer[0] == "res":
+                    new, h, wd = resblock(pre, cur, None, layer[1], layer[2], layer[3], h, wd)
+                    A.release(cur)
+                    cur = new
+                else:
+                    new = attnblock(pre, cur, layer[1], layer[2], h, wd)
+                    A.release(cur)
+                    cur = new
+        ch0 = int(self.channel_mult[0] * mc)
+        a = A.get((B, h * wd, ch0))
+        gn(cur, None, w["out.g"], w["out.b"], True, a)
+        P.out_nhwc = torch.empty((B, h * wd, self.cout_pad), dtype=f16, device=dev)
+        gemm(a=a, w=w["out2.w"], N=self.cout_pad, B=B, H=h, W=wd, c1=ch0, out=P.out_nhwc, out_ld=self.cout_pad,
+             bias=w["out2.b"], ksize=3)
+
+        need = max([ops.gemm_workspace_bytes(d) for d in descs] + [16])
+        P.gemm_ws = torch.empty(need // 4, dtype=f32, device=dev)
+        for d in descs:
+            d.workspace = P.gemm_ws.data_ptr()
+            d.workspace_bytes = P.gemm_ws.numel() * 4
+        P.gn_ws = torch.empty(gn_need[0], dtype=f32, device=dev)
+        P.main, P.meta, P.descs, P.arena = main, meta, descs, A
+        P.keep = (t_emb, cat_in, emb, xf_out)
+        P.graph, P.graph_failed = None, False
+        self._plans[key] = P
+        return P
+
+    # ------------------------------------------------------------------ execution
+    def forward_nhwc(self, x, timesteps, tokens, mask, low_res=None):
+        """Returns the plan's static NHWC fp16 output [N, H*W, 8] (6 channels valid; overwritten by the next call)."""
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            raise MdxError("x must be a CUDA(HIP) tensor (no CPU fallback)")
+        B, _, H, W = x.shape
+        P = self._plan(B, H, W)
+        P.x_static.copy_(x)
+        P.t_static.copy_(torch.as_tensor(timesteps).to(device=self.device, dtype=f32).expand(B))
+        P.tok_static.copy_(torch.as_tensor(tokens).to(self.device))
+        P.mask_static.copy_(torch.as_tensor(mask).to(self.device))
+        if self.super_res:
+            if low_res is None:
+                raise MdxError("SuperResText2ImUNet needs low_res")
+            P.low_static.copy_(low_res)
+        if self.use_graph and not P.graph_failed:
+            if P.graph is None:
+                try:
+                    for op in P.main:
+                        op()
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        for op in P.main:
+                            op()
+                    P.graph = g
+                except Exception as e:  # pragma: no cover
+                    P.graph, P.graph_failed = None, True
+                    import warnings
+                    warnings.warn(f"hipGraph capture failed, running eagerly: {e}")
+            if P.graph is not None:
+                P.graph.replay()
+                return P.out_nhwc
+        for op in P.main:
+            op()
+        return P.out_nhwc
+
+    def construct(self, x, timesteps, tokens=None, mask=None):
+        """text2im_model.py:101-123 -> [N, 6, H, W] fp32."""
+        out = self.forward_nhwc(x, timesteps, tokens, mask)
+        return ops.nhwc_to_nchw(out, self.out_channels, x.shape[2], x.shape[3])
+
+    __call__ = construct
+
+
+class SuperResText2ImUNet(Text2ImUNet):
+    """text2im_model.py:126-238: the same UNet on [x | bilinear(low_res)] (6 input channels)."""
+    super_res = True
+
+    def __init__(self, image_size, text_ctx, xf_width, xf_layers, xf_heads, xf_final_ln, n_vocab, in_channels=6,
+                 low_size=64, **kw):
+        super().__init__(text_ctx, xf_width, xf_layers, xf_heads, xf_final_ln, n_vocab, in_channels=in_channels,
+                         image_size=image_size, **kw)
+        self.low_size = low_size
+
+    def construct(self, x, timesteps, low_res=None, tokens=None, mask=None):
+        out = self.forward_nhwc(x, timesteps, tokens, mask, low_res=low_res)
+        return ops.nhwc_to_nchw(out, self.out_channels, x.shape[2], x.shape[3])
+
+    __call__ = construct

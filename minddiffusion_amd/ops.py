@@ -5,7 +5,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, EPI_NONE, EPI_GEGLU, OUT_ROWMAJOR, OUT_TRANSPOSED  # noqa: F401
+from ._lib import GemmDesc, EPI_NONE, EPI_GEGLU, EPI_GELU, OUT_ROWMAJOR, OUT_TRANSPOSED  # noqa: F401
 
 f16 = torch.float16
 f32 = torch.float32
@@ -71,6 +71,68 @@ def groupnorm(x1, x2, gamma, beta, eps, silu, ws=None, out=None, groups=32):
     return out
 
 
+def groupnorm_scaleshift(x1, x2, gamma, beta, scale, shift, mod_ld, eps, silu, ws=None, out=None, groups=32):
+    """GLIDE ResBlock FiLM norm: silu?(GN(cat(x1,x2)) * (1 + scale[b]) + shift[b]); scale/shift fp32 views [B, C]."""
+    _chk(x1, f16, "x1"); _chk(x2, f16, "x2")
+    B, HW, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[2]
+    C = C1 + C2
+    if ws is None:
+        ws = torch.empty(groupnorm_ws_floats(B, HW, C, groups), dtype=f32, device=x1.device)
+    if out is None:
+        out = torch.empty((B, HW, C), dtype=f16, device=x1.device)
+    _lib.check(_lib.load().mdx_groupnorm_scaleshift_f16(
+        _ptr(x1), C1, _ptr(x2), C2, _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift), int(mod_ld), _ptr(out), B, HW,
+        groups, float(eps), int(bool(silu)), _ptr(ws), _stream()), "mdx_groupnorm_scaleshift_f16")
+    return out
+
+
+def avgpool2x2(x, B, H, W, C, out=None):
+    if out is None:
+        out = torch.empty((B, (H // 2) * (W // 2), C), dtype=f16, device=x.device)
+    _lib.check(_lib.load().mdx_avgpool2x2_f16(_ptr(x), _ptr(out), B, H, W, C, _stream()), "mdx_avgpool2x2_f16")
+    return out
+
+
+def upsample_nearest2x(x, B, H, W, C, out=None):
+    if out is None:
+        out = torch.empty((B, 4 * H * W, C), dtype=f16, device=x.device)
+    _lib.check(_lib.load().mdx_upsample_nearest2x_f16(_ptr(x), _ptr(out), B, H, W, C, _stream()),
+               "mdx_upsample_nearest2x_f16")
+    return out
+
+
+def glide_text_embed(tokens, mask, tok_emb, pos, pad, out=None):
+    """tokens/mask int32 [B,T]; tables fp16; -> [B,T,width] fp16."""
+    B, T = tokens.shape
+    width = pos.shape[1]
+    if out is None:
+        out = torch.empty((B, T, width), dtype=f16, device=tokens.device)
+    _lib.check(_lib.load().mdx_glide_text_embed_f16(_ptr(tokens), _ptr(mask), _ptr(tok_emb), _ptr(pos), _ptr(pad),
+                                                    _ptr(out), B, T, width, tok_emb.shape[0], _stream()),
+               "mdx_glide_text_embed_f16")
+    return out
+
+
+def glide_superres_input(x, low, out=None):
+    """x [B,3,S,S] fp32, low [B,3,s,s] fp32 -> NHWC fp16 [B, S*S, 8] = [x | bilinear(quantised low) | 0 0]."""
+    B, _, S, _ = x.shape
+    if out is None:
+        out = torch.empty((B, S * S, 8), dtype=f16, device=x.device)
+    _lib.check(_lib.load().mdx_glide_superres_input_f16(_ptr(x), _ptr(low), _ptr(out), B, S, low.shape[2], _stream()),
+               "mdx_glide_superres_input_f16")
+    return out
+
+
+def glide_step(x, out_c, out_u, ld, scale, coef8, mode, noise_scale, noise, x_next, pred_x0):
+    B, _, H, W = x.shape
+    c8 = (ctypes.c_float * 8)(*[float(v) for v in coef8])
+    _lib.check(_lib.load().mdx_glide_step_f32(_ptr(x), _ptr(out_c), _ptr(out_u), int(ld), float(scale),
+                                              ctypes.cast(c8, ctypes.c_void_p), int(mode), float(noise_scale),
+                                              _ptr(noise), _ptr(x_next), _ptr(pred_x0), B, H, W, _stream()),
+               "mdx_glide_step_f32")
+
+
 def layernorm(x, gamma, beta, eps, out=None):
     _chk(x, f16, "x"); _chk(gamma, f32, "gamma"); _chk(beta, f32, "beta")
     C = x.shape[-1]
@@ -122,7 +184,7 @@ def pack_conv_weight(w4d, cin_pad=None, cout_pad=None):
 
 def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, rowbias=None, rowbias_ld=0,
                    residual=None, residual_ld=0, ksize=1, stride=1, upsample=0, epilogue=EPI_NONE,
-                   out_mode=OUT_ROWMAJOR, splitk=0, workspace=None):
+                   out_mode=OUT_ROWMAJOR, splitk=0, workspace=None, out_bs=0):
     d = GemmDesc()
     d.a = a.data_ptr()
     d.a2 = 0 if a2 is None else a2.data_ptr()
@@ -140,6 +202,7 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
     d.epilogue, d.out_mode, d.splitk = int(epilogue), int(out_mode), int(splitk)
     d.workspace = 0 if workspace is None else workspace.data_ptr()
     d.workspace_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    d.out_bs = int(out_bs)
     return d
 
 

@@ -1,0 +1,232 @@
+"""GPU parity for the Taichu-GLIDE path: new kernels one by one, then the planned
+Text2ImUNet / SuperResText2ImUNet and the two sampling loops against oracle/glide.py.
+Tolerances as in test_unet_gpu.py (fp16 storage / fp32 accumulate vs fp32 oracle)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from _util import check, h16
+from oracle import glide as OG
+from oracle import ldm as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+TINY = dict(image_size=16, num_channels=64, num_res_blocks=1, channel_mult=(1, 2), num_heads=1, num_head_channels=64,
+            num_heads_upsample=-1, attention_resolutions=(1, 2), dropout=0.0, text_ctx=16, xf_width=64, xf_layers=2,
+            xf_heads=1, xf_final_ln=True, n_vocab=100, xf_padding=True, diffusion_steps=1000,
+            noise_schedule="squaredcos_cap_v2", timestep_respacing="10", use_scale_shift_norm=True,
+            resblock_updown=True, use_fp16=True, cache_text_emb=False)
+OTINY = dict(OG.BASE_OPTIONS, image_size=16, model_channels=64, num_res_blocks=1, channel_mult=(1, 2),
+             attention_resolutions=(1, 2), text_ctx=16, xf_width=64, xf_layers=2, xf_heads=1, n_vocab=100,
+             timestep_respacing="10")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from minddiffusion_amd import ops as _ops
+    return _ops
+
+
+def dev16(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, torch.float16)
+
+
+def dev32(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, torch.float32)
+
+
+def nhwc(x):
+    b, c, h, w = x.shape
+    return np.ascontiguousarray(x.transpose(0, 2, 3, 1).reshape(b, h * w, c))
+
+
+def from_nhwc(y, b, h, w):
+    return y.reshape(b, h, w, -1).transpose(0, 3, 1, 2)
+
+
+def test_groupnorm_scaleshift(ops):
+    """unet.py:203-208: GN(h) * (1 + scale) + shift, then SiLU."""
+    rng = np.random.RandomState(0)
+    B, C, H, W = 3, 192, 8, 8
+    x = h16(rng.standard_normal((B, C, H, W)) + 0.2)
+    g, b = rng.standard_normal(C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    emb = rng.standard_normal((B, 1000)).astype(np.float32)
+    sc, sh = emb[:, 100:100 + C], emb[:, 100 + C:100 + 2 * C]
+    ref = O.silu(O.group_norm(torch.tensor(x), torch.tensor(g), torch.tensor(b), 1e-5)
+                 * (1 + torch.tensor(sc)[:, :, None, None]) + torch.tensor(sh)[:, :, None, None])
+    e = dev32(emb)
+    y = ops.groupnorm_scaleshift(dev16(nhwc(x)), None, dev32(g), dev32(b), e[:, 100:100 + C],
+                                 e[:, 100 + C:100 + 2 * C], 1000, 1e-5, True)
+    check("groupnorm_scaleshift", from_nhwc(y.float().cpu().numpy(), B, H, W), ref, rel_l2=1e-3, max_abs=3e-2)
+
+
+def test_avgpool_and_upsample(ops):
+    rng = np.random.RandomState(1)
+    B, C, H, W = 2, 64, 6, 8
+    x = h16(rng.standard_normal((B, C, H, W)))
+    y = ops.avgpool2x2(dev16(nhwc(x)), B, H, W, C)
+    ref = torch.nn.functional.avg_pool2d(torch.tensor(x), 2, 2)
+    check("avgpool2x2", from_nhwc(y.float().cpu().numpy(), B, H // 2, W // 2), ref, rel_l2=1e-3)
+    u = ops.upsample_nearest2x(dev16(nhwc(x)), B, H, W, C)
+    np.testing.assert_array_equal(from_nhwc(u.float().cpu().numpy(), B, 2 * H, 2 * W),
+                                  O.upsample_nearest2x(torch.tensor(x)).numpy())
+
+
+def test_text_embed(ops):
+    rng = np.random.RandomState(2)
+    B, T, Wd, V = 3, 16, 64, 50
+    tok = rng.randint(0, V, (B, T)).astype(np.int32)
+    mask = (rng.rand(B, T) > 0.3).astype(np.int32)
+    te, pe, pad = [h16(rng.standard_normal(s)) for s in ((V, Wd), (T, Wd), (T, Wd))]
+    ref = np.where(mask[..., None] != 0, te[tok] + pe[None], np.broadcast_to(pad[None], (B, T, Wd)))
+    out = ops.glide_text_embed(torch.tensor(tok, device=DEV), torch.tensor(mask, device=DEV), dev16(te), dev16(pe), dev16(pad))
+    check("glide_text_embed", out, ref, rel_l2=1e-3)
+
+
+def test_superres_input(ops):
+    """[x | legacy-bilinear(round((low+1)*127.5)/127.5-1)] (text2im_model.py:214-216, gaussian_diffusion.py:307-313)."""
+    rng = np.random.RandomState(3)
+    B, S, sl = 2, 32, 8
+    x = rng.standard_normal((B, 3, S, S)).astype(np.float32)
+    low = np.clip(rng.standard_normal((B, 3, sl, sl)) * 0.5, -1, 1).astype(np.float32)
+    q = torch.round((torch.tensor(low) + 1) * 127.5) / 127.5 - 1
+    ref = torch.cat([torch.tensor(x), OG.legacy_bilinear(q, S)], 1)
+    out = ops.glide_superres_input(dev32(x), dev32(low))
+    got = from_nhwc(out.float().cpu().numpy(), B, S, S)
+    check("glide_superres_input", got[:, :6], ref, rel_l2=1e-3)
+    assert np.all(got[:, 6:] == 0)
+
+
+@pytest.mark.parametrize("mode,i", [(0, 5), (0, 0), (1, 5), (1, 0)])
+def test_glide_step(ops, mode, i):
+    """Guider + PMeanVariance + PSample / DDimSample (guider.py:73-86, gaussian_diffusion.py:79-142, 229-254)."""
+    from minddiffusion_amd.glide.diffusion_creator import _Schedule
+    rng = np.random.RandomState(mode + i)
+    B, H, W = 2, 8, 8
+    sch = OG.respaced_schedule("squaredcos_cap_v2", 1000, "10")
+    x = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    oc = h16(rng.standard_normal((B, 6, H, W)))
+    ou = h16(rng.standard_normal((B, 6, H, W)))
+    noise = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    scale = 5.0
+    if mode == 0:
+        eps = torch.tensor(ou[:, :3]) + scale * (torch.tensor(oc[:, :3]) - torch.tensor(ou[:, :3]))
+        mean, logvar, x0, _ = OG.p_mean_variance(sch, torch.tensor(x), eps, torch.tensor(oc[:, 3:]), i)
+        ref = mean + (0.0 if i == 0 else 1.0) * torch.exp(0.5 * logvar) * torch.tensor(noise)
+    else:
+        _, _, x0, e2 = OG.p_mean_variance(sch, torch.tensor(x), torch.tensor(oc[:, :3]), torch.tensor(oc[:, 3:]), i)
+        ab = float(sch["alphas_cumprod_prev"][i])
+        ref = math.sqrt(ab) * x0 + math.sqrt(1 - ab) * e2
+
+    def buf(o):
+        t = np.zeros((B, H * W, 8), np.float32)
+        t[:, :, :6] = nhwc(o)
+        return dev16(t)
+
+    s = _Schedule("squaredcos_cap_v2", 1000, "10")
+    xd = dev32(x)
+    xn, px = torch.empty_like(xd), torch.empty_like(xd)
+    ops.glide_step(xd, buf(oc), buf(ou) if mode == 0 else None, 8, scale, s.coef8(i), mode,
+                   1.0 if (mode == 0 and i != 0) else 0.0, dev32(noise) if (mode == 0 and i != 0) else None, xn, px)
+    check(f"glide_step_mode{mode}_i{i}", xn, ref, rel_l2=2e-5)
+    check(f"glide_step_mode{mode}_i{i}_x0", px, x0, rel_l2=2e-5)
+
+
+def test_gemm_gelu_and_batch_strided_store(ops):
+    """MDX_EPI_GELU (xf.py:52-59) and writing a projection into a token sub-range of [B][ctx+T][C] (unet.py:296-300)."""
+    rng = np.random.RandomState(5)
+    B, T, ctx, K, N = 2, 64, 16, 64, 128
+    a = h16(rng.standard_normal((B * T, K)))
+    w = h16(rng.standard_normal((N, K)) / 8)
+    bv = rng.standard_normal(N).astype(np.float32)
+    wp = ops.pack_gemm_weight(dev16(w))
+    out = ops.gemm(dev16(a), wp, N, 1, B * T, 1, K, bias=dev32(bv), epilogue=ops.EPI_GELU)
+    check("gemm_gelu", out, O.gelu_tanh(torch.tensor(a) @ torch.tensor(w).T + torch.tensor(bv)), rel_l2=1e-3)
+    kbuf = torch.full((B, ctx + T, N), 7.0, dtype=torch.float16, device=DEV)
+    d = ops.make_gemm_desc(dev16(a), wp, N, B, T, 1, K, kbuf[:, ctx:], N, bias=dev32(bv), out_bs=(ctx + T) * N)
+    ops.gemm_run(d)
+    torch.cuda.synchronize()
+    ref = (a @ w.T + bv).reshape(B, T, N)
+    check("gemm_batch_strided_rows", kbuf[:, ctx:], ref, rel_l2=1e-3)
+    assert float((kbuf[:, :ctx] - 7.0).abs().max()) == 0.0     # the text-key rows were not touched
+
+
+def _build(graph=True):
+    from minddiffusion_amd.glide.diffusion_creator import create_model
+    params = OG.init_params(OTINY, seed=0)
+    net = create_model(**TINY)
+    net.use_graph = graph
+    net.load_state_dict(params)
+    return net, OG.GlideUNetOracle(OTINY, params)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_tiny_text2im_unet(graph):
+    net, oracle = _build(graph)
+    rng = np.random.RandomState(7)
+    B = 4
+    x = rng.randn(B, 3, 16, 16).astype(np.float32)
+    tok = rng.randint(1, 99, (B, 16)).astype(np.int32)
+    mask = np.ones((B, 16), np.int32)
+    mask[1, 9:] = 0
+    ref = oracle(x, torch.full((B,), 333.0), tok, mask)
+    got = net(torch.tensor(x, device=DEV), torch.full((B,), 333.0, device=DEV), torch.tensor(tok, device=DEV),
+              torch.tensor(mask, device=DEV))
+    check(f"glide_tiny_unet_graph{int(graph)}", got, ref, rel_l2=5e-3, max_abs=5e-2)
+
+
+def test_tiny_p_sample_loop():
+    """gaussian_p_sample_loop with CFG (main_funcs.py:21-44) on injected random prompts and noises."""
+    from minddiffusion_amd.glide.diffusion_creator import init_diffusion_model
+    from minddiffusion_amd.glide.main_funcs import gaussian_p_sample_loop
+    params = OG.init_params(OTINY, seed=2)
+    P, steps = 2, 10
+    dm = init_diffusion_model(options=TINY, guidance_scale=3.0, shape=(2 * P, 3, 16, 16), params=params)
+    assert dm.num_timesteps == steps
+    oracle = OG.GlideUNetOracle(OTINY, params)
+    sch = OG.respaced_schedule("squaredcos_cap_v2", 1000, "10")
+    rng = np.random.RandomState(11)
+    x_T = rng.randn(P, 3, 16, 16).astype(np.float32)
+    tok = rng.randint(1, 99, (P, 16)).astype(np.int32)
+    mask = np.ones((P, 16), np.int32)
+    unc = rng.randint(1, 99, (steps, 16)).astype(np.int32)
+    noises = rng.randn(steps, P, 3, 16, 16).astype(np.float32)
+    ref = OG.p_sample_loop(oracle, sch, x_T, tok, mask, 3.0, unc, noises)
+    x2 = np.concatenate([x_T, x_T], 0)
+    tok2, mask2 = np.concatenate([tok, tok], 0), np.concatenate([mask, mask], 0)   # second half is overwritten (guider.py:46)
+    got = gaussian_p_sample_loop(dm, torch.tensor(tok2), torch.tensor(mask2), (2 * P, 3, 16, 16), steps, text_ctx=16,
+                                 noise=torch.tensor(x2), vocab_len=100, uncond_tokens=list(unc),
+                                 step_noises=[torch.tensor(n, device=DEV) for n in noises])[:P]
+    check("glide_tiny_p_sample_loop", got, ref, rel_l2=1e-2, max_abs=3e-2)
+
+
+def test_tiny_superres_unet_and_ddim_loop():
+    from minddiffusion_amd.glide.diffusion_creator import init_super_res_model
+    from minddiffusion_amd.glide.main_funcs import ddim_sample_loop
+    opts = dict(TINY, image_size=32, channel_mult=(1, 1, 2), noise_schedule="linear", timestep_respacing="fast27",
+                low_size=8)
+    oopts = dict(OTINY, in_channels=6, image_size=32, channel_mult=(1, 1, 2), noise_schedule="linear",
+                 timestep_respacing="fast27")
+    params = OG.init_params(oopts, seed=4)
+    P = 2
+    sr = init_super_res_model(options=opts, shape=(P, 3, 32, 32), params=params)
+    assert sr.num_timesteps == 27
+    oracle = OG.GlideUNetOracle(oopts, params)
+    rng = np.random.RandomState(13)
+    x = rng.randn(P, 3, 32, 32).astype(np.float32)
+    low = np.clip(rng.randn(P, 3, 8, 8) * 0.5, -1, 1).astype(np.float32)
+    tok = rng.randint(1, 99, (P, 16)).astype(np.int32)
+    mask = np.ones((P, 16), np.int32)
+    lowq = torch.round((torch.tensor(low) + 1) * 127.5) / 127.5 - 1
+    ref1 = oracle(x, torch.full((P,), 500.0), tok, mask, low_res=lowq)
+    got1 = sr.model(torch.tensor(x, device=DEV), torch.full((P,), 500.0, device=DEV), torch.tensor(low, device=DEV),
+                    torch.tensor(tok, device=DEV), torch.tensor(mask, device=DEV))
+    check("glide_tiny_superres_unet", got1, ref1, rel_l2=5e-3, max_abs=5e-2)
+    sch = OG.respaced_schedule("linear", 1000, "fast27")
+    ref = OG.ddim_sample_loop(oracle, sch, x * 0.997, low, tok, mask)
+    got = ddim_sample_loop(sr, (P, 3, 32, 32), torch.tensor(low, device=DEV), torch.tensor(tok), torch.tensor(mask), 27,
+                           noise=torch.tensor(x * 0.997))
+    check("glide_tiny_ddim_superres_loop", got, ref, rel_l2=2e-2, max_abs=5e-2)

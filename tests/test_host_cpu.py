@@ -146,3 +146,52 @@ def test_unet_plan_builds_and_every_descriptor_validates():
             assert rc == 0, lib.mdx_last_error()
     with pytest.raises(_lib.MdxError):
         net._plan(1, 7, 8)   # not divisible by the downsampling factor
+
+
+TINY_GLIDE = dict(image_size=16, num_channels=64, num_res_blocks=1, channel_mult=(1, 2), num_heads=1,
+                  num_head_channels=64, num_heads_upsample=-1, attention_resolutions=(1, 2), dropout=0.0, text_ctx=16,
+                  xf_width=64, xf_layers=2, xf_heads=1, xf_final_ln=True, n_vocab=100, xf_padding=True,
+                  diffusion_steps=1000, noise_schedule="squaredcos_cap_v2", timestep_respacing="10",
+                  use_scale_shift_norm=True, resblock_updown=True, use_fp16=True, cache_text_emb=False)
+
+
+def test_glide_names_structure_and_plan_on_host():
+    """GLIDE mirror: parameter names/shapes equal the oracle's, the product's schedules equal the reference goldens,
+    and the planned op list validates descriptor by descriptor (nothing is launched)."""
+    import ctypes
+    from oracle import glide as OG
+    from minddiffusion_amd import _lib
+    from minddiffusion_amd.glide import gaussian_computation as gc
+    from minddiffusion_amd.glide.default_options import model_and_diffusion_defaults, model_and_diffusion_upsample
+    from minddiffusion_amd.glide.diffusion_creator import create_model, create_upsample_model, _Schedule
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "glide_schedule.npz"))
+    np.testing.assert_array_equal(gc.get_named_beta_schedule("squaredcos_cap_v2", 1000), gold["cosine_betas_1000"])
+    np.testing.assert_array_equal(gc.get_named_beta_schedule("linear", 1000), gold["linear_betas_1000"])
+    assert sorted(gc.space_timesteps(1000, "60")) == list(gold["space_60"])
+    assert sorted(gc.space_timesteps(1000, "fast27")) == list(gold["space_fast27"])
+    s, so = _Schedule("squaredcos_cap_v2", 1000, "60"), OG.respaced_schedule("squaredcos_cap_v2", 1000, "60")
+    np.testing.assert_array_equal(s.timestep_map, so["timestep_map"])
+    np.testing.assert_array_equal(s.coef1, so["coef1"])
+    np.testing.assert_array_equal(s.post_logvar, so["post_logvar_clipped"])
+    # full-size models: names and shapes only
+    base = create_model(device="cpu", **model_and_diffusion_defaults())
+    assert base.parameter_shapes() == OG.param_shapes(OG.BASE_OPTIONS)
+    up = create_upsample_model(device="cpu", **model_and_diffusion_upsample())
+    assert up.parameter_shapes() == OG.param_shapes(OG.UPSAMPLE_OPTIONS)
+    # tiny model: plan on the host and validate every descriptor
+    otiny = dict(OG.BASE_OPTIONS, image_size=16, model_channels=64, num_res_blocks=1, channel_mult=(1, 2),
+                 attention_resolutions=(1, 2), text_ctx=16, xf_width=64, xf_layers=2, xf_heads=1, n_vocab=100)
+    net = create_model(device="cpu", **TINY_GLIDE)
+    assert net.parameter_shapes() == OG.param_shapes(otiny)
+    net.load_state_dict(OG.init_params(otiny, seed=0))
+    lib = _lib.load()
+    P = net._plan(4, 16, 16)
+    assert len(P.main) > 80
+    for d in P.descs:
+        assert lib.mdx_gemm_check(ctypes.byref(d)) == 0, lib.mdx_last_error()
+    upt = create_upsample_model(device="cpu", low_size=8, **dict(TINY_GLIDE, image_size=32, channel_mult=(1, 1, 2)))
+    oup = dict(otiny, in_channels=6, image_size=32, channel_mult=(1, 1, 2))
+    upt.load_state_dict(OG.init_params(oup, seed=1))
+    Pu = upt._plan(2, 32, 32)
+    for d in Pu.descs:
+        assert lib.mdx_gemm_check(ctypes.byref(d)) == 0, lib.mdx_last_error()
