@@ -28,7 +28,7 @@ def metrics(got, ref):
     }
 
 
-def check(name, got, ref, rel_l2=None, max_abs=None, max_rel=None, **extra):
+def check(name, got, ref, rel_l2=None, max_abs=None, max_rel=None, abs_q=None, **extra):
     """Log and assert.  Tolerances are stated at the call site (fp16 storage / fp32 accumulate vs fp32 oracle)."""
     m = metrics(got, ref)
     rec = dict(name=name, **m, tol_rel_l2=rel_l2, tol_max_abs=max_abs, tol_max_rel=max_rel, **extra)
@@ -47,6 +47,9 @@ def check(name, got, ref, rel_l2=None, max_abs=None, max_rel=None, **extra):
     if max_rel is not None:  # max |d| relative to the largest reference magnitude
         assert m["max_abs"] <= max_rel * max(m["ref_max"], 1e-30), \
             f"{name}: max_abs {m['max_abs']:.3e} > {max_rel:.1e} * ref_max {m['ref_max']:.3e}"
+    if abs_q is not None:  # (quantile, bound): robust to the few elements a clipped / chaotic trajectory flips
+        qv = float(np.quantile(np.abs(to_np(got).astype(np.float64) - to_np(ref).astype(np.float64)), abs_q[0]))
+        assert qv <= abs_q[1], f"{name}: |d| quantile {abs_q[0]} = {qv:.3e} > {abs_q[1]:.1e}"
     return m
 
 
