@@ -31,6 +31,43 @@ TFLOP_PER_UNET_ROW_64 = 0.804      # SDv2 UNet, one eval, one ba
 MFMA_PEAK_TFLOPS = 2500.0          # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
+# BASELINE.json configs -> per-GPU workloads.  `sd2_512` (configs[1]) is the headline / default.
+CONFIGS = {
+    "sd2_512": dict(family="ldm", unet="sd2", latent=64, sampler="ddim", steps=50, scale=9.0, batch=1, ctx_dim=1024,
+                    tflop_per_row=0.804, unit="latents/s", metric="512x512 txt2img latents/sec (50-step DDIM)",
+                    workload="SDv2 txt2img 512x512 (64x64 latent), 50-step DDIM, CFG 9.0, batch 1 per GPU "
+                             "(BASELINE.json configs[1])"),
+    "wukong_512_plms": dict(family="ldm", unet="wukong", latent=64, sampler="plms", steps=50, scale=7.5, batch=8,
+                            ctx_dim=768, tflop_per_row=0.803, unit="latents/s",
+                            metric="512x512 txt2img latents/sec (50-step PLMS, Wukong-Huahua)",
+                            workload="Wukong-Huahua txt2img 512x512, PLMS 50 steps (51 UNet calls), CFG 7.5, batch 8 "
+                                     "per GPU (BASELINE.json configs[2])"),
+    "sd2_768": dict(family="ldm", unet="sd2", latent=96, sampler="ddim", steps=50, scale=7.5, batch=4, ctx_dim=1024,
+                    tflop_per_row=2.149, unit="latents/s", metric="768x768 txt2img latents/sec (50-step DDIM)",
+                    workload="SDv2 txt2img 768x768 (96x96 latent), 50-step DDIM, CFG 7.5, 4 images per GPU "
+                             "(BASELINE.json configs[3]: batch 32 over 8 GPUs)"),
+    "glide_256": dict(family="glide", batch=8, scale=5.0, tflop_per_image=63.2, unit="images/s",
+                      metric="Taichu-GLIDE 256x256 images/sec (60-step guided base + 27-step DDIM super-res)",
+                      workload="Taichu-GLIDE 64x64 base (60 ancestral steps, CFG 5, UNet batch 2P) + 256x256 super-res "
+                               "(27 DDIM steps), 8 images per GPU (BASELINE.json configs[4]: batch 16 over 2 GPUs)"),
+}
+
+
+def build_glide(device):
+    from minddiffusion_amd.glide.default_options import model_and_diffusion_defaults, model_and_diffusion_upsample
+    from minddiffusion_amd.glide.diffusion_creator import init_diffusion_model, init_super_res_model
+    from minddiffusion_amd.weights import synthetic_unet_params_device
+    P = CONFIGS["glide_256"]["batch"]
+    ob = dict(model_and_diffusion_defaults(), device=str(device))
+    ou = dict(model_and_diffusion_upsample(), device=str(device))
+    dm = init_diffusion_model(ob, CONFIGS["glide_256"]["scale"], (2 * P, 3, 64, 64))
+    dm.model.load_state_dict(synthetic_unet_params_device(dm.model.parameter_shapes(), seed=0, device=device))
+    sr = init_super_res_model(ou, (P, 3, 256, 256))
+    sr.model.load_state_dict(synthetic_unet_params_device(sr.model.parameter_shapes(), seed=1, device=device))
+    torch.cuda.synchronize()
+    return dm, sr
+
+
 def build_model(device, cfg_name="sd2"):
     from minddiffusion_amd.configs import SD2_LDM, SD2_UNET, WUKONG_UNET
     from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
@@ -108,17 +145,26 @@ def cpu_baseline(n_evals=1):
     }
 
 
+def pmc_traffic():
+    """HBM bytes per gemm_kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
+    profiles/r01_c_pmc_traffic.json; PMC counters cannot be read live from inside this process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")) as f:
+            return int(json.load(f)["gemm_kernel_total"]["hbm_bytes_per_launch_corrected"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1, help="images per GPU")
-    ap.add_argument("--ddim-steps", type=int, default=50)
-    ap.add_argument("--scale", type=float, default=9.0)
+    ap.add_argument("--config", default="sd2_512", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     from minddiffusion_amd import distributed as D
     from minddiffusion_amd.pipeline import DiffusionPipeline
@@ -128,22 +174,46 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    batch = cfg["batch"]
+    Bg = batch * world
 
-    model = build_model(device)
-    if args.no_graph:
-        model.unet.use_graph = False
-    pipe = DiffusionPipeline(model, sampler="ddim", device=device)
-    Bg = args.batch * world
-    h = w = 64
-    # synthetic prompts: N(0,1) text embeddings [B,77,1024] (seed 1), one unconditional row (seed 2), x_T seed 42
-    c = uc = x_T = None
-    if rank == 0:
-        c = torch.from_numpy(np.random.RandomState(1).randn(Bg, 77, 1024).astype(np.float32)).to(device, torch.float16)
-        uc = torch.from_numpy(np.random.RandomState(2).randn(1, 77, 1024).astype(np.float32)).to(device, torch.float16)
-        x_T = torch.from_numpy(np.random.RandomState(42).randn(Bg, 4, h, w).astype(np.float32)).to(device)
+    if cfg["family"] == "ldm":
+        model = build_model(device, cfg["unet"])
+        if args.no_graph:
+            model.unet.use_graph = False
+        pipe = DiffusionPipeline(model, sampler=cfg["sampler"], device=device)
+        h = w = cfg["latent"]
+        # synthetic prompts: N(0,1) text embeddings [B,77,ctx] (seed 1), one unconditional row (seed 2), x_T seed 42
+        c = uc = x_T = None
+        if rank == 0:
+            rs = np.random.RandomState
+            c = torch.from_numpy(rs(1).randn(Bg, 77, cfg["ctx_dim"]).astype(np.float32)).to(device, torch.float16)
+            uc = torch.from_numpy(rs(2).randn(1, 77, cfg["ctx_dim"]).astype(np.float32)).to(device, torch.float16)
+            x_T = torch.from_numpy(rs(42).randn(Bg, 4, h, w).astype(np.float32)).to(device)
 
-    def one_step():
-        return pipe(c=c, uc=uc, x_T=x_T, H=8 * h, W=8 * w, steps=args.ddim_steps, scale=args.scale, eta=0.0)
+        def one_step():
+            return pipe(c=c, uc=uc, x_T=x_T, H=8 * h, W=8 * w, steps=cfg["steps"], scale=cfg["scale"], eta=0.0)
+    else:
+        from minddiffusion_amd.glide.main_funcs import ddim_sample_loop, gaussian_p_sample_loop
+        dm, sr = build_glide(device)
+        if args.no_graph:
+            dm.model.use_graph = sr.model.use_graph = False
+        P = batch
+        tok = torch.from_numpy(np.random.RandomState(1).randint(1, 50000, (2 * P, 128)).astype(np.int32)).to(device)
+        if world > 1:   # rank 0's synthetic prompts go to every rank (RCCL broadcast, 8 KB)
+            torch.distributed.broadcast(tok, src=0)
+        msk = torch.ones((2 * P, 128), dtype=torch.int32, device=device)
+        rng = np.random.RandomState(7 + rank)
+        g = torch.Generator(device=device)
+        g.manual_seed(42 + rank)
+        dm.generator = g
+
+        def one_step():
+            x0 = torch.randn((2 * P, 3, 64, 64), device=device, generator=g)
+            base = gaussian_p_sample_loop(dm, tok, msk, (2 * P, 3, 64, 64), dm.num_timesteps, text_ctx=128, noise=x0,
+                                          vocab_len=50001, rng=rng)[:P]
+            up0 = torch.randn((P, 3, 256, 256), device=device, generator=g) * 0.997
+            return ddim_sample_loop(sr, (P, 3, 256, 256), base, tok[:P], msk[:P], sr.num_timesteps, noise=up0)
 
     def barrier():
         if world > 1:
@@ -165,46 +235,54 @@ def main():
     assert torch.isfinite(out).all()
 
     ms_per_step = elapsed / args.steps * 1e3
-    latents_per_s = Bg * args.steps / elapsed
-    result = None
+    units_per_s = Bg * args.steps / elapsed
     if rank == 0:
-        # per-UNet-step ms: HIP events around apply_model (CFG batch = 2 x per-GPU batch), median of 20 warm calls
-        net = model.unet
-        nb = 2 * args.batch
-        ctx = torch.randn(nb, 77, 1024, device=device, dtype=torch.float16)
-        xs = torch.randn(nb, 4, h, w, device=device)
-        tsv = torch.full((nb,), 501.0, device=device)
-        for _ in range(3):
-            model.apply_model_nhwc(xs, tsv, ctx)
-        evs = []
-        for _ in range(20):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            model.apply_model_nhwc(xs, tsv, ctx)
-            e1.record()
-            evs.append((e0, e1))
-        torch.cuda.synchronize()
-        unet_ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
-        tflop_per_latent = TFLOP_PER_UNET_ROW_64 * 2 * args.ddim_steps   # CFG doubles the rows
-        whole = latents_per_s / world * tflop_per_latent
-        roof = dominant_kernel_roofline(model, nb, h, w, ctx)
-        roof["whole_path"] = {"achieved": round(whole, 2), "frac": round(whole / MFMA_PEAK_TFLOPS, 4),
-                              "algorithmic_tflop_per_latent": tflop_per_latent,
-                              "note": "latents/s/GPU x SURVEY 8(d) TFLOP-per-latent (all kernels, launch gaps included)"}
         result = {
-            "metric": "512x512 txt2img latents/sec (50-step DDIM)", "value": round(latents_per_s, 4),
-            "unit": "latents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "SDv2 txt2img 512x512 (64x64 latent), 50-step DDIM, CFG 9.0, batch 1 per GPU "
-                                   "(BASELINE.json configs[1]); synthetic seeded weights + N(0,1) text embeddings",
-                       "global_batch": Bg, "ddim_steps": args.ddim_steps, "cfg_scale": args.scale,
-                       "unet_batch_per_gpu": nb, "parallelism": f"batch-shard x{world}",
-                       "hip_graph": bool(net.use_graph)},
-            "per_unet_step_ms": round(unet_ms, 3),
-            "roofline": roof,
+            "metric": cfg["metric"], "value": round(units_per_s, 4), "unit": cfg["unit"], "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": cfg["workload"] + "; synthetic seeded weights + synthetic text conditioning",
+                       "name": args.config, "global_batch": Bg, "parallelism": f"batch-shard x{world}",
+                       "hip_graph": not args.no_graph},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if cfg["family"] == "ldm":
+            # per-UNet-step ms: HIP events around apply_model (CFG batch = 2 x per-GPU batch), median of 20 warm calls
+            nb = 2 * batch
+            ctx = torch.randn(nb, 77, cfg["ctx_dim"], device=device, dtype=torch.float16)
+            xs = torch.randn(nb, 4, h, w, device=device)
+            tsv = torch.full((nb,), 501.0, device=device)
+            for _ in range(3):
+                model.apply_model_nhwc(xs, tsv, ctx)
+            evs = []
+            for _ in range(20):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                model.apply_model_nhwc(xs, tsv, ctx)
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            result["per_unet_step_ms"] = round(float(np.median([a.elapsed_time(b) for a, b in evs])), 3)
+            result["config"].update(ddim_steps=cfg["steps"], cfg_scale=cfg["scale"], unet_batch_per_gpu=nb,
+                                    sampler=cfg["sampler"])
+            n_evals = cfg["steps"] + (1 if cfg["sampler"] == "plms" else 0)
+            tflop_per_unit = cfg["tflop_per_row"] * 2 * n_evals      # CFG doubles the rows
+            roof = dominant_kernel_roofline(model, nb, h, w, ctx)
+            if args.config == "sd2_512":
+                roof["traffic"] = pmc_traffic()
+                roof["traffic_note"] = ("HBM bytes per launch, rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), "
+                                        "from profiles/r01_c_pmc_traffic.json (same workload, eager)")
+        else:
+            tflop_per_unit = cfg["tflop_per_image"]
+            roof = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                    "traffic": None, "kernel": "gemm_kernel (not broken out for this config)"}
+        whole = units_per_s / world * tflop_per_unit
+        roof["whole_path"] = {"achieved": round(whole, 2), "frac": round(whole / MFMA_PEAK_TFLOPS, 4),
+                              "algorithmic_tflop_per_unit": tflop_per_unit,
+                              "note": "units/s/GPU x SURVEY 8(d) TFLOP per unit (all kernels, launch gaps included)"}
+        if roof.get("achieved") is None:
+            roof["achieved"], roof["frac"] = roof["whole_path"]["achieved"], roof["whole_path"]["frac"]
+        result["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline and args.config == "sd2_512":
             result["cpu_baseline"] = cpu_baseline()
         else:
             result["cpu_baseline"] = None
