@@ -79,6 +79,155 @@ __device__ __forceinline__ void epilogue_store_row8(const GemmParams& p, float (
     *reinterpret_cast<f16x8*>(p.out + row + n) = o;
 }
 
+// Row maps: tile-local output row -> global output row m.
+struct LinearRows {
+    int m0;
+    __device__ __forceinline__ int operator()(int row) const { return m0 + row; }
+};
+// HALO conv tiles are 8 x 16 pixel patches: row = py*16 + px
+struct PatchRows {
+    int base, W;   // base = (b*H + y0)*W + x0
+    __device__ __forceinline__ int operator()(int row) const { return base + (row >> 4) * W + (row & 15); }
+};
+
+// Fused epilogue shared by the GEMM kernels.  SWAP: accumulators hold C^T (col = lane&31 -> m), staged through LDS
+// and stored row-major with bias / rowbias / residual / GEGLU / GELU; !SWAP: split-K partial slab or transposed store.
+template <int BM, int BN, bool SWAP, class RowMap>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / 64][BN / 64], char* smem,
+                                              const RowMap rm, const int n0, const int split) {
+    constexpr int TM = BM / 64;
+    constexpr int TN = BN / 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+    if constexpr (!SWAP) {
+        if (p.nsplit > 1) {
+            // split-K partial: C layout (col = lane&31 -> n, rows -> m), 128-B row segments per store
+            float* wsz = p.ws + (size_t)split * p.M * p.N;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = rm(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                        if (m < p.M && n < p.N) wsz[(size_t)m * p.N + n] = acc[i][j][r];
+                    }
+                }
+            return;
+        }
+        // transposed store (V^T): stage [n][m]
+        constexpr int TLD = BM + 8;
+        f16* stg = reinterpret_cast<f16*>(smem);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n_l = wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int m_l = wm * (BM / 2) + i * 32 + 8 * g + 4 * hi;
+                    *reinterpret_cast<f16x4*>(&stg[n_l * TLD + m_l]) =
+                        cvt4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                }
+            }
+        __syncthreads();
+        constexpr int CPT = BM / 8;        // 16-B chunks per staged n-row
+        constexpr int RPT = 256 / CPT;     // n-rows per pass
+        const int chunk = tid % CPT, r0 = tid / CPT;
+        const int m = rm(chunk * 8);
+#pragma unroll
+        for (int pass = 0; pass < BN / RPT; ++pass) {
+            const int nrow = r0 + pass * RPT;
+            const int n = n0 + nrow;
+            if (n < p.N && m < p.M) {
+                f16x8 v = *reinterpret_cast<const f16x8*>(&stg[nrow * TLD + chunk * 8]);
+                if (p.bias) {
+                    const float bb = p.bias[n];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + bb);
+                }
+                const int b = m / p.HoWo;
+                const int tok = m - b * p.HoWo;
+                *reinterpret_cast<f16x8*>(p.out + ((size_t)b * p.N + n) * p.out_ld + tok) = v;
+            }
+        }
+    } else {
+        // row-major store: C^T layout (col = lane&31 -> m, 4 consecutive n per register group)
+        constexpr int SLD = BN + 8;
+        f16* stg = reinterpret_cast<f16*>(smem);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int m_l = wm * (BM / 2) + i * 32 + l31;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n_l = wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
+                    *reinterpret_cast<f16x4*>(&stg[m_l * SLD + n_l]) =
+                        cvt4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                }
+            }
+        __syncthreads();
+        if (p.epilogue == MDX_EPI_GEGLU) {
+            if constexpr (BN == 128) {
+                // tile = 64 'a' columns | 64 'gate' columns -> 64 outputs at column n0/2
+                const int chunk = tid & 7, r0 = tid >> 3;
+                const int pn = n0 + chunk * 8;       // packed column of the 'a' part
+                const int on = (n0 >> 1) + chunk * 8;  // output column
+                float ba[8], bg[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ba[e] = (p.bias && pn < p.N) ? p.bias[pn + e] : 0.f;
+                    bg[e] = (p.bias && pn < p.N) ? p.bias[pn + 64 + e] : 0.f;
+                }
+#pragma unroll
+                for (int pass = 0; pass < BM / 32; ++pass) {
+                    const int row = r0 + pass * 32;
+                    const int m = rm(row);
+                    if (m < p.M && pn < p.N) {
+                        const f16x8 va = *reinterpret_cast<const f16x8*>(&stg[row * SLD + chunk * 8]);
+                        const f16x8 vg = *reinterpret_cast<const f16x8*>(&stg[row * SLD + 64 + chunk * 8]);
+                        float f[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            f[e] = ((float)va[e] + ba[e]) * gelu_tanh_f((float)vg[e] + bg[e]);
+                        epilogue_store_row8(p, f, m, on);
+                    }
+                }
+            }
+        } else {
+            constexpr int CPR = BN / 8;
+            constexpr int RPP = 256 / CPR;
+            const int chunk = tid % CPR, r0 = tid / CPR;
+            const int n = n0 + chunk * 8;
+            float bb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bb[e] = (p.bias && n < p.N) ? p.bias[n + e] : 0.f;
+#pragma unroll
+            for (int pass = 0; pass < BM / RPP; ++pass) {
+                const int row = r0 + pass * RPP;
+                const int m = rm(row);
+                if (m < p.M && n < p.N) {
+                    const f16x8 v = *reinterpret_cast<const f16x8*>(&stg[row * SLD + chunk * 8]);
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (float)v[e] + bb[e];
+                    if (p.epilogue == MDX_EPI_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = gelu_tanh_f(f[e]);
+                    }
+                    epilogue_store_row8(p, f, m, n);
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     constexpr int TM = BM / 64;             // 32-row MFMA tiles per wave along m (waves are 2 x 2)
@@ -306,130 +455,177 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
     __syncthreads();  // all waves done with the ring before the epilogue reuses it
 
-    // ------------------------------------------------------------------ epilogue
-    if constexpr (!SWAP) {
-        if (p.nsplit > 1) {
-            // split-K partial: C layout (col = lane&31 -> n, rows -> m), 128-B row segments per store
-            float* wsz = p.ws + (size_t)split * p.M * p.N;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wn * (BN / 2) + j * 32 + l31;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (m < p.M && n < p.N) wsz[(size_t)m * p.N + n] = acc[i][j][r];
-                    }
-                }
-            return;
-        }
-        // transposed store (V^T): stage [n][m]
-        constexpr int TLD = BM + 8;
-        f16* stg = reinterpret_cast<f16*>(smem);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n_l = wn * (BN / 2) + j * 32 + l31;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int m_l = wm * (BM / 2) + i * 32 + 8 * g + 4 * hi;
-                    *reinterpret_cast<f16x4*>(&stg[n_l * TLD + m_l]) =
-                        cvt4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                }
-            }
-        __syncthreads();
-        constexpr int CPT = BM / 8;        // 16-B chunks per staged n-row
-        constexpr int RPT = 256 / CPT;     // n-rows per pass
-        const int chunk = tid % CPT, r0 = tid / CPT;
-        const int m = m0 + chunk * 8;
-#pragma unroll
-        for (int pass = 0; pass < BN / RPT; ++pass) {
-            const int nrow = r0 + pass * RPT;
-            const int n = n0 + nrow;
-            if (n < p.N && m < p.M) {
-                f16x8 v = *reinterpret_cast<const f16x8*>(&stg[nrow * TLD + chunk * 8]);
-                if (p.bias) {
-                    const float bb = p.bias[n];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + bb);
-                }
-                const int b = m / p.HoWo;
-                const int tok = m - b * p.HoWo;
-                *reinterpret_cast<f16x8*>(p.out + ((size_t)b * p.N + n) * p.out_ld + tok) = v;
-            }
-        }
+    gemm_epilogue<BM, BN, SWAP>(p, acc, smem, LinearRows{m0}, n0, split);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// HALO conv kernel: 3x3, stride 1, pad 1, single source, Cin % 64 == 0, H % 8 == 0, W % 16 == 0.
+//
+// The generic kernel DMAs a fresh 128 x 64 activation tile for each of the 9 taps (L2 serves the re-read, but the
+// per-CU DMA rate -- the measured limiter, profiles/r01_dma_probe.txt -- still pays 9x).  Here the M tile is an
+// 8 x 16 PIXEL PATCH: for each 64-channel chunk the 10 x 18 halo (180 rows x 128 B, zero padding supplied by the
+// buffer bounds check) is brought into LDS ONCE and the A fragments of all 9 taps are read from it at
+// halo row (py+ky)*18 + (px+kx).  Activation DMA bytes drop 9 x 16 KiB -> 24 KiB per chunk (6x); with the weight
+// tiles (unchanged, one per tap) total DMA bytes per chunk drop 288 -> 168 KiB (BN = 128), 216 -> 96 KiB (BN = 64).
+//
+// LDS: halo[2][192 rows][128 B] (double buffered across chunks; same XOR swizzle keyed by the halo row) followed by an
+// NSB-stage ring of weight tiles.  The next chunk's halo is fetched one DMA instruction per wave per tap during
+// taps 0..5 of the current chunk, so the DMA stream stays even.
+template <int BN, int NSB, bool SWAP>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p) {
+    constexpr int BM = 128;
+    constexpr int TM = 2;
+    constexpr int TN = BN / 64;
+    constexpr int HALO_ROWS = 192;           // 180 used
+    constexpr int HALO_BYTES = HALO_ROWS * 128;
+    constexpr int HJ = HALO_ROWS / 8 / 4;    // halo DMA instructions per wave per chunk (6)
+    constexpr int B_BYTES = BN * 128;
+    constexpr int BJ = BN / 8 / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int tile_id = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile_id >= p.tiles_m * p.tiles_n) return;
+    int tile_m, tile_n;
+    if (p.n_fastest) {
+        tile_m = tile_id / p.tiles_n;
+        tile_n = tile_id - tile_m * p.tiles_n;
     } else {
-        // row-major store: C^T layout (col = lane&31 -> m, 4 consecutive n per register group)
-        constexpr int SLD = BN + 8;
-        f16* stg = reinterpret_cast<f16*>(smem);
+        tile_n = tile_id / p.tiles_m;
+        tile_m = tile_id - tile_n * p.tiles_m;
+    }
+    const int n0 = tile_n * BN;
+    const int pw = p.W >> 4, ph = p.H >> 3;
+    const int pb = tile_m / (ph * pw);
+    const int prem = tile_m - pb * (ph * pw);
+    const int py0 = (prem / pw) * 8, px0 = (prem % pw) * 16;
+    const int split = blockIdx.y;
+    const int kt_begin = split * p.ktiles_per_split;            // multiples of 9 (host guarantees chunk-aligned splits)
+    const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
+    const int nt = kt_end - kt_begin;
+    const int c_begin = kt_begin / 9, c_end = kt_end / 9;
+
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+
+    // halo loader: DMA instruction q of this wave covers halo rows (wave*HJ + q)*8 .. +7, lane -> row + lane/8
+    const int lrow = lane >> 3, lchk = lane & 7;
+    unsigned hal_off[HJ];
+    const unsigned row_bytes = (unsigned)p.cin * 2;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int q = 0; q < HJ; ++q) {
+        const int hp = (wave * HJ + q) * 8 + lrow;
+        const int hr = hp / 18, hc = hp - hr * 18;
+        const int y = py0 - 1 + hr, x = px0 - 1 + hc;
+        const bool ok = hp < 180 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        hal_off[q] = ok ? (unsigned)((pb * p.H + y) * p.W + x) * row_bytes + (unsigned)((lchk ^ ((hp >> 1) & 7)) * 16)
+                        : MDX_OOB;
+    }
+    unsigned b_off[BJ];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int m_l = wm * (BM / 2) + i * 32 + l31;
+    for (int j = 0; j < BJ; ++j) {
+        const int row = (wave * BJ + j) * 8 + lrow;
+        const int panel = (n0 >> 6) + (row >> 6);
+        b_off[j] = (unsigned)(((size_t)panel * p.kt64) * 8192 + ((row & 63) * 8 + lchk) * 16);
+    }
+    auto dma_halo = [&](int q, int chunk, int hb) {
+        const unsigned off = hal_off[q] == MDX_OOB ? MDX_OOB : hal_off[q] + (unsigned)chunk * 128u;
+        dma16(rs_a, smem + hb * HALO_BYTES + (wave * HJ + q) * 1024, off);
+    };
+    auto dma_b = [&](int kt, int stage) {
+        char* sb = smem + 2 * HALO_BYTES + stage * B_BYTES;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n_l = wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
-                    *reinterpret_cast<f16x4*>(&stg[m_l * SLD + n_l]) =
-                        cvt4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                }
+        for (int j = 0; j < BJ; ++j) dma16(rs_w, sb + (wave * BJ + j) * 1024, b_off[j] + (unsigned)kt * 8192);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addressing: A rows are patch pixels q = wm*64 + i*32 + l31 -> halo row of tap (0,0) = (q>>4)*18 + (q&15)
+    int hp0[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int q = wm * 64 + i * 32 + l31;
+        hp0[i] = (q >> 4) * 18 + (q & 15);
+    }
+    const int swz_b = (l31 >> 1) & 7;
+    const int b_row_off = 2 * HALO_BYTES + (wn * (BN / 2) + l31) * 128;
+
+    // prologue: whole halo of the first chunk + the first NSB-1 weight tiles
+#pragma unroll
+    for (int q = 0; q < HJ; ++q) dma_halo(q, c_begin, 0);
+#pragma unroll
+    for (int i = 0; i < NSB - 1; ++i)
+        if (i < nt) dma_b(kt_begin + i, i);
+
+    int t = 0;
+    int rd = 0, wr = NSB - 1;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int hb = (c - c_begin) & 1;
+        const bool more = c + 1 < c_end;
+        for (int tap = 0; tap < 9; ++tap, ++t) {
+            // weight tiles t .. t+NSB-2 (and at most one halo slice, older than tile t+1) are outstanding
+            if (NSB >= 3 && t + 1 < nt)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BJ) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
+            if (t + NSB - 1 < nt) dma_b(kt_begin + t + NSB - 1, wr);
+
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int dq = ky * 18 + kx;
+            int a_row[TM], a_key[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int hp = hp0[i] + dq;
+                a_row[i] = hb * HALO_BYTES + hp * 128;
+                a_key[i] = ((hp >> 1) & 7) << 4;
             }
-        __syncthreads();
-        if (p.epilogue == MDX_EPI_GEGLU) {
-            if constexpr (BN == 128) {
-                // tile = 64 'a' columns | 64 'gate' columns -> 64 outputs at column n0/2
-                const int chunk = tid & 7, r0 = tid >> 3;
-                const int pn = n0 + chunk * 8;       // packed column of the 'a' part
-                const int on = (n0 >> 1) + chunk * 8;  // output column
-                float ba[8], bg[8];
+            const char* sb = smem + rd * B_BYTES;
+            f16x8 af[2][TM], bf[2][TN];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    ba[e] = (p.bias && pn < p.N) ? p.bias[pn + e] : 0.f;
-                    bg[e] = (p.bias && pn < p.N) ? p.bias[pn + 64 + e] : 0.f;
+            for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + ((hi << 4) ^ a_key[i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + ((hi ^ swz_b) << 4));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                if (s < 3) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        af[nxt][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + (((2 * (s + 1) + hi) << 4) ^ a_key[i]));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + (((2 * (s + 1) + hi) ^ swz_b) << 4));
                 }
 #pragma unroll
-                for (int pass = 0; pass < BM / 32; ++pass) {
-                    const int row = r0 + pass * 32;
-                    const int m = m0 + row;
-                    if (m < p.M && pn < p.N) {
-                        const f16x8 va = *reinterpret_cast<const f16x8*>(&stg[row * SLD + chunk * 8]);
-                        const f16x8 vg = *reinterpret_cast<const f16x8*>(&stg[row * SLD + 64 + chunk * 8]);
-                        float f[8];
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            f[e] = ((float)va[e] + ba[e]) * gelu_tanh_f((float)vg[e] + bg[e]);
-                        epilogue_store_row8(p, f, m, on);
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (SWAP)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
                     }
-                }
             }
-        } else {
-            constexpr int CPR = BN / 8;
-            constexpr int RPP = 256 / CPR;
-            const int chunk = tid % CPR, r0 = tid / CPR;
-            const int n = n0 + chunk * 8;
-            float bb[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bb[e] = (p.bias && n < p.N) ? p.bias[n + e] : 0.f;
-#pragma unroll
-            for (int pass = 0; pass < BM / RPP; ++pass) {
-                const int row = r0 + pass * RPP;
-                const int m = m0 + row;
-                if (m < p.M && n < p.N) {
-                    const f16x8 v = *reinterpret_cast<const f16x8*>(&stg[row * SLD + chunk * 8]);
-                    float f[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = (float)v[e] + bb[e];
-                    if (p.epilogue == MDX_EPI_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] = gelu_tanh_f(f[e]);
-                    }
-                    epilogue_store_row8(p, f, m, n);
-                }
-            }
+            rd = (rd + 1 == NSB) ? 0 : rd + 1;
+            wr = (wr + 1 == NSB) ? 0 : wr + 1;
         }
     }
+    __syncthreads();
+    gemm_epilogue<BM, BN, SWAP>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split);
 }
 
 // split-K reduce + fused epilogue: one thread per (m, 8 output columns)
@@ -631,6 +827,28 @@ bool launch_bn(const GemmCfg& c, const GemmParams& p, bool swap, bool fastk, dim
     return true;
 }
 
+template <int BN, int NSB, bool SWAP>
+void launch_halo(const GemmParams& p, dim3 grid, hipStream_t st) {
+    constexpr size_t ring = 2 * 192 * 128 + (size_t)NSB * BN * 128;
+    constexpr size_t epi = (size_t)128 * (BN + 8) * 2 + 4096;
+    constexpr size_t lds = ring > epi ? ring : epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN, NSB, SWAP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, NSB, SWAP>), grid, dim3(256), lds, st, p);
+}
+
+// The HALO kernel applies to 3x3 / stride 1 / single-source convs whose image tiles into 8 x 16 patches.
+bool halo_eligible(const GemmParams& p) {
+    static const char* env = getenv("MDX_GEMM_HALO");
+    if (env && atoi(env) == 0) return false;
+    return p.ksize == 3 && p.stride == 1 && !p.upsample && p.c2 == 0 && p.cin % 64 == 0 && p.H % 8 == 0 &&
+           p.W % 16 == 0 && p.out_mode == MDX_OUT_ROWMAJOR;
+}
+
 }  // namespace
 
 extern "C" size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d) {
@@ -673,8 +891,17 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
             return MDX_E_WORKSPACE;
         }
     }
+    const bool halo = c.bm == 128 && halo_eligible(p);
     p.nsplit = ns;
-    p.ktiles_per_split = (p.ktiles + ns - 1) / ns;
+    if (halo) {
+        // chunk-aligned splits: a split owns whole 64-channel chunks (9 K tiles each)
+        const int chunks = p.cin / 64;
+        if (ns > chunks) ns = chunks;
+        const int cps = (chunks + ns - 1) / ns;
+        p.ktiles_per_split = cps * 9;
+    } else {
+        p.ktiles_per_split = (p.ktiles + ns - 1) / ns;
+    }
     p.nsplit = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;  // no empty splits
     ns = p.nsplit;
     p.tiles_m = (p.M + c.bm - 1) / c.bm;
@@ -694,7 +921,19 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     }
     const bool swap = (ns == 1) && (p.out_mode == MDX_OUT_ROWMAJOR);
     bool ok;
-    if (cc.bm == 64)
+    if (halo) {
+        int nsb = 2;   // measured: the 2-stage weight ring (2 blocks per CU) beats 3 stages at every UNet shape
+        static const char* envn = getenv("MDX_HALO_NSB");
+        if (envn && atoi(envn) >= 2 && atoi(envn) <= 3) nsb = atoi(envn);
+        if (bn == 128) {
+            if (nsb == 3) { if (swap) launch_halo<128, 3, true>(p, grid, st); else launch_halo<128, 3, false>(p, grid, st); }
+            else          { if (swap) launch_halo<128, 2, true>(p, grid, st); else launch_halo<128, 2, false>(p, grid, st); }
+        } else {
+            if (nsb == 3) { if (swap) launch_halo<64, 3, true>(p, grid, st); else launch_halo<64, 3, false>(p, grid, st); }
+            else          { if (swap) launch_halo<64, 2, true>(p, grid, st); else launch_halo<64, 2, false>(p, grid, st); }
+        }
+        ok = true;
+    } else if (cc.bm == 64)
         ok = (bn == 128) ? launch_bn<64, 128>(cc, p, swap, fastk, grid, st) : launch_bn<64, 64>(cc, p, swap, fastk, grid, st);
     else
         ok = (bn == 128) ? launch_bn<128, 128>(cc, p, swap, fastk, grid, st) : launch_bn<128, 64>(cc, p, swap, fastk, grid, st);

@@ -195,15 +195,37 @@ def test_tiny_p_sample_loop():
     mask = np.ones((P, 16), np.int32)
     unc = rng.randint(1, 99, (steps, 16)).astype(np.int32)
     noises = rng.randn(steps, P, 3, 16, 16).astype(np.float32)
-    ref = OG.p_sample_loop(oracle, sch, x_T, tok, mask, 3.0, unc, noises)
-    x2 = np.concatenate([x_T, x_T], 0)
+    traj = []
+    ref = OG.p_sample_loop(oracle, sch, x_T, tok, mask, 3.0, unc, noises, trajectory=traj)
     tok2, mask2 = np.concatenate([tok, tok], 0), np.concatenate([mask, mask], 0)   # second half is overwritten (guider.py:46)
+    # (1) teacher-forced along the ORACLE's trajectory (not amplified by the chaotic 10-step recursion):
+    #   (a) the guided network output at every x_t carries the tight, well-conditioned tolerance;
+    #   (b) x_{t-1}: the first respaced step has alpha-bar ~ 2e-9, so x0 = 2.4e4 * (...) is clipped to +-1 for EVERY
+    #       element and an eps difference of 1e-2 flips the sign of a few of them (|d| = 2 * coef1 = 0.34): bound the
+    #       bulk (99 % within 2e-2) and the energy, not the flipped elements.  The step kernel itself is exact on
+    #       identical network outputs (test_glide_step, 1e-6).
+    ones = np.ones((16,), np.int32)
+    for k, i in enumerate(range(steps - 1, -1, -1)):
+        xk = torch.cat([traj[k], traj[k]], 0)
+        t = torch.full((2 * P,), float(sch["timestep_map"][i]))
+        tk = torch.cat([torch.tensor(tok), torch.tensor(unc[k])[None].expand(P, -1)], 0)
+        mk = torch.cat([torch.tensor(mask), torch.ones(P, 16, dtype=torch.int32)], 0)
+        ref_out = oracle(xk, t, tk, mk)
+        dout = dm.model.forward_nhwc(xk.to(DEV), t.to(DEV), tk.to(DEV), mk.to(DEV))
+        got_out = dout.reshape(2 * P, 16, 16, -1)[..., :6].permute(0, 3, 1, 2).float()
+        check(f"glide_tiny_guided_net_out_step{i}", got_out, ref_out, rel_l2=5e-3, max_abs=5e-2)
+        got_k, _ = dm(x=xk.to(DEV), timesteps=torch.tensor([i], dtype=torch.int32), token=torch.tensor(tok2),
+                      mask=torch.tensor(mask2), random_token=unc[k], random_mask=ones,
+                      noise=torch.tensor(noises[k], device=DEV))
+        check(f"glide_tiny_p_sample_step{i}", got_k[:P], traj[k + 1], rel_l2=2e-2, abs_q=(0.99, 2e-2))
+    # (2) free-running loop: 10 ancestral steps with CFG 3, x0 clipping and exp(logvar/2) noise scaling on random
+    # weights compound the per-call fp16 error (2e-3) chaotically -- which elements flip at the clip changes with any
+    # change of fp32 summation order -- so bound the energy of the difference and the bulk of the distribution
+    x2 = np.concatenate([x_T, x_T], 0)
     got = gaussian_p_sample_loop(dm, torch.tensor(tok2), torch.tensor(mask2), (2 * P, 3, 16, 16), steps, text_ctx=16,
                                  noise=torch.tensor(x2), vocab_len=100, uncond_tokens=list(unc),
                                  step_noises=[torch.tensor(n, device=DEV) for n in noises])[:P]
-    # 10 ancestral steps with CFG 3, x0 clipping and exp(logvar/2) noise scaling on random weights compound the
-    # per-call fp16 error (2e-3): bound the bulk of the distribution, not the few elements that flip at the clip
-    check("glide_tiny_p_sample_loop", got, ref, rel_l2=3e-2, abs_q=(0.99, 5e-2))
+    check("glide_tiny_p_sample_loop", got, ref, rel_l2=3e-2, abs_q=(0.95, 5e-2))
 
 
 def test_tiny_superres_unet_and_ddim_loop():

@@ -173,6 +173,13 @@ def test_gemm_two_source_1x1(ops):
     (1, 32, 32, 320, 640, 1, 0, 1),
     (1, 8, 8, 8, 64, 1, 0, 1),          # conv_in: Cin padded 4 -> 8, generic (non 64-aligned) K path
     (1, 8, 8, 64, 8, 1, 0, 1),          # conv_out: Cout padded 4 -> 8
+    # 8x16-patch HALO kernel (H % 8 == 0, W % 16 == 0, Cin % 64 == 0, stride 1):
+    (2, 16, 32, 192, 320, 1, 0, 1),     # 64-wide N tiles, several chunks, patches across two images
+    (2, 16, 16, 320, 320, 1, 0, 0),     # auto split-K (chunk-aligned)
+    (1, 16, 16, 640, 128, 1, 0, 3),     # 10 chunks over 3 splits (4 + 4 + 2)
+    (3, 8, 16, 64, 72, 1, 0, 1),        # one patch per image, N tail
+    (1, 24, 48, 128, 8, 1, 0, 1),       # conv_out shape, non-power-of-two patch grid
+    (1, 64, 64, 64, 64, 1, 0, 1),       # 32 patches: image borders on all sides + interior
 ])
 def test_gemm_conv3x3(ops, B, H, W, Cin, Cout, stride, up, splitk):
     rng = np.random.RandomState(Cin + Cout + H + stride + up)
@@ -205,6 +212,24 @@ def test_gemm_conv_rowbias_residual(ops):
     out = ops.gemm(dev16(nhwc(x)), pack_conv(w), C, B, H, W, C, bias=dev32(bv), ksize=3,
                    rowbias=embd[:, 72:136], rowbias_ld=200, residual=dev16(nhwc(res)), residual_ld=C)
     check("conv3x3_rowbias_residual", from_nhwc(out.float().cpu().numpy(), B, H, W), ref, rel_l2=1e-3)
+
+
+@pytest.mark.parametrize("splitk", [1, 2])
+def test_gemm_conv_halo_rowbias_residual(ops, splitk):
+    """Same fused epilogue through the 8x16-patch HALO kernel (row -> pixel map differs from the linear one)."""
+    rng = np.random.RandomState(19)
+    B, H, W, C, N = 3, 16, 32, 128, 192
+    x = h16(rng.standard_normal((B, C, H, W)))
+    w = h16(rng.standard_normal((N, C, 3, 3)) / 34)
+    bv = rng.standard_normal(N).astype(np.float32)
+    emb = rng.standard_normal((B, 400)).astype(np.float32)
+    res = h16(rng.standard_normal((B, N, H, W)))
+    ref = O.conv2d(torch.tensor(x), torch.tensor(w), torch.tensor(bv)) + torch.tensor(emb[:, 8:200])[:, :, None, None] \
+        + torch.tensor(res)
+    embd = dev32(emb)
+    out = ops.gemm(dev16(nhwc(x)), pack_conv(w), N, B, H, W, C, bias=dev32(bv), ksize=3, splitk=splitk,
+                   rowbias=embd[:, 8:200], rowbias_ld=400, residual=dev16(nhwc(res)), residual_ld=N)
+    check(f"conv3x3_halo_rowbias_residual_k{splitk}", from_nhwc(out.float().cpu().numpy(), B, H, W), ref, rel_l2=1e-3)
 
 
 @pytest.mark.parametrize("M,C,splitk", [(256, 64, 1), (100, 320, 1), (64, 320, 2)])
