@@ -186,6 +186,10 @@ int mdx_probe_mfma_32x32x16_f16(const void* a, const void* b, float* c, mdx_stre
 int mdx_probe_dma_stream(const void* src, size_t bytes_per_block, int nblocks, int waves, int per, int ns, int mode,
                          int stride_tiles, float* sink, mdx_stream_t s);
 
+/* diagnostics: register a device buffer (bytes >= 64 x blocks) that the blocks of subsequent mdx_gemm_f16 launches
+ * fill with phase timestamps (8 x u64 per block, 100 MHz realtime counter); NULL unregisters.  tools/gemm_trace.py */
+int mdx_probe_gemm_trace(void* buf, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdx.so")
+# MDX_LIBRARY selects another build of the SAME C-ABI (the diagnostics build libmdx_trace.so, tools/gemm_trace.py)
+LIB_PATH = os.environ.get("MDX_LIBRARY") or os.path.join(_HERE, "libmdx.so")
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -66,6 +67,7 @@ SIGNATURES = {
     "mdx_glide_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_float, c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mdx_probe_mfma_32x32x16_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdx_probe_gemm_trace": (c_int, [c_void_p, c_size_t]),
     "mdx_probe_dma_stream": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 

@@ -20,6 +20,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace {
 
 struct GemmParams {
@@ -42,6 +44,7 @@ struct GemmParams {
     int kt64;   // 64-wide K tiles in the packed weight storage
     unsigned a_bytes, a2_bytes, w_bytes;
     int bk;
+    unsigned long long* trace;   // diagnostics: per-block phase timestamps (mdx_probe_gemm_trace), else null
 };
 
 
@@ -77,6 +80,15 @@ __device__ __forceinline__ void epilogue_store_row8(const GemmParams& p, float (
         row = (size_t)b * p.out_bs + (size_t)(m - b * p.HoWo) * p.out_ld;
     }
     *reinterpret_cast<f16x8*>(p.out + row + n) = o;
+}
+
+// Diagnostics (mdx_probe_gemm_trace): block `bid` records the 100 MHz realtime counter at phase `slot`.
+// Compiled in only with -DMDX_GEMM_TRACE (libmdx_trace.so, `make trace`); the product library carries no trace code.
+__device__ __forceinline__ void trace_mark(const GemmParams& p, int slot) {
+#ifdef MDX_GEMM_TRACE
+    if (p.trace && threadIdx.x == 0)
+        p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // Row maps: tile-local output row -> global output row m.
@@ -256,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     // XCD a CONTIGUOUS run of tile ids; ids run fastest along the dimension that shares the bigger operand.
     const int tile_id = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
     if (tile_id >= p.tiles_m * p.tiles_n) return;
+    trace_mark(p, 0);
     int tile_m, tile_n;
     if (p.n_fastest) {
         tile_m = tile_id / p.tiles_n;
@@ -288,6 +301,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         const int row = (wave * AJ + j) * RPI + lrow;
         const int m = m0 + row;
         const bool okm = m < p.M;
+        a_cb[j] = (unsigned)((lchk ^ ((row / RP256) % CPRW)) * 16);
+        if (p.ksize == 1 && p.stride == 1 && !p.upsample) {
+            // Dense / 1x1 conv (most launches): the source pixel IS the output row -- skip the (b, y, x) divisions
+            a_y[j] = a_x[j] = 0;
+            a_pix[j] = a_b[j] = okm ? m : 0;
+            a_mask[j] = okm ? 1u : 0u;
+            continue;
+        }
         const int mm = okm ? m : 0;
         const int b = mm / p.HoWo;
         const int rem = mm - b * p.HoWo;
@@ -297,7 +318,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         a_y[j] = yo * p.stride - p.pad;
         a_x[j] = xo * p.stride - p.pad;
         a_pix[j] = a_b[j] + a_y[j] * p.W + a_x[j];
-        a_cb[j] = (unsigned)((lchk ^ ((row / RP256) % CPRW)) * 16);
         unsigned mk = 0;
         for (int t = 0; t < p.ksize * p.ksize; ++t) {
             const int ky = (p.ksize == 3) ? t / 3 : 0, kx = (p.ksize == 3) ? t - ky * 3 : 0;
@@ -411,6 +431,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         if (i < nt) stage_tile(kt_begin + i, i);
     int rd = 0;            // stage holding tile t
     int wr = NS - 1;       // stage that tile t+NS-1 goes to
+    trace_mark(p, 1);
     for (int t = 0; t < nt; ++t) {
         // tiles t .. min(t+NS-2, nt-1) are outstanding; allow all but the oldest to stay in flight
         const int ahead = min(NS - 2, nt - 1 - t);
@@ -423,6 +444,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (t == 0) trace_mark(p, 2);
         if (t + NS - 1 < nt) stage_tile(kt_begin + t + NS - 1, wr);
         const char* sb = smem + rd * STAGE;
         f16x8 af[2][TM], bf[2][TN];
@@ -454,8 +476,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         wr = (wr + 1 == NS) ? 0 : wr + 1;
     }
     __syncthreads();  // all waves done with the ring before the epilogue reuses it
-
+    trace_mark(p, 3);
     gemm_epilogue<BM, BN, SWAP>(p, acc, smem, LinearRows{m0}, n0, split);
+    trace_mark(p, 4);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -500,6 +523,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p
         tile_n = tile_id / p.tiles_m;
         tile_m = tile_id - tile_n * p.tiles_m;
     }
+    trace_mark(p, 0);
     const int n0 = tile_n * BN;
     const int pw = p.W >> 4, ph = p.H >> 3;
     const int pb = tile_m / (ph * pw);
@@ -571,6 +595,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p
 
     int t = 0;
     int rd = 0, wr = NSB - 1;
+    trace_mark(p, 1);
     for (int c = c_begin; c < c_end; ++c) {
         const int hb = (c - c_begin) & 1;
         const bool more = c + 1 < c_end;
@@ -581,6 +606,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if (t == 0) trace_mark(p, 2);
             if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
             if (t + NSB - 1 < nt) dma_b(kt_begin + t + NSB - 1, wr);
 
@@ -625,7 +651,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p
         }
     }
     __syncthreads();
+    trace_mark(p, 3);
     gemm_epilogue<BM, BN, SWAP>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split);
+    trace_mark(p, 4);
+}
+
+// 8 consecutive fp32 of row m from every split-K slab, summed in slab order (deterministic).  The loads of up to four
+// slabs are issued before the first add so that the HBM/L2 latency is paid once per batch, not once per slab.
+__device__ __forceinline__ void splitk_sum8(const GemmParams& p, const float* base, const size_t slab, float (&f)[8]) {
+    int z = 0;
+    for (; z + 4 <= p.nsplit; z += 4) {
+        float4 v[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4* s = reinterpret_cast<const float4*>(base + (size_t)(z + u) * slab);
+            v[u][0] = s[0];
+            v[u][1] = s[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f[0] += v[u][0].x; f[1] += v[u][0].y; f[2] += v[u][0].z; f[3] += v[u][0].w;
+            f[4] += v[u][1].x; f[5] += v[u][1].y; f[6] += v[u][1].z; f[7] += v[u][1].w;
+        }
+    }
+    for (; z < p.nsplit; ++z) {
+        const float4* s = reinterpret_cast<const float4*>(base + (size_t)z * slab);
+        const float4 s0 = s[0], s1 = s[1];
+        f[0] += s0.x; f[1] += s0.y; f[2] += s0.z; f[3] += s0.w; f[4] += s1.x; f[5] += s1.y; f[6] += s1.z; f[7] += s1.w;
+    }
 }
 
 // split-K reduce + fused epilogue: one thread per (m, 8 output columns)
@@ -647,23 +700,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
                 a[e] = p.bias ? p.bias[pa + e] : 0.f;
                 g[e] = p.bias ? p.bias[pa + 64 + e] : 0.f;
             }
-            for (int z = 0; z < p.nsplit; ++z) {
-                const float4* s = reinterpret_cast<const float4*>(p.ws + z * slab + (size_t)m * p.N + pa);
-                const float4* t = reinterpret_cast<const float4*>(p.ws + z * slab + (size_t)m * p.N + pa + 64);
-                const float4 s0 = s[0], s1 = s[1], t0 = t[0], t1 = t[1];
-                a[0] += s0.x; a[1] += s0.y; a[2] += s0.z; a[3] += s0.w; a[4] += s1.x; a[5] += s1.y; a[6] += s1.z; a[7] += s1.w;
-                g[0] += t0.x; g[1] += t0.y; g[2] += t0.z; g[3] += t0.w; g[4] += t1.x; g[5] += t1.y; g[6] += t1.z; g[7] += t1.w;
-            }
+            splitk_sum8(p, p.ws + (size_t)m * p.N + pa, slab, a);
+            splitk_sum8(p, p.ws + (size_t)m * p.N + pa + 64, slab, g);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = a[e] * gelu_tanh_f(g[e]);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = p.bias ? p.bias[oc + e] : 0.f;
-            for (int z = 0; z < p.nsplit; ++z) {
-                const float4* s = reinterpret_cast<const float4*>(p.ws + z * slab + (size_t)m * p.N + oc);
-                const float4 s0 = s[0], s1 = s[1];
-                f[0] += s0.x; f[1] += s0.y; f[2] += s0.z; f[3] += s0.w; f[4] += s1.x; f[5] += s1.y; f[6] += s1.z; f[7] += s1.w;
-            }
+            splitk_sum8(p, p.ws + (size_t)m * p.N + oc, slab, f);
             if (p.epilogue == MDX_EPI_GELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = gelu_tanh_f(f[e]);
@@ -759,12 +803,10 @@ struct GemmCfg {
 // Tile configuration.  Experiments: MDX_GEMM_CFG="bk,ns" overrides (bk in {32,64}, ns in {2,3,4}).
 GemmCfg pick_cfg(const GemmParams& p) {
     GemmCfg c;
-    c.bm = 128;
+    c.bm = 128;   // finalised by choose_tiling
     c.bn = pick_bn(p);
     c.bk = 64;
     c.ns = 2;   // ring depth is finalised in mdx_gemm_f16 once the grid size is known
-    static const char* envbm = getenv("MDX_GEMM_BM");
-    if (envbm && atoi(envbm) == 64) c.bm = 64;
     static const char* env = getenv("MDX_GEMM_CFG");
     if (env) {
         int bk = 0, ns = 0;
@@ -776,16 +818,67 @@ GemmCfg pick_cfg(const GemmParams& p) {
     return c;
 }
 
-// Split-K heuristic, from the measured sweep (profiles/r01_gemm_splitk_sweep.txt): one 128-row tile pulls only
-// ~50 GB/s through the DMA path, so small grids are spread over ~1.4 blocks per CU by splitting K; above ~176 tiles
-// the fp32 slab round trip costs more than it buys.
-int auto_split(const GemmParams& p, int bm, int bn) {
-    const int tiles = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-    int ns = (352 + tiles / 2) / tiles;
-    const int maxk = (p.K / 64) / 4;    // keep >= 256 k per split
-    if (ns > maxk) ns = maxk;
-    if (ns > 16) ns = 16;
-    return ns < 1 ? 1 : ns;
+bool halo_eligible(const GemmParams& p);
+
+// Tile height and split-K factor from a cost model fitted to the B=2 micro-benchmarks
+// (profiles/r01_gemm_auto_tiling.txt, tools/gemm_trace.py), in microseconds:
+//   main loop   = K tiles per split x tau(kernel, tile) x occupancy    tau = 0.65 us for the generic 128x128 tile:
+//                 a K-tile step of ONE block is bound by its own DMA-issue + MFMA + barrier chain, so small grids
+//                 finish sooner with more, smaller blocks -- until every CU holds one (occupancy = 1 up to 256
+//                 blocks, 1.15 x rounds of 512 beyond); never less than streaming the cold operands once from HBM;
+//   split-K     = 3.5 (the extra reduce launch) + 0.3 x splits x slab MB (slab write + re-read);
+// fixed per-launch costs are the same for every candidate and drop out.  Splits keep >= 4 K tiles (HALO convs: whole
+// 64-channel chunks).  The 64-row tile is only a candidate for the generic kernel (HALO patches are 128 pixels).
+struct Tiling {
+    int bm, ns;
+};
+
+Tiling choose_tiling(const GemmParams& p, int bn, int forced_ns) {
+    static const char* envbm = getenv("MDX_GEMM_BM");
+    const bool halo_ok = halo_eligible(p);
+    const int kt = (p.K + 63) / 64;
+    const int chunks = p.cin / 64;
+    const double slab_mb = (double)p.M * p.N * 4.0 / 1048576.0;
+    const double unique_mb = ((double)p.N * p.K + (double)p.M * p.cin) * 2.0 / 1048576.0;
+    Tiling best{128, 1};
+    double best_cost = 1e30;
+    for (int bm = 128; bm >= 64; bm -= 64) {
+        if (envbm && atoi(envbm) != bm) continue;
+        const bool halo = halo_ok && bm == 128;
+        if (bm == 64 && halo_ok && !envbm) continue;
+        const int tiles = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+        // us per K-tile step of one block running alone on its CU (tools/gemm_trace.py): fewer DMA instructions and
+        // MFMAs per step for the smaller tiles and for the HALO kernel (one activation DMA per 9 taps)
+        const double tau = (halo ? 0.60 : 0.65) * (bm == 64 ? 0.7 : 1.0) * (bn == 64 ? 0.7 : 1.0);
+        const int max_ns = forced_ns > 0 ? forced_ns : 16;
+        for (int ns = forced_ns > 0 ? forced_ns : 1; ns <= max_ns; ++ns) {
+            int kps, eff;
+            if (halo) {
+                if (ns > chunks && forced_ns <= 0) break;
+                const int cps = (chunks + std::min(ns, chunks) - 1) / std::min(ns, chunks);
+                kps = cps * 9;
+                eff = (chunks + cps - 1) / cps;
+            } else {
+                if (forced_ns <= 0 && ns > 1 && kt / ns < 4) break;
+                kps = (kt + std::min(ns, kt) - 1) / std::min(ns, kt);
+                eff = (kt + kps - 1) / kps;
+            }
+            if (forced_ns <= 0 && eff != ns) continue;   // same launch as a smaller ns
+            // up to 256 blocks run one per CU; beyond that two share a CU (their stalls overlap: only ~1.15x slower
+            // each) and the grid runs in rounds of 512 -- the last, partly filled round costs as much as a full one
+            const int blocks = tiles * eff;
+            const double occ = blocks <= 256 ? 1.0 : 1.15 * ((blocks + 511) / 512);
+            const double main_us = std::max(kps * tau * occ, unique_mb / 3.5);   // cold operands stream at ~3.5 TB/s
+            const double cost = main_us + (eff > 1 ? 3.5 + 0.3 * eff * slab_mb : 0.0);
+            // candidates come in order of increasing launch complexity (128-row tiles first, fewer splits first):
+            // the model is only good to ~10-20 %, so a more complex one must promise a clear win
+            if (cost < 0.9 * best_cost) {
+                best_cost = cost;
+                best = Tiling{bm, ns};
+            }
+        }
+    }
+    return best;
 }
 
 template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK>
@@ -851,11 +944,23 @@ bool halo_eligible(const GemmParams& p) {
 
 }  // namespace
 
+static unsigned long long* g_gemm_trace = nullptr;
+static size_t g_gemm_trace_slots = 0;
+
+// Diagnostics: while a buffer is registered, every block of the next mdx_gemm_f16 launches writes 8 x u64 phase
+// timestamps (s_memrealtime, 100 MHz): 0 start, 1 prologue issued, 2 first tile landed, 3 main loop done, 4 epilogue
+// done.  NULL unregisters.  Not thread safe; not for production use.
+extern "C" int mdx_probe_gemm_trace(void* buf, size_t bytes) {
+    g_gemm_trace = (unsigned long long*)buf;
+    g_gemm_trace_slots = buf ? bytes / 64 : 0;
+    return MDX_OK;
+}
+
 extern "C" size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d) {
     GemmParams p{};
     if (fill_params(d, p) != MDX_OK) return 0;
     const GemmCfg c = pick_cfg(p);
-    const int ns = d->splitk > 0 ? d->splitk : auto_split(p, c.bm, c.bn);
+    const int ns = choose_tiling(p, c.bn, d->splitk).ns;
     return ns > 1 ? (size_t)ns * p.M * p.N * sizeof(float) : 0;
 }
 
@@ -873,11 +978,13 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     int rc = fill_params(d, p);
     if (rc != MDX_OK) return rc;
     hipStream_t st = (hipStream_t)s;
-    const GemmCfg c = pick_cfg(p);
+    GemmCfg c = pick_cfg(p);
     const int bn = c.bn;
     p.bk = c.bk;
     p.ktiles = (p.K + c.bk - 1) / c.bk;
-    int ns = d->splitk > 0 ? d->splitk : auto_split(p, c.bm, bn);
+    const Tiling tl = choose_tiling(p, bn, d->splitk);
+    c.bm = tl.bm;
+    int ns = tl.ns;
     if (ns > p.ktiles) ns = p.ktiles;
     if (ns > 1) {
         // shrink to what the caller's workspace can hold
@@ -913,6 +1020,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     // share the bigger operand inside an XCD: unique activation bytes vs weight bytes
     p.n_fastest = ((size_t)p.M * p.cin >= (size_t)p.N * p.K) ? 1 : 0;
     dim3 grid(8 * p.tiles_per_xcd, ns);
+    p.trace = (g_gemm_trace && (size_t)grid.x * grid.y <= g_gemm_trace_slots) ? g_gemm_trace : nullptr;
     GemmCfg cc = c;
     if (!getenv("MDX_GEMM_CFG")) {
         // <= 1 block per CU: LDS is not what limits residency, so spend it on a deeper DMA ring (measured +15-20 %

@@ -58,7 +58,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnParams p) {
         float s[8], q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-        for (int pix = p0 + tr; pix < p1; pix += trows) {
+        // four independent loads in flight per thread (the slab is short: latency, not bandwidth, is the cost)
+        int pix = p0 + tr;
+        for (; pix + 3 * trows < p1; pix += 4 * trows) {
+            f16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = gn_load(p, b, pix + u * trows, col0 + tc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[u][e];
+                    s[e] += f;
+                    q[e] += f * f;
+                }
+        }
+        for (; pix < p1; pix += trows) {
             const f16x8 v = gn_load(p, b, pix, col0 + tc);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -173,7 +188,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
         sc[e] = ss[(tc * 8 + e) * 2];
         sh[e] = ss[(tc * 8 + e) * 2 + 1];
     }
-    for (int pix = p0 + tr; pix < p1; pix += trows) {
+    int pix = p0 + tr;
+    for (; pix + 3 * trows < p1; pix += 4 * trows) {
+        f16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = gn_load(p, b, pix + u * trows, col0 + tc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[u][e] * sc[e] + sh[e];
+                if (p.silu) f = silu_f(f);
+                o[e] = (f16)f;
+            }
+            *reinterpret_cast<f16x8*>(p.y + ((size_t)b * p.HW + pix + u * trows) * p.C + (col0 + tc) * 8) = o;
+        }
+    }
+    for (; pix < p1; pix += trows) {
         const f16x8 v = gn_load(p, b, pix, col0 + tc);
         f16x8 o;
 #pragma unroll

@@ -149,6 +149,42 @@ def test_gemm_dense(ops, M, N, K, bias, res, splitk):
     check(f"gemm_dense_M{M}_N{N}_K{K}_b{int(bias)}_r{int(res)}_s{splitk}", out, ref, rel_l2=1e-3)
 
 
+def test_gemm_splitk_workspace_reuse(ops):
+    """ONE split-K workspace serves different problems launched back to back and repeatedly (the planned executor and
+    hipGraph replay rely on this), and the slab reduction order is fixed, so results are bit-identical run to run."""
+    rng = np.random.RandomState(77)
+    probs = []
+    for (M, N, K, sk) in [(256, 320, 1280, 5), (512, 128, 2560, 8), (100, 72, 640, 3)]:
+        a = h16(rng.standard_normal((M, K)))
+        w = h16(rng.standard_normal((N, K)) / math.sqrt(K))
+        bv = rng.standard_normal(N).astype(np.float32)
+        ref = torch.tensor(a).float() @ torch.tensor(w).float().T + torch.tensor(bv)
+        probs.append((dev16(a), pack_dense(w), dev32(bv), M, N, K, sk, ref))
+    need = 0
+    descs = []
+    for (a, w, bv, M, N, K, sk, ref) in probs:
+        out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        d = ops.make_gemm_desc(a, w, N, M, 1, 1, K, out, N, bias=bv, splitk=sk)
+        need = max(need, sk * M * N * 4)
+        descs.append((d, out))
+    ws = torch.full((need // 4,), float("nan"), dtype=torch.float32, device=DEV)   # stale garbage must not leak
+    for d, _ in descs:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    first = None
+    for rep in range(3):
+        for d, _ in descs:
+            ops.gemm_run(d)
+        torch.cuda.synchronize()
+        outs = [o.float().cpu() for _, o in descs]
+        if first is None:
+            first = outs
+        else:
+            for o, f in zip(outs, first):
+                assert torch.equal(o, f), "split-K result changed between launches (must be deterministic)"
+    for o, pr in zip(first, probs):
+        check(f"gemm_splitk_reuse_M{pr[3]}", o, pr[7], rel_l2=1e-3)
+
+
 def test_gemm_two_source_1x1(ops):
     """ResBlock skip_connection on the (virtual) concat of h and the UNet skip tensor (openaimodel.py:174,568)."""
     rng = np.random.RandomState(5)

@@ -32,6 +32,10 @@ SHAPES_B1ROW = [
     ("geglu16_1280", 256, 1, 1280, 10240, 1, 1),
     ("ff2_16_5120_1280", 256, 1, 5120, 1280, 1, 0),
     ("proj16_1280", 256, 1, 1280, 1280, 1, 0),
+    ("proj32_640", 1024, 1, 640, 640, 1, 0),
+    ("proj8_1280", 64, 1, 1280, 1280, 1, 0),
+    ("ff2_32_2560_640", 1024, 1, 2560, 640, 1, 0),
+    ("qk16_1280_2560", 256, 1, 1280, 2560, 1, 0),
 ]
 
 

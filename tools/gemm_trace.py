@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Per-block phase timeline of one mdx_gemm_f16 launch (mdx_probe_gemm_trace): where inside the kernel the time goes.
+
+    python tools/gemm_trace.py --shape M,N,K[,ksize,H,W] [--split S] [--batch B]
+
+Phases (100 MHz realtime counter, shown in us relative to the earliest block start):
+  start -> prologue DMAs issued -> first K tile landed -> main loop done -> epilogue done.
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the trace marks exist only in the diagnostics build (make -C minddiffusion_amd/csrc trace)
+os.environ.setdefault("MDX_LIBRARY", os.path.join(ROOT, "minddiffusion_amd", "libmdx_trace.so"))
+
+
+def trace_one(ops, lib, name, B, H, W, cin, cout, ks, sk, reps=3):
+    dev = torch.device("cuda:0")
+    K = ks * ks * cin
+    M = B * H * W
+    a = torch.randn(B, H * W, cin, device=dev, dtype=torch.float16)
+    out = torch.empty(M, cout, device=dev, dtype=torch.float16)
+    bias = torch.randn(cout, device=dev)
+    tbuf = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
+    res = []
+    for r in range(reps):
+        w = ops.pack_gemm_weight(torch.randn(cout, K, device=dev, dtype=torch.float16) * (K ** -0.5))  # cold weights
+        d = ops.make_gemm_desc(a, w, cout, B, H, W, cin, out, cout, bias=bias, ksize=ks, splitk=sk)
+        need = ops.gemm_workspace_bytes(d)
+        wsp = torch.empty(max(need, 16) // 4, device=dev, dtype=torch.float32)
+        d.workspace, d.workspace_bytes = wsp.data_ptr(), wsp.numel() * 4
+        flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev).fill_(r)   # push the weights out of L2/MALL
+        torch.cuda.synchronize()
+        tbuf.zero_()
+        lib.mdx_probe_gemm_trace(ctypes.c_void_p(tbuf.data_ptr()), ctypes.c_size_t(tbuf.numel() * 8))
+        ops.gemm_run(d)
+        lib.mdx_probe_gemm_trace(None, 0)
+        torch.cuda.synchronize()
+        t = tbuf.view(-1, 8).cpu()
+        t = t[t[:, 0] != 0][:, :5].double() / 100.0   # us
+        t0 = t[:, 0].min()
+        t = t - t0
+        res.append(t)
+        del flush
+    t = res[-1]
+    nb = t.shape[0]
+    names = ["start", "prologue issued", "first tile landed", "main loop done", "epilogue done"]
+    print(f"{name}: M={M} N={cout} K={K} split={sk} -> {nb} blocks; kernel span {t[:, 4].max():.2f} us")
+    for i, nm in enumerate(names):
+        c = t[:, i]
+        print(f"   {nm:18s} mean {c.mean():7.2f}  min {c.min():7.2f}  max {c.max():7.2f}")
+    d = t[:, 1:] - t[:, :-1]
+    print("   per-block phase durations (mean us): setup %.2f | first-tile wait %.2f | main loop %.2f | epilogue %.2f"
+          % tuple(d.mean(0).tolist()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--split", type=int, default=0)
+    args = ap.parse_args()
+    from minddiffusion_amd import ops, _lib
+    lib = _lib.load()
+    B = args.batch
+    shapes = [("proj16_1280", 16, 16, 1280, 1280, 1), ("proj32_640", 32, 32, 640, 640, 1),
+              ("qk64_320", 64, 64, 320, 320, 1), ("conv16_1280_1280", 16, 16, 1280, 1280, 3),
+              ("conv32_640_640", 32, 32, 640, 640, 3), ("conv64_320_320", 64, 64, 320, 320, 3),
+              ("ff2_16_5120_1280", 16, 16, 5120, 1280, 1), ("geglu32_640", 32, 32, 640, 5120, 1)]
+    for name, H, W, cin, cout, ks in shapes:
+        trace_one(ops, lib, name, B, H, W, cin, cout, ks, args.split)
+
+
+if __name__ == "__main__":
+    main()
