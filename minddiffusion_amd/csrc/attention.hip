@@ -17,6 +17,8 @@
 // (MDX_OUT_TRANSPOSED), which keeps every LDS read of this kernel wide and conflict-light.
 #include "mdx_common.h"
 
+#include <type_traits>
+
 namespace {
 
 struct AttnParams {
@@ -114,12 +116,15 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
 
     const int vswz = (lane >> 1) & 7;
     const int ntiles = (p.Nk + BKV - 1) / BKV;
-    stage_tile(0, 0);
-    __syncthreads();
-    int buf = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) stage_tile(t + 1, buf ^ 1);
-        const char* sk = smem + buf * STAGE;
+
+    // One KV tile.  BUF and MASK are compile-time so that every LDS address is (loop-invariant register + immediate)
+    // and the tail-key masking costs nothing in the full tiles.  The softmax is the VALU-bound part of this kernel at
+    // D = 64 (32 exp per lane per tile vs 16 MFMAs): raw v_exp_f32 (__builtin_amdgcn_exp2f: no denormal range fix-up,
+    // arguments below -126 flush to 0, which is exactly what a softmax weight of 2^-126 should be).
+    auto tile = [&](auto buf_c, auto mask_c, const int t) {
+        constexpr int BUF = decltype(buf_c)::value;
+        constexpr bool MASK = decltype(mask_c)::value;
+        const char* sk = smem + BUF * STAGE;
         const char* sv = sk + K_BYTES;
 
         // ---- S^T = K Q^T : two 32-key tiles
@@ -135,9 +140,8 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
                 acc_s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], acc_s[kt], 0, 0, 0);
             }
         }
-        // ---- mask keys beyond Nk (last tile only)
-        const int key0 = t * BKV;
-        if (key0 + BKV > p.Nk) {
+        if constexpr (MASK) {   // keys beyond Nk (last tile only)
+            const int key0 = t * BKV;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc_s[kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);           // finite: every tile has >= 1 valid key
-        const float alpha = exp2f((m_run - m_new) * p.scale_log2);  // first tile: exp2(-inf) = 0
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);  // first tile: exp2(-inf) = 0
         const float mb = m_new * p.scale_log2;
         float psum = 0.f;
         f16x8 pf[4];  // B fragments for the 4 16-key chunks
@@ -162,16 +166,19 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(acc_s[kt][r] * p.scale_log2 - mb);
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc_s[kt][r], p.scale_log2, -mb));
                 psum += pv;
                 pf[kt * 2 + (r >> 3)][r & 7] = (f16)pv;
             }
         l_run = l_run * alpha + psum;
+        // rescale O only when some query of this wave saw a new maximum (alpha == 1 everywhere otherwise)
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+        }
         m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
 
         // ---- O^T += V^T P^T
 #pragma unroll
@@ -187,8 +194,36 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
                 acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c], acc_o[d], 0, 0, 0);
             }
         }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    const bool ragged = (p.Nk % BKV) != 0;
+    const int nfull = ragged ? ntiles - 1 : ntiles;   // tiles that need no key masking
+
+    stage_tile(0, 0);
+    __syncthreads();
+    int t = 0;
+    for (; t + 2 <= nfull; t += 2) {
+        stage_tile(t + 1, 1);
+        tile(B0{}, std::false_type{}, t);
         __syncthreads();
-        buf ^= 1;
+        if (t + 2 < ntiles) stage_tile(t + 2, 0);
+        tile(B1{}, std::false_type{}, t + 1);
+        __syncthreads();
+    }
+    // remaining 0..2 tiles: (full)? (masked)?
+    if (t < nfull) {            // one more full tile in buffer 0
+        if (t + 1 < ntiles) stage_tile(t + 1, 1);
+        tile(B0{}, std::false_type{}, t);
+        __syncthreads();
+        ++t;
+        if (t < ntiles) {       // masked tail in buffer 1
+            tile(B1{}, std::true_type{}, t);
+            __syncthreads();
+        }
+    } else if (t < ntiles) {    // masked tail in buffer 0
+        tile(B0{}, std::true_type{}, t);
+        __syncthreads();
     }
 
     // ---- finalize: O /= l ; stage [q][d] per wave in LDS, then full-row stores
