@@ -57,19 +57,34 @@ __device__ __forceinline__ f16x4 cvt4(float a, float b, float c, float d) {
     return v;
 }
 
-// Shared fused epilogue for 8 consecutive output columns of one row (fp32 in, fp16 out).
-__device__ __forceinline__ void epilogue_store_row8(const GemmParams& p, float (&f)[8], int m, int n) {
+// Fused epilogue for 8 consecutive output columns of one row (fp32 in, fp16 out), in two halves so that callers can
+// issue the global loads (time-embedding row, residual) EARLY -- before the LDS staging barrier / the slab loads --
+// and pay their latency once, overlapped, instead of once per dependent step.
+struct Row8Extras {
+    float4 r0, r1;   // per-sample row bias
+    f16x8 res;       // residual
+};
+
+__device__ __forceinline__ Row8Extras epilogue_prefetch_row8(const GemmParams& p, int m, int n) {
+    Row8Extras x;
     if (p.rowbias) {
         const int b = m / p.HoWo;
         const float4* rb = reinterpret_cast<const float4*>(p.rowbias + (size_t)b * p.rowbias_ld + n);
-        const float4 r0 = rb[0], r1 = rb[1];
-        f[0] += r0.x; f[1] += r0.y; f[2] += r0.z; f[3] += r0.w;
-        f[4] += r1.x; f[5] += r1.y; f[6] += r1.z; f[7] += r1.w;
+        x.r0 = rb[0];
+        x.r1 = rb[1];
+    }
+    if (p.residual) x.res = *reinterpret_cast<const f16x8*>(p.residual + (size_t)m * p.residual_ld + n);
+    return x;
+}
+
+__device__ __forceinline__ void epilogue_apply_row8(const GemmParams& p, float (&f)[8], int m, int n, const Row8Extras& x) {
+    if (p.rowbias) {
+        f[0] += x.r0.x; f[1] += x.r0.y; f[2] += x.r0.z; f[3] += x.r0.w;
+        f[4] += x.r1.x; f[5] += x.r1.y; f[6] += x.r1.z; f[7] += x.r1.w;
     }
     if (p.residual) {
-        const f16x8 r = *reinterpret_cast<const f16x8*>(p.residual + (size_t)m * p.residual_ld + n);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
+        for (int e = 0; e < 8; ++e) f[e] += (float)x.res[e];
     }
     f16x8 o;
 #pragma unroll
@@ -80,6 +95,11 @@ __device__ __forceinline__ void epilogue_store_row8(const GemmParams& p, float (
         row = (size_t)b * p.out_bs + (size_t)(m - b * p.HoWo) * p.out_ld;
     }
     *reinterpret_cast<f16x8*>(p.out + row + n) = o;
+}
+
+__device__ __forceinline__ void epilogue_store_row8(const GemmParams& p, float (&f)[8], int m, int n) {
+    const Row8Extras x = epilogue_prefetch_row8(p, m, n);
+    epilogue_apply_row8(p, f, m, n, x);
 }
 
 // Diagnostics (mdx_probe_gemm_trace): block `bid` records the 100 MHz realtime counter at phase `slot`.
@@ -172,6 +192,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         // row-major store: C^T layout (col = lane&31 -> m, 4 consecutive n per register group)
         constexpr int SLD = BN + 8;
         f16* stg = reinterpret_cast<f16*>(smem);
+        // plain (non-GEGLU) store: thread -> (row r0 + pass * RPP, 8 columns at n).  Its global loads (bias, and the
+        // first pass's time-embedding row / residual) are issued BEFORE the staging barrier so that their latency
+        // overlaps the accumulator -> LDS pass; later passes prefetch one pass ahead.
+        constexpr int CPR = BN / 8;
+        constexpr int RPP = 256 / CPR;
+        const int chunk = tid % CPR, r0 = tid / CPR;
+        const int n = n0 + chunk * 8;
+        const bool plain = p.epilogue != MDX_EPI_GEGLU;
+        float bb[8];
+        Row8Extras xa;
+        if (plain) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bb[e] = (p.bias && n < p.N) ? p.bias[n + e] : 0.f;
+            const int m = rm(r0);
+            if (m < p.M && n < p.N) xa = epilogue_prefetch_row8(p, m, n);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -213,17 +249,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 }
             }
         } else {
-            constexpr int CPR = BN / 8;
-            constexpr int RPP = 256 / CPR;
-            const int chunk = tid % CPR, r0 = tid / CPR;
-            const int n = n0 + chunk * 8;
-            float bb[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bb[e] = (p.bias && n < p.N) ? p.bias[n + e] : 0.f;
 #pragma unroll
             for (int pass = 0; pass < BM / RPP; ++pass) {
                 const int row = r0 + pass * RPP;
                 const int m = rm(row);
+                Row8Extras xn;
+                if (pass + 1 < BM / RPP) {
+                    const int m2 = rm(row + RPP);
+                    if (m2 < p.M && n < p.N) xn = epilogue_prefetch_row8(p, m2, n);
+                }
                 if (m < p.M && n < p.N) {
                     const f16x8 v = *reinterpret_cast<const f16x8*>(&stg[row * SLD + chunk * 8]);
                     float f[8];
@@ -233,8 +267,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] = gelu_tanh_f(f[e]);
                     }
-                    epilogue_store_row8(p, f, m, n);
+                    epilogue_apply_row8(p, f, m, n, xa);
                 }
+                xa = xn;
             }
         }
     }
@@ -691,6 +726,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int m = (int)(idx / cpr);
         const int oc = (int)(idx - (size_t)m * cpr) * 8;
+        // time-embedding row / residual first: their latency overlaps the slab loads instead of following them
+        Row8Extras xtra;
+        if (p.out_mode != MDX_OUT_TRANSPOSED) xtra = epilogue_prefetch_row8(p, m, oc);
         float f[8];
         if (geglu) {
             const int pa = (oc >> 6) * 128 + (oc & 63);
@@ -719,7 +757,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 #pragma unroll
             for (int e = 0; e < 8; ++e) p.out[((size_t)b * p.N + oc + e) * p.out_ld + tok] = (f16)f[e];
         } else {
-            epilogue_store_row8(p, f, m, oc);
+            epilogue_apply_row8(p, f, m, oc, xtra);
         }
     }
 }
