@@ -124,10 +124,12 @@ struct PatchRows {
 
 // Fused epilogue shared by the GEMM kernels.  SWAP: accumulators hold C^T (col = lane&31 -> m), staged through LDS
 // and stored row-major with bias / rowbias / residual / GEGLU / GELU; !SWAP: split-K partial slab or transposed store.
-template <int BM, int BN, bool SWAP, class RowMap>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / 64][BN / 64], char* smem,
+template <int BM, int BN, bool SWAP, int NW, class RowMap>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / (16 * NW)][BN / 64], char* smem,
                                               const RowMap rm, const int n0, const int split) {
-    constexpr int TM = BM / 64;
+    constexpr int NT = NW * 64;           // threads per block
+    constexpr int WROWS = BM / (NW / 2);  // rows of the block tile owned by one wave row (waves are (NW/2) x 2)
+    constexpr int TM = WROWS / 32;
     constexpr int TN = BN / 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -146,7 +148,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     const int n = n0 + wn * (BN / 2) + j * 32 + l31;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int m = rm(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
+                        const int m = rm(wm * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
                         if (m < p.M && n < p.N) wsz[(size_t)m * p.N + n] = acc[i][j][r];
                     }
                 }
@@ -162,14 +164,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 const int n_l = wn * (BN / 2) + j * 32 + l31;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int m_l = wm * (BM / 2) + i * 32 + 8 * g + 4 * hi;
+                    const int m_l = wm * WROWS + i * 32 + 8 * g + 4 * hi;
                     *reinterpret_cast<f16x4*>(&stg[n_l * TLD + m_l]) =
                         cvt4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
                 }
             }
         __syncthreads();
         constexpr int CPT = BM / 8;        // 16-B chunks per staged n-row
-        constexpr int RPT = 256 / CPT;     // n-rows per pass
+        constexpr int RPT = NT / CPT;      // n-rows per pass
         const int chunk = tid % CPT, r0 = tid / CPT;
         const int m = rm(chunk * 8);
 #pragma unroll
@@ -196,7 +198,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         // first pass's time-embedding row / residual) are issued BEFORE the staging barrier so that their latency
         // overlaps the accumulator -> LDS pass; later passes prefetch one pass ahead.
         constexpr int CPR = BN / 8;
-        constexpr int RPP = 256 / CPR;
+        constexpr int RPP = NT / CPR;
         const int chunk = tid % CPR, r0 = tid / CPR;
         const int n = n0 + chunk * 8;
         const bool plain = p.epilogue != MDX_EPI_GEGLU;
@@ -212,7 +214,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int m_l = wm * (BM / 2) + i * 32 + l31;
+                const int m_l = wm * WROWS + i * 32 + l31;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n_l = wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
@@ -234,8 +236,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     bg[e] = (p.bias && pn < p.N) ? p.bias[pn + 64 + e] : 0.f;
                 }
 #pragma unroll
-                for (int pass = 0; pass < BM / 32; ++pass) {
-                    const int row = r0 + pass * 32;
+                for (int pass = 0; pass < BM / (NT / 8); ++pass) {
+                    const int row = r0 + pass * (NT / 8);
                     const int m = rm(row);
                     if (m < p.M && pn < p.N) {
                         const f16x8 va = *reinterpret_cast<const f16x8*>(&stg[row * SLD + chunk * 8]);
@@ -275,10 +277,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     }
 }
 
-template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
-    constexpr int TM = BM / 64;             // 32-row MFMA tiles per wave along m (waves are 2 x 2)
+template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const GemmParams p) {
+    // NW = 4 (2 x 2 waves) or 8 (4 x 2 waves, BM = 128 only).  The 8-wave form is for grids of at most one block per
+    // CU: a wave's K-step is a serial chain (wait -> barrier -> DMA issue -> ds_read -> MFMA), so a lone 4-wave block
+    // leaves each SIMD idle for most of it; eight waves halve every wave's share of the DMA issue and MFMAs and give
+    // each SIMD a second wave to overlap with.
+    constexpr int WROWS = BM / (NW / 2);    // rows per wave row
+    constexpr int TM = WROWS / 32;          // 32-row MFMA tiles per wave along m
     constexpr int TN = BN / 64;             // 32-wide MFMA tiles per wave along n
+    static_assert(TM >= 1, "tile too short for this many waves");
     constexpr int ROWB = BK * 2;            // bytes per LDS row (128 | 64)
     constexpr int CPRW = BK / 8;            // 16-B chunks per row (8 | 4)
     constexpr int RPI = 64 / CPRW;          // rows covered by one wave-wide DMA instruction (8 | 16)
@@ -287,9 +295,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     constexpr int A_BYTES = BM * ROWB;
     constexpr int B_BYTES = BN * ROWB;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int AJ = BM / RPI / 4;        // A-tile DMA instructions per wave
-    constexpr int BJ = BN / RPI / 4;        // B-tile DMA instructions per wave
-    static_assert(AJ >= 1 && BJ >= 1, "tile too small for 4 loader waves");
+    constexpr int AJ = BM / RPI / NW;       // A-tile DMA instructions per wave
+    constexpr int BJ = BN / RPI / NW;       // B-tile DMA instructions per wave
+    static_assert(AJ >= 1 && BJ >= 1, "tile too small for this many loader waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -451,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 
     // fragment read offsets: row*ROWB + ((2s+hi) ^ key(row))*16; key(row) depends only on the lane for all our row bases
     const int swz = (l31 / RP256) % CPRW;
-    const int a_row_off = (wm * (BM / 2) + l31) * ROWB;
+    const int a_row_off = (wm * WROWS + l31) * ROWB;
     const int b_row_off = A_BYTES + (wn * (BN / 2) + l31) * ROWB;
 
     // ---- main loop: NS-stage LDS ring.  DMAs of the next NS-1 K tiles stay in flight ACROSS the per-tile barrier
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
     __syncthreads();  // all waves done with the ring before the epilogue reuses it
     trace_mark(p, 3);
-    gemm_epilogue<BM, BN, SWAP>(p, acc, smem, LinearRows{m0}, n0, split);
+    gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{m0}, n0, split);
     trace_mark(p, 4);
 }
 
@@ -529,16 +537,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 // LDS: halo[2][192 rows][128 B] (double buffered across chunks; same XOR swizzle keyed by the halo row) followed by an
 // NSB-stage ring of weight tiles.  The next chunk's halo is fetched one DMA instruction per wave per tap during
 // taps 0..5 of the current chunk, so the DMA stream stays even.
-template <int BN, int NSB, bool SWAP>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p) {
-    constexpr int BM = 128;
-    constexpr int TM = 2;
+//
+// BM = 128: 8 x 16 patch, 4 waves (2 blocks per CU).  BM = 256: 16 x 16 patch, 8 waves (one block per CU): the halo grows
+// 180 -> 324 rows for twice the pixels and every weight tile is shared by twice as many rows, so the DMA bytes per MAC --
+// what bounds this kernel (about 60 GB/s per CU, 6 TB/s chip-wide through buffer_load..lds) -- drop by another 45 %.
+template <int BM, int BN, int NSB, bool SWAP>
+__global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel(const GemmParams p) {
+    constexpr int NW = BM / 32;              // waves: (NW/2) x 2, each 64 patch pixels x BN/2 channels
+    constexpr int PH = BM / 16;              // patch rows (8 | 16); patch columns are always 16
+    constexpr int WROWS = BM / (NW / 2);     // patch pixels per wave row (64)
+    constexpr int TM = WROWS / 32;
     constexpr int TN = BN / 64;
-    constexpr int HALO_ROWS = 192;           // 180 used
-    constexpr int HALO_BYTES = HALO_ROWS * 128;
-    constexpr int HJ = HALO_ROWS / 8 / 4;    // halo DMA instructions per wave per chunk (6)
+    constexpr int HROWS = (PH + 2) * 18;     // halo pixels (180 | 324)
+    constexpr int HINST = (HROWS + 7) / 8;   // halo DMA instructions per chunk (23 | 41)
+    constexpr int HALO_BYTES = HINST * 1024;
+    constexpr int HJ = (HINST + NW - 1) / NW;   // ... per wave (6 | 6)
     constexpr int B_BYTES = BN * 128;
-    constexpr int BJ = BN / 8 / 4;
+    constexpr int BJ = BN / 8 / NW;
+    static_assert(BJ >= 1, "weight tile too small for this many loader waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -560,10 +576,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p
     }
     trace_mark(p, 0);
     const int n0 = tile_n * BN;
-    const int pw = p.W >> 4, ph = p.H >> 3;
+    const int pw = p.W >> 4, ph = p.H / PH;
     const int pb = tile_m / (ph * pw);
     const int prem = tile_m - pb * (ph * pw);
-    const int py0 = (prem / pw) * 8, px0 = (prem % pw) * 16;
+    const int py0 = (prem / pw) * PH, px0 = (prem % pw) * 16;
     const int split = blockIdx.y;
     const int kt_begin = split * p.ktiles_per_split;            // multiples of 9 (host guarantees chunk-aligned splits)
     const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
@@ -573,7 +589,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a, p.a_bytes);
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
 
-    // halo loader: DMA instruction q of this wave covers halo rows (wave*HJ + q)*8 .. +7, lane -> row + lane/8
+    // halo loader: DMA instruction q of this wave covers halo rows (wave*HJ + q)*8 .. +7, lane -> row + lane/8.
+    // Swizzle: physical chunk = logical chunk ^ ((halo column >> 1) & 7).  A ds_read_b128 lane group reads 16 pixels
+    // that span two patch rows (halo rows 18 apart) but 16 CONSECUTIVE columns, so keying on the column (not on the
+    // linear halo row) puts them on 16 distinct 16-B slots of the 256-B bank row: conflict-free.
     const int lrow = lane >> 3, lchk = lane & 7;
     unsigned hal_off[HJ];
     const unsigned row_bytes = (unsigned)p.cin * 2;
@@ -582,8 +601,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p
         const int hp = (wave * HJ + q) * 8 + lrow;
         const int hr = hp / 18, hc = hp - hr * 18;
         const int y = py0 - 1 + hr, x = px0 - 1 + hc;
-        const bool ok = hp < 180 && y >= 0 && y < p.H && x >= 0 && x < p.W;
-        hal_off[q] = ok ? (unsigned)((pb * p.H + y) * p.W + x) * row_bytes + (unsigned)((lchk ^ ((hp >> 1) & 7)) * 16)
+        const bool ok = hp < HROWS && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        hal_off[q] = ok ? (unsigned)((pb * p.H + y) * p.W + x) * row_bytes + (unsigned)((lchk ^ ((hc >> 1) & 7)) * 16)
                         : MDX_OOB;
     }
     unsigned b_off[BJ];
@@ -594,6 +613,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p
         b_off[j] = (unsigned)(((size_t)panel * p.kt64) * 8192 + ((row & 63) * 8 + lchk) * 16);
     }
     auto dma_halo = [&](int q, int chunk, int hb) {
+        if (wave * HJ + q >= HINST) return;   // (wave-uniform) the last wave's spare slots lie beyond the halo image
         const unsigned off = hal_off[q] == MDX_OOB ? MDX_OOB : hal_off[q] + (unsigned)chunk * 128u;
         dma16(rs_a, smem + hb * HALO_BYTES + (wave * HJ + q) * 1024, off);
     };
@@ -615,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p
     int hp0[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int q = wm * 64 + i * 32 + l31;
+        const int q = wm * WROWS + i * 32 + l31;
         hp0[i] = (q >> 4) * 18 + (q & 15);
     }
     const int swz_b = (l31 >> 1) & 7;
@@ -652,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p
             for (int i = 0; i < TM; ++i) {
                 const int hp = hp0[i] + dq;
                 a_row[i] = hb * HALO_BYTES + hp * 128;
-                a_key[i] = ((hp >> 1) & 7) << 4;
+                a_key[i] = ((((l31 & 15) + kx) >> 1) & 7) << 4;   // swizzle key = halo COLUMN / 2 (see the loader)
             }
             const char* sb = smem + rd * B_BYTES;
             f16x8 af[2][TM], bf[2][TN];
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const GemmParams p
     }
     __syncthreads();
     trace_mark(p, 3);
-    gemm_epilogue<BM, BN, SWAP>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split);
+    gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split);
     trace_mark(p, 4);
 }
 
@@ -856,7 +876,7 @@ GemmCfg pick_cfg(const GemmParams& p) {
     return c;
 }
 
-bool halo_eligible(const GemmParams& p);
+bool halo_eligible(const GemmParams& p, int bm);
 
 // Tile height and split-K factor from a cost model fitted to the B=2 micro-benchmarks
 // (profiles/r01_gemm_auto_tiling.txt, tools/gemm_trace.py), in microseconds:
@@ -866,28 +886,33 @@ bool halo_eligible(const GemmParams& p);
 //                 blocks, 1.15 x rounds of 512 beyond); never less than streaming the cold operands once from HBM;
 //   split-K     = 3.5 (the extra reduce launch) + 0.3 x splits x slab MB (slab write + re-read);
 // fixed per-launch costs are the same for every candidate and drop out.  Splits keep >= 4 K tiles (HALO convs: whole
-// 64-channel chunks).  The 64-row tile is only a candidate for the generic kernel (HALO patches are 128 pixels).
+// 64-channel chunks).  The 64-row tile is only a candidate for the generic kernel, the 256-row tile only for HALO.
 struct Tiling {
     int bm, ns;
 };
 
 Tiling choose_tiling(const GemmParams& p, int bn, int forced_ns) {
     static const char* envbm = getenv("MDX_GEMM_BM");
-    const bool halo_ok = halo_eligible(p);
     const int kt = (p.K + 63) / 64;
     const int chunks = p.cin / 64;
     const double slab_mb = (double)p.M * p.N * 4.0 / 1048576.0;
     const double unique_mb = ((double)p.N * p.K + (double)p.M * p.cin) * 2.0 / 1048576.0;
     Tiling best{128, 1};
     double best_cost = 1e30;
-    for (int bm = 128; bm >= 64; bm -= 64) {
+    static const int order[3] = {128, 256, 64};   // increasing launch complexity (see the hysteresis below)
+    for (int oi = 0; oi < 3; ++oi) {
+        const int bm = order[oi];
         if (envbm && atoi(envbm) != bm) continue;
-        const bool halo = halo_ok && bm == 128;
-        if (bm == 64 && halo_ok && !envbm) continue;
+        const bool halo = bm >= 128 && halo_eligible(p, bm);
+        // 256-row tiles exist for the HALO kernel only and are opt-in (MDX_GEMM_BM=256): measured on MI355X they move
+        // 45 % fewer DMA bytes per MAC yet run no faster than two co-resident 128-row blocks (profiles/
+        // r01_halo256_ab.txt) -- the K-step's barrier/issue structure, not the DMA rate, is what bounds this kernel
+        if (bm == 256 && (!halo || !envbm)) continue;
+        if (bm == 64 && halo_eligible(p, 128) && !envbm) continue;  // HALO beats the generic kernel on every conv
         const int tiles = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
         // us per K-tile step of one block running alone on its CU (tools/gemm_trace.py): fewer DMA instructions and
         // MFMAs per step for the smaller tiles and for the HALO kernel (one activation DMA per 9 taps)
-        const double tau = (halo ? 0.60 : 0.65) * (bm == 64 ? 0.7 : 1.0) * (bn == 64 ? 0.7 : 1.0);
+        const double tau = (halo ? (bm == 256 ? 0.65 : 0.60) : 0.65) * (bm == 64 ? 0.7 : 1.0) * (bn == 64 ? 0.7 : 1.0);
         const int max_ns = forced_ns > 0 ? forced_ns : 16;
         for (int ns = forced_ns > 0 ? forced_ns : 1; ns <= max_ns; ++ns) {
             int kps, eff;
@@ -902,14 +927,14 @@ Tiling choose_tiling(const GemmParams& p, int bn, int forced_ns) {
                 eff = (kt + kps - 1) / kps;
             }
             if (forced_ns <= 0 && eff != ns) continue;   // same launch as a smaller ns
-            // up to 256 blocks run one per CU; beyond that two share a CU (their stalls overlap: only ~1.15x slower
-            // each) and the grid runs in rounds of 512 -- the last, partly filled round costs as much as a full one
+            // up to 256 blocks run one per CU.  128/64-row tiles: beyond that two share a CU (their stalls overlap:
+            // only ~1.15x slower each) and the grid runs in rounds of 512; 256-row tiles own a CU: rounds of 256.
+            // The last, partly filled round costs as much as a full one.
             const int blocks = tiles * eff;
-            const double occ = blocks <= 256 ? 1.0 : 1.15 * ((blocks + 511) / 512);
+            const double occ = blocks <= 256 ? 1.0 : (bm == 256 ? (blocks + 255) / 256 : 1.15 * ((blocks + 511) / 512));
             const double main_us = std::max(kps * tau * occ, unique_mb / 3.5);   // cold operands stream at ~3.5 TB/s
             const double cost = main_us + (eff > 1 ? 3.5 + 0.3 * eff * slab_mb : 0.0);
-            // candidates come in order of increasing launch complexity (128-row tiles first, fewer splits first):
-            // the model is only good to ~10-20 %, so a more complex one must promise a clear win
+            // the model is only good to ~10-20 %, so a more complex candidate must promise a clear win
             if (cost < 0.9 * best_cost) {
                 best_cost = cost;
                 best = Tiling{bm, ns};
@@ -919,64 +944,74 @@ Tiling choose_tiling(const GemmParams& p, int bn, int forced_ns) {
     return best;
 }
 
-template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK>
+template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK, int NW>
 void launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t ring = (size_t)NS * (BM + BN) * BK * 2;
     constexpr size_t epi = (size_t)(BM > BN ? BM : BN) * ((BM > BN ? BN : BM) + 8) * 2 + 4096;  // staged C tile
     constexpr size_t lds = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, BK, NS, SWAP, FASTK>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, BK, NS, SWAP, FASTK, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, NS, SWAP, FASTK>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, NS, SWAP, FASTK, NW>), grid, dim3(NW * 64), lds, st, p);
 }
 
-template <int BM, int BN, int BK, int NS>
+template <int BM, int BN, int BK, int NS, int NW>
 void launch_cfg(const GemmParams& p, bool swap, bool fastk, dim3 grid, hipStream_t st) {
     if (swap) {
         if (fastk)
-            launch_one<BM, BN, BK, NS, true, true>(p, grid, st);
+            launch_one<BM, BN, BK, NS, true, true, NW>(p, grid, st);
         else
-            launch_one<BM, BN, BK, NS, true, false>(p, grid, st);
+            launch_one<BM, BN, BK, NS, true, false, NW>(p, grid, st);
     } else {
         if (fastk)
-            launch_one<BM, BN, BK, NS, false, true>(p, grid, st);
+            launch_one<BM, BN, BK, NS, false, true, NW>(p, grid, st);
         else
-            launch_one<BM, BN, BK, NS, false, false>(p, grid, st);
+            launch_one<BM, BN, BK, NS, false, false, NW>(p, grid, st);
     }
 }
 
 template <int BM, int BN>
 bool launch_bn(const GemmCfg& c, const GemmParams& p, bool swap, bool fastk, dim3 grid, hipStream_t st) {
-    if (c.bk == 64 && c.ns == 2) launch_cfg<BM, BN, 64, 2>(p, swap, fastk, grid, st);
-    else if (c.bk == 64 && c.ns == 3) launch_cfg<BM, BN, 64, 3>(p, swap, fastk, grid, st);
-    else if (BM == 128 && c.bk == 64 && c.ns == 4) launch_cfg<128, BN, 64, 4>(p, swap, fastk, grid, st);
-    else if (BM == 128 && c.bk == 64 && c.ns == 5) launch_cfg<128, BN, 64, 5>(p, swap, fastk, grid, st);
+    if (c.bk == 64 && c.ns == 2) launch_cfg<BM, BN, 64, 2, 4>(p, swap, fastk, grid, st);
+    else if (c.bk == 64 && c.ns == 3) launch_cfg<BM, BN, 64, 3, 4>(p, swap, fastk, grid, st);
+    else if (BM == 128 && c.bk == 64 && c.ns == 4) launch_cfg<128, BN, 64, 4, 4>(p, swap, fastk, grid, st);
+    else if (BM == 128 && c.bk == 64 && c.ns == 5) launch_cfg<128, BN, 64, 5, 4>(p, swap, fastk, grid, st);
     else return false;
     return true;
 }
 
-template <int BN, int NSB, bool SWAP>
+template <int BM, int BN, int NSB, bool SWAP>
 void launch_halo(const GemmParams& p, dim3 grid, hipStream_t st) {
-    constexpr size_t ring = 2 * 192 * 128 + (size_t)NSB * BN * 128;
-    constexpr size_t epi = (size_t)128 * (BN + 8) * 2 + 4096;
+    constexpr size_t hinst = ((BM / 16 + 2) * 18 + 7) / 8;
+    constexpr size_t ring = 2 * hinst * 1024 + (size_t)NSB * BN * 128;
+    constexpr size_t epi = (size_t)BM * (BN + 8) * 2 + 4096;
     constexpr size_t lds = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN, NSB, SWAP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, NSB, SWAP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, NSB, SWAP>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, NSB, SWAP>), grid, dim3(BM * 2), lds, st, p);
+}
+
+template <int BM, int BN>
+void launch_halo_cfg(const GemmParams& p, int nsb, bool swap, dim3 grid, hipStream_t st) {
+    if (nsb == 3) {
+        if (swap) launch_halo<BM, BN, 3, true>(p, grid, st); else launch_halo<BM, BN, 3, false>(p, grid, st);
+    } else {
+        if (swap) launch_halo<BM, BN, 2, true>(p, grid, st); else launch_halo<BM, BN, 2, false>(p, grid, st);
+    }
 }
 
 // The HALO kernel applies to 3x3 / stride 1 / single-source convs whose image tiles into 8 x 16 patches.
-bool halo_eligible(const GemmParams& p) {
+bool halo_eligible(const GemmParams& p, int bm) {
     static const char* env = getenv("MDX_GEMM_HALO");
     if (env && atoi(env) == 0) return false;
-    return p.ksize == 3 && p.stride == 1 && !p.upsample && p.c2 == 0 && p.cin % 64 == 0 && p.H % 8 == 0 &&
+    return p.ksize == 3 && p.stride == 1 && !p.upsample && p.c2 == 0 && p.cin % 64 == 0 && p.H % (bm / 16) == 0 &&
            p.W % 16 == 0 && p.out_mode == MDX_OUT_ROWMAJOR;
 }
 
@@ -1036,7 +1071,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
             return MDX_E_WORKSPACE;
         }
     }
-    const bool halo = c.bm == 128 && halo_eligible(p);
+    const bool halo = c.bm >= 128 && halo_eligible(p, c.bm);
     p.nsplit = ns;
     if (halo) {
         // chunk-aligned splits: a split owns whole 64-channel chunks (9 K tiles each)
@@ -1068,15 +1103,15 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     const bool swap = (ns == 1) && (p.out_mode == MDX_OUT_ROWMAJOR);
     bool ok;
     if (halo) {
-        int nsb = 2;   // measured: the 2-stage weight ring (2 blocks per CU) beats 3 stages at every UNet shape
+        // 128-pixel patches: the 2-stage weight ring keeps two blocks per CU (measured better than 3 stages at every
+        // UNet shape); 256-pixel patches own the CU, so the LDS left over goes to a third stage
+        int nsb = c.bm == 256 ? 3 : 2;
         static const char* envn = getenv("MDX_HALO_NSB");
         if (envn && atoi(envn) >= 2 && atoi(envn) <= 3) nsb = atoi(envn);
-        if (bn == 128) {
-            if (nsb == 3) { if (swap) launch_halo<128, 3, true>(p, grid, st); else launch_halo<128, 3, false>(p, grid, st); }
-            else          { if (swap) launch_halo<128, 2, true>(p, grid, st); else launch_halo<128, 2, false>(p, grid, st); }
+        if (c.bm == 256) {
+            if (bn == 128) launch_halo_cfg<256, 128>(p, nsb, swap, grid, st); else launch_halo_cfg<256, 64>(p, nsb, swap, grid, st);
         } else {
-            if (nsb == 3) { if (swap) launch_halo<64, 3, true>(p, grid, st); else launch_halo<64, 3, false>(p, grid, st); }
-            else          { if (swap) launch_halo<64, 2, true>(p, grid, st); else launch_halo<64, 2, false>(p, grid, st); }
+            if (bn == 128) launch_halo_cfg<128, 128>(p, nsb, swap, grid, st); else launch_halo_cfg<128, 64>(p, nsb, swap, grid, st);
         }
         ok = true;
     } else if (cc.bm == 64)
