@@ -145,14 +145,21 @@ def cpu_baseline(n_evals=1):
     }
 
 
+PMC_FILE = "r01_i_pmc_traffic.json"
+
+
 def pmc_traffic():
-    """HBM bytes per gemm_kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
-    profiles/r01_c_pmc_traffic.json; PMC counters cannot be read live from inside this process)."""
+    """HBM-side bytes per GEMM-family launch (implicit-GEMM kernels + their split-K reduces) from the committed
+    rocprofv3 PMC passes (tools/pmc_traffic.py: FETCH_SIZE x2-corrected + WRITE_SIZE; PMC counters cannot be read
+    live from inside this process).  Returns (bytes per launch, algorithmic-bytes note) or (None, None)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")) as f:
-            return int(json.load(f)["gemm_kernel_total"]["hbm_bytes_per_launch_corrected"])
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
+            fam = json.load(f)["families"]
+        g, r = fam["gemm"], fam.get("splitk_reduce", {"launches_per_eval": 0, "read_MB_per_eval": 0, "write_MB_per_eval": 0})
+        total = (g["read_MB_per_eval"] + g["write_MB_per_eval"] + r["read_MB_per_eval"] + r["write_MB_per_eval"]) * 1e6
+        return int(total / (g["launches_per_eval"] + r["launches_per_eval"])), None
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -268,9 +275,11 @@ def main():
             tflop_per_unit = cfg["tflop_per_row"] * 2 * n_evals      # CFG doubles the rows
             roof = dominant_kernel_roofline(model, nb, h, w, ctx)
             if args.config == "sd2_512":
-                roof["traffic"] = pmc_traffic()
-                roof["traffic_note"] = ("HBM bytes per launch, rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), "
-                                        "from profiles/r01_c_pmc_traffic.json (same workload, eager)")
+                roof["traffic"] = pmc_traffic()[0]
+                roof["traffic_note"] = ("L2<->fabric bytes per GEMM-family launch (MALL hits included), rocprofv3 PMC: "
+                                        "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from profiles/" + PMC_FILE +
+                                        " (same workload, eager); algorithmic bytes per launch = (1.73 GB weights + "
+                                        "2 x 1.36 GB activations) / launches")
         else:
             tflop_per_unit = cfg["tflop_per_image"]
             roof = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
