@@ -46,6 +46,12 @@ CONFIGS = {
                     tflop_per_row=2.149, unit="latents/s", metric="768x768 txt2img latents/sec (50-step DDIM)",
                     workload="SDv2 txt2img 768x768 (96x96 latent), 50-step DDIM, CFG 7.5, 4 images per GPU "
                              "(BASELINE.json configs[3]: batch 32 over 8 GPUs)"),
+    # the same run followed by AutoencoderKL.decode (1.24 TFLOP per 512x512 image) -> images/s
+    "sd2_512_images": dict(family="ldm", unet="sd2", latent=64, sampler="ddim", steps=50, scale=9.0, batch=1,
+                           ctx_dim=1024, tflop_per_row=0.804, vae=True, vae_tflop=1.24, unit="images/s",
+                           metric="512x512 txt2img images/sec (50-step DDIM + VAE decode)",
+                           workload="SDv2 txt2img 512x512: 50-step DDIM, CFG 9.0, batch 1 per GPU, then "
+                                    "AutoencoderKL.decode to a 512x512 image (configs[1] + SURVEY 8(f) item 1)"),
     "glide_256": dict(family="glide", batch=8, scale=5.0, tflop_per_image=63.2, unit="images/s",
                       metric="Taichu-GLIDE 256x256 images/sec (60-step guided base + 27-step DDIM super-res)",
                       workload="Taichu-GLIDE 64x64 base (60 ancestral steps, CFG 5, UNet batch 2P) + 256x256 super-res "
@@ -66,6 +72,16 @@ def build_glide(device):
     sr.model.load_state_dict(synthetic_unet_params_device(sr.model.parameter_shapes(), seed=1, device=device))
     torch.cuda.synchronize()
     return dm, sr
+
+
+def build_vae(device):
+    from minddiffusion_amd.configs import SD_VAE_DDCONFIG
+    from minddiffusion_amd.ldm.models.autoencoder import AutoencoderKL
+    from minddiffusion_amd.weights import synthetic_unet_params_device
+    vae = AutoencoderKL(ddconfig=SD_VAE_DDCONFIG, embed_dim=4, device=device)
+    vae.load_state_dict(synthetic_unet_params_device(vae.parameter_shapes(), seed=3, device=device))
+    torch.cuda.synchronize()
+    return vae
 
 
 def build_model(device, cfg_name="sd2"):
@@ -188,6 +204,8 @@ def main():
         model = build_model(device, cfg["unet"])
         if args.no_graph:
             model.unet.use_graph = False
+        if cfg.get("vae"):
+            model.first_stage_model = build_vae(device)
         pipe = DiffusionPipeline(model, sampler=cfg["sampler"], device=device)
         h = w = cfg["latent"]
         # synthetic prompts: N(0,1) text embeddings [B,77,ctx] (seed 1), one unconditional row (seed 2), x_T seed 42
@@ -199,7 +217,8 @@ def main():
             x_T = torch.from_numpy(rs(42).randn(Bg, 4, h, w).astype(np.float32)).to(device)
 
         def one_step():
-            return pipe(c=c, uc=uc, x_T=x_T, H=8 * h, W=8 * w, steps=cfg["steps"], scale=cfg["scale"], eta=0.0)
+            return pipe(c=c, uc=uc, x_T=x_T, H=8 * h, W=8 * w, steps=cfg["steps"], scale=cfg["scale"], eta=0.0,
+                        decode=bool(cfg.get("vae")))
     else:
         from minddiffusion_amd.glide.main_funcs import ddim_sample_loop, gaussian_p_sample_loop
         dm, sr = build_glide(device)
@@ -272,8 +291,23 @@ def main():
             result["config"].update(ddim_steps=cfg["steps"], cfg_scale=cfg["scale"], unet_batch_per_gpu=nb,
                                     sampler=cfg["sampler"])
             n_evals = cfg["steps"] + (1 if cfg["sampler"] == "plms" else 0)
-            tflop_per_unit = cfg["tflop_per_row"] * 2 * n_evals      # CFG doubles the rows
+            tflop_per_unit = cfg["tflop_per_row"] * 2 * n_evals + cfg.get("vae_tflop", 0.0)   # CFG doubles the rows
             roof = dominant_kernel_roofline(model, nb, h, w, ctx)
+            if cfg.get("vae"):   # VAE decode alone: HIP events around AutoencoderKL.decode, median of 10 warm calls
+                zz = torch.randn(batch, 4, h, w, device=device)
+                for _ in range(2):
+                    model.first_stage_model.decode(zz)
+                evs = []
+                for _ in range(10):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    model.first_stage_model.decode(zz)
+                    e1.record()
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                vms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+                result["vae_decode_ms"] = round(vms, 3)
+                result["vae_decode_tflops"] = round(cfg["vae_tflop"] * batch / vms * 1e3, 1)
             if args.config == "sd2_512":
                 roof["traffic"] = pmc_traffic()[0]
                 roof["traffic_note"] = ("L2<->fabric bytes per GEMM-family launch (MALL hits included), rocprofv3 PMC: "

@@ -180,6 +180,15 @@ int mdx_glide_step_f32(const float* x, const void* out_c, const void* out_u, int
                        const float* coef8, int mode, float noise_scale, const float* noise, float* x_next,
                        float* pred_x0, int B, int H, int W, mdx_stream_t s);
 
+/* ---- VAE decoder attention (AutoencoderKL.decode -> Decoder.mid.attn_1, ldm/modules/diffusionmodules/model.py:151-206):
+ * one head of d = C = 512, scores materialised as in the reference: S = Q K^T and O = P V run through mdx_gemm_f16. */
+/* Re-lay a row-major fp16 ACTIVATION matrix src[rows][K] (row stride src_ld elements) as the packed B operand of
+ * mdx_gemm_f16 (the format ops.pack_gemm_weight builds for weights): dst holds ceil(rows/64)*ceil(K/64)*4096 halves. */
+int mdx_pack_b_operand_f16(const void* src, long src_ld, int rows, int K, void* dst, mdx_stream_t s);
+/* In place: x[r][0..cols) = softmax(scale * x[r][0..cols)) for fp16 scores (P.Softmax(axis=2), model.py:192-194);
+ * fp32 max / sum.  cols % 8 == 0, cols <= 16384. */
+int mdx_softmax_rows_f16(void* x, long ld, int rows, int cols, float scale, mdx_stream_t s);
+
 /* ---- probes used by tests to pin hardware layout assumptions (not on the hot path) */
 int mdx_probe_mfma_32x32x16_f16(const void* a, const void* b, float* c, mdx_stream_t s);
 /* streaming-bandwidth probe of the HBM/L2 -> LDS DMA path (mode 0) vs plain vector loads (mode 1) */

@@ -66,6 +66,8 @@ SIGNATURES = {
     "mdx_glide_superres_input_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mdx_glide_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_float, c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mdx_pack_b_operand_f16": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]),
+    "mdx_softmax_rows_f16": (c_int, [c_void_p, c_long, c_int, c_int, c_float, c_void_p]),
     "mdx_probe_mfma_32x32x16_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdx_probe_gemm_trace": (c_int, [c_void_p, c_size_t]),
     "mdx_probe_dma_stream": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

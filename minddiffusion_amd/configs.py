@@ -24,3 +24,11 @@ TINY_UNET = dict(image_size=8, in_channels=4, out_channels=4, model_channels=64,
 SMALL_WUKONG_UNET = dict(image_size=8, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[2, 1],
                          num_res_blocks=1, channel_mult=[1, 2], num_heads=8, use_spatial_transformer=True,
                          transformer_depth=1, context_dim=96, legacy=False)
+
+# first_stage_config.params.ddconfig of both YAMLs (v2-inference.yaml:46-60): the SD VAE (embed_dim 4)
+SD_VAE_DDCONFIG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                       ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+
+# small structurally identical decoder for tests (channels multiples of 64 so the HALO conv kernel is exercised)
+TINY_VAE_DDCONFIG = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=64,
+                         ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[], dropout=0.0)

@@ -293,3 +293,24 @@ def probe_mfma(a, b):
     c = torch.empty((64, 16), dtype=f32, device=a.device)
     _lib.check(_lib.load().mdx_probe_mfma_32x32x16_f16(_ptr(a), _ptr(b), _ptr(c), _stream()), "mdx_probe_mfma")
     return c
+
+
+def pack_b_operand(src2d, out=None):
+    """Row-major fp16 activation matrix [rows, K] (any row stride) -> packed B operand of mdx_gemm_f16."""
+    rows, K = src2d.shape
+    n = ((rows + 63) // 64) * ((K + 63) // 64) * 4096
+    if out is None:
+        out = torch.empty(n, dtype=f16, device=src2d.device)
+    assert out.numel() >= n and src2d.stride(1) == 1
+    _lib.check(_lib.load().mdx_pack_b_operand_f16(_ptr(src2d), src2d.stride(0), rows, K, _ptr(out), _stream()),
+               "mdx_pack_b_operand_f16")
+    return out
+
+
+def softmax_rows(x2d, scale):
+    """In place: x[r] = softmax(scale * x[r]) on fp16 scores [rows, cols]."""
+    rows, cols = x2d.shape
+    assert x2d.stride(1) == 1
+    _lib.check(_lib.load().mdx_softmax_rows_f16(_ptr(x2d), x2d.stride(0), rows, cols, float(scale), _stream()),
+               "mdx_softmax_rows_f16")
+    return x2d

@@ -195,3 +195,30 @@ def test_glide_names_structure_and_plan_on_host():
     Pu = upt._plan(2, 32, 32)
     for d in Pu.descs:
         assert lib.mdx_gemm_check(ctypes.byref(d)) == 0, lib.mdx_last_error()
+
+
+def test_vae_decoder_names_structure_and_plan_on_host():
+    """VAE decode mirror: parameter names/shapes equal the oracle's for the shipped ddconfig, and
+    the planned op list of a tiny decoder validates descriptor by descriptor (nothing is launched)."""
+    import ctypes
+    from oracle import vae as OV
+    from minddiffusion_amd import _lib
+    from minddiffusion_amd.configs import SD_VAE_DDCONFIG, TINY_VAE_DDCONFIG
+    from minddiffusion_amd.ldm.models.autoencoder import AutoencoderKL
+    full = AutoencoderKL(ddconfig=SD_VAE_DDCONFIG, embed_dim=4, device="cpu")
+    assert full.parameter_shapes() == OV.param_shapes(OV.SD_VAE, 4)
+    assert sum(int(np.prod(s)) for s in full.parameter_shapes().values()) == 49_490_199
+    dd = dict(TINY_VAE_DDCONFIG)
+    vae = AutoencoderKL(ddconfig=dd, embed_dim=4, device="cpu")
+    assert vae.parameter_shapes() == OV.param_shapes(dd, 4)
+    vae.load_state_dict(OV.init_params(dd, seed=0))
+    lib = _lib.load()
+    P = vae.decoder._plan(2, 16, 16)
+    assert P.out_hw == (32, 32) and tuple(P.out_nchw.shape) == (2, 3, 32, 32)
+    kinds = [m["kind"] for m in P.meta]
+    # conv_in + post_quant + (3 mid/2 + 2 up-level) resblocks ... : every GEMM descriptor must validate on the host
+    assert kinds.count("gemm") == len(P.descs) and len(P.descs) >= 20
+    for d in P.descs:
+        assert lib.mdx_gemm_check(ctypes.byref(d)) == 0, lib.mdx_last_error()
+    with pytest.raises(NotImplementedError):
+        vae.encode(None)

@@ -26,16 +26,21 @@ def main():
     ap.add_argument("--model", default="sd2")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
-    from bench import build_model
+    from bench import build_model, build_vae
     dev = torch.device("cuda:0")
-    model = build_model(dev, args.model)
-    net = model.unet
     B, h = args.batch, args.latent
-    P = net._plan(B, h, h)
-    ctx = torch.randn(B, 77, net.context_dim, device=dev, dtype=torch.float16)
-    net._ensure_context(P, ctx)
-    P.x_static.copy_(torch.randn(B, 4, h, h, device=dev))
-    P.t_static.fill_(501.0)
+    if args.model == "vae":     # AutoencoderKL.decode of the SD VAE
+        dec = build_vae(dev).decoder
+        P = dec._plan(B, h, h)
+        P.z_static.copy_(torch.randn(B, 4, h, h, device=dev))
+    else:
+        model = build_model(dev, args.model)
+        net = model.unet
+        P = net._plan(B, h, h)
+        ctx = torch.randn(B, 77, net.context_dim, device=dev, dtype=torch.float16)
+        net._ensure_context(P, ctx)
+        P.x_static.copy_(torch.randn(B, 4, h, h, device=dev))
+        P.t_static.fill_(501.0)
     for op in P.main:
         op()
     torch.cuda.synchronize()
@@ -58,7 +63,7 @@ def main():
         k[1] += 1
         k[2] += m["flops"]
     total = sum(best)
-    print(f"UNet eval B={B} latent={h}: sum of per-op times {total / 1e3:.3f} ms over {len(best)} ops")
+    print(f"{args.model} eval B={B} latent={h}: sum of per-op times {total / 1e3:.3f} ms over {len(best)} ops")
     for k, (t, n, f) in sorted(kinds.items(), key=lambda kv: -kv[1][0]):
         print(f"  {k:10s} {t / 1e3:8.3f} ms  {n:4d} ops  {f / 1e12:7.4f} TFLOP  {f / max(t, 1e-9) / 1e6:8.1f} TFLOP/s")
     order = sorted(range(len(best)), key=lambda i: -best[i])[: args.top]
