@@ -234,7 +234,7 @@ void gn_geometry(GnParams& p) {
     // every gn_apply block re-folds all slab partials of its groups: keep the fold short for the UNet's small tensors
     // (measured: 256 slabs cost the 64x64-latent UNet +17 % GroupNorm time) and only widen for image-sized ones
     // (VAE decoder at 256^2 / 512^2, GLIDE super-resolution), which otherwise leave 3/4 of the CUs idle
-    const int cap = p.HW >= 16384 ? GN_MAX_NBLK : 64;
+    const int cap = p.HW >= 16384 ? GN_MAX_NBLK : 64;   // keep in step with mdx_groupnorm_ws_floats
     if (nblk > cap) nblk = cap;
     const int max_by_pix = (p.HW + 3) / 4;          // at least ~4 pixels per slab
     if (nblk > max_by_pix) nblk = max_by_pix;
@@ -300,9 +300,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
 }  // namespace
 
 extern "C" size_t mdx_groupnorm_ws_floats(int B, int HW, int C, int groups) {
-    (void)HW;
     (void)C;
-    return (size_t)B * GN_MAX_NBLK * groups * 2;
+    return (size_t)B * (HW >= 16384 ? GN_MAX_NBLK : 64) * groups * 2;   // slab cap of gn_geometry
 }
 
 static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
