@@ -52,6 +52,12 @@ CONFIGS = {
                            metric="512x512 txt2img images/sec (50-step DDIM + VAE decode)",
                            workload="SDv2 txt2img 512x512: 50-step DDIM, CFG 9.0, batch 1 per GPU, then "
                                     "AutoencoderKL.decode to a 512x512 image (configs[1] + SURVEY 8(f) item 1)"),
+    # txt2img.py --dpm_solver (DPM-Solver++ 2M; S UNet evaluations at fractional timesteps)
+    "sd2_512_dpm_solver": dict(family="ldm", unet="sd2", latent=64, sampler="dpm_solver", steps=50, scale=9.0, batch=1,
+                               ctx_dim=1024, tflop_per_row=0.804, unit="latents/s",
+                               metric="512x512 txt2img latents/sec (50-step DPM-Solver++ 2M)",
+                               workload="SDv2 txt2img 512x512, DPM-Solver++ (multistep order 2, time_uniform) with the "
+                                        "CLI's default 50 steps, CFG 9.0, batch 1 per GPU (configs[1] with --dpm_solver)"),
     "glide_256": dict(family="glide", batch=8, scale=5.0, tflop_per_image=63.2, unit="images/s",
                       metric="Taichu-GLIDE 256x256 images/sec (60-step guided base + 27-step DDIM super-res)",
                       workload="Taichu-GLIDE 64x64 base (60 ancestral steps, CFG 5, UNet batch 2P) + 256x256 super-res "

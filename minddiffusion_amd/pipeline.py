@@ -25,9 +25,13 @@ class DiffusionPipeline:
         self.model = model
         self.device = torch.device(device) if device is not None else model.unet.device
         if isinstance(sampler, str):
-            if sampler not in ("ddim", "plms"):
-                raise ValueError("sampler must be 'ddim' or 'plms' (DPM-Solver++ is SURVEY 8(f) 'next')")
-            sampler = (DDIMSampler if sampler == "ddim" else PLMSSampler)(model)
+            if sampler not in ("ddim", "plms", "dpm_solver"):
+                raise ValueError("sampler must be 'ddim', 'plms' or 'dpm_solver'")
+            if sampler == "dpm_solver":
+                from .ldm.models.diffusion.dpm_solver import DPMSolverSampler
+                sampler = DPMSolverSampler(model)                      # txt2img.py --dpm_solver
+            else:
+                sampler = (DDIMSampler if sampler == "ddim" else PLMSSampler)(model)
         self.sampler = sampler
 
     def start_noise(self, batch, shape, seed):

@@ -118,6 +118,35 @@ def test_tiny_sampler_trajectory(sampler, S, scale):
     check(f"tiny_{sampler}_S{S}_scale{scale}_pred_x0", inter["pred_x0"][-1], ref_inter["pred_x0"][-1], rel_l2=2e-2)
 
 
+@pytest.mark.parametrize("S,scale", [(10, 7.5), (20, 7.5), (15, 1.0)])
+def test_tiny_dpm_solver_trajectory(S, scale):
+    """DPMSolverSampler (DPM-Solver++ 2M, time_uniform, fractional UNet timesteps, S model calls)
+    against oracle/dpm_solver.py on the same tiny UNet; S < 15 takes the lower_order_final branch."""
+    from oracle import dpm_solver as OD
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from minddiffusion_amd.ldm.models.diffusion.dpm_solver import DPMSolverSampler
+    cfg = _tiny_cfg()
+    params = O.init_params(_oracle_cfg(cfg), seed=3)
+    net = _build(cfg, params, True)
+    model = LatentDiffusion(net, linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    omodel = O.ModelOracle(O.UNetOracle(_oracle_cfg(cfg), params))
+    B, H, W, T = 2, 8, 8, 6
+    x_T = np.random.RandomState(42).randn(B, 4, H, W).astype(np.float32)
+    c = np.random.RandomState(1).randn(B, T, cfg["context_dim"]).astype(np.float32)
+    uc = np.repeat(np.random.RandomState(2).randn(1, T, cfg["context_dim"]).astype(np.float32), B, 0)
+    ref, solver = OD.sample(omodel, S, B, (4, H, W), c, x_T, unconditional_guidance_scale=scale,
+                            unconditional_conditioning=uc)
+    assert solver.nfe == S
+    calls, x0s = [], []
+    got, inter = DPMSolverSampler(model).sample(S, B, (4, H, W), conditioning=torch.tensor(c, device=DEV),
+                                                x_T=torch.tensor(x_T, device=DEV), unconditional_guidance_scale=scale,
+                                                unconditional_conditioning=torch.tensor(uc, device=DEV), verbose=False,
+                                                callback=lambda i: calls.append(i),
+                                                img_callback=lambda x0, i: x0s.append(float(x0.abs().max())))
+    assert inter is None and calls == list(range(S)) and len(x0s) == S and all(np.isfinite(x0s))
+    check(f"tiny_dpm_solver_S{S}_scale{scale}", got, ref, rel_l2=1e-2, max_rel=1e-2)
+
+
 def test_ddim_eta_runs_and_plms_rejects_eta():
     from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
     from minddiffusion_amd.ldm.models.diffusion.plms import PLMSSampler
