@@ -52,6 +52,12 @@ CONFIGS = {
                            metric="512x512 txt2img images/sec (50-step DDIM + VAE decode)",
                            workload="SDv2 txt2img 512x512: 50-step DDIM, CFG 9.0, batch 1 per GPU, then "
                                     "AutoencoderKL.decode to a 512x512 image (configs[1] + SURVEY 8(f) item 1)"),
+    # SURVEY 8(f) items 1 + 2: the whole txt2img.py body -- text encoder (synthetic token ids), DDIM-50, VAE decode
+    "sd2_512_e2e": dict(family="ldm", unet="sd2", latent=64, sampler="ddim", steps=50, scale=9.0, batch=1, ctx_dim=1024,
+                        tflop_per_row=0.804, vae=True, vae_tflop=1.24, text=True, unit="images/s",
+                        metric="512x512 txt2img images/sec (text encoder + 50-step DDIM + VAE decode)",
+                        workload="SDv2 txt2img 512x512 end to end: FrozenCLIPEmbedder_ZH on [prompt; empty prompt] token "
+                                 "ids, 50-step DDIM with CFG 9.0, AutoencoderKL.decode; batch 1 per GPU (txt2img.py:242-268)"),
     # txt2img.py --dpm_solver (DPM-Solver++ 2M; S UNet evaluations at fractional timesteps)
     "sd2_512_dpm_solver": dict(family="ldm", unet="sd2", latent=64, sampler="dpm_solver", steps=50, scale=9.0, batch=1,
                                ctx_dim=1024, tflop_per_row=0.804, unit="latents/s",
@@ -88,6 +94,30 @@ def build_vae(device):
     vae.load_state_dict(synthetic_unet_params_device(vae.parameter_shapes(), seed=3, device=device))
     torch.cuda.synchronize()
     return vae
+
+
+def build_text_encoder(device):
+    from minddiffusion_amd.ldm.modules.encoders.modules import FrozenCLIPEmbedder_ZH
+    from minddiffusion_amd.weights import synthetic_unet_params_device
+    rng = np.random.RandomState(11)
+    # the BPE vocabulary is not shipped: a deterministic stand-in tokenizer (random ids, end-token padded) feeds the
+    # real encoder; "" -> all end tokens, like the reference's empty prompt
+    def tokenizer(texts):
+        out = np.full((len(texts), 77), 49407, np.int64)
+        for i, t in enumerate(texts):
+            n = min(75, len(t.split()) * 2)
+            out[i, 0] = 49406
+            out[i, 1:1 + n] = rng.randint(0, 49406, n)
+        return out
+    enc = FrozenCLIPEmbedder_ZH(tokenizer=tokenizer, device=device)
+    shapes = enc.parameter_shapes()
+    params = synthetic_unet_params_device(shapes, seed=5, device=device)
+    for k in params:   # tables: O(0.5) entries so that the first LayerNorm sees a realistic signal
+        if k.endswith("embedding_table") or k.endswith("positional_embedding"):
+            params[k] = torch.randn(shapes[k], device=device) * 0.5
+    enc.load_state_dict(params)
+    torch.cuda.synchronize()
+    return enc
 
 
 def build_model(device, cfg_name="sd2"):
@@ -212,6 +242,8 @@ def main():
             model.unet.use_graph = False
         if cfg.get("vae"):
             model.first_stage_model = build_vae(device)
+        if cfg.get("text"):
+            model.cond_stage_model = build_text_encoder(device)
         pipe = DiffusionPipeline(model, sampler=cfg["sampler"], device=device)
         h = w = cfg["latent"]
         # synthetic prompts: N(0,1) text embeddings [B,77,ctx] (seed 1), one unconditional row (seed 2), x_T seed 42
@@ -222,7 +254,12 @@ def main():
             uc = torch.from_numpy(rs(2).randn(1, 77, cfg["ctx_dim"]).astype(np.float32)).to(device, torch.float16)
             x_T = torch.from_numpy(rs(42).randn(Bg, 4, h, w).astype(np.float32)).to(device)
 
+        prompts = ["a photograph of an astronaut riding a horse"] * Bg
+
         def one_step():
+            if cfg.get("text"):     # rank 0 encodes [prompts; empty prompts]; the pipeline broadcasts the embeddings
+                return pipe(prompts=prompts, x_T=x_T, H=8 * h, W=8 * w, steps=cfg["steps"], scale=cfg["scale"], eta=0.0,
+                            decode=True)
             return pipe(c=c, uc=uc, x_T=x_T, H=8 * h, W=8 * w, steps=cfg["steps"], scale=cfg["scale"], eta=0.0,
                         decode=bool(cfg.get("vae")))
     else:
@@ -312,6 +349,16 @@ def main():
                     evs.append((e0, e1))
                 torch.cuda.synchronize()
                 vms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+                if cfg.get("text"):
+                    evs = []
+                    for _ in range(12):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        model.get_learned_conditioning(prompts)
+                        e1.record()
+                        evs.append((e0, e1))
+                    torch.cuda.synchronize()
+                    result["text_encode_ms"] = round(float(np.median([a.elapsed_time(b) for a, b in evs[2:]])), 3)
                 result["vae_decode_ms"] = round(vms, 3)
                 result["vae_decode_tflops"] = round(cfg["vae_tflop"] * batch / vms * 1e3, 1)
             if args.config == "sd2_512":

@@ -107,7 +107,8 @@ typedef struct mdx_gemm_desc {
 #define MDX_EPI_NONE 0
 #define MDX_EPI_GEGLU 1 /* out[m][j] = a * gelu_tanh(g); packed so that each 128-wide N tile = 64 'a' | 64 'gate' cols
                            (attention.py:41-51) */
-#define MDX_EPI_GELU 2  /* out = gelu_tanh(acc + bias)  (GLIDE text-transformer MLP, xf.py:52-59) */
+#define MDX_EPI_GELU 2  /* out = gelu_tanh(acc + bias)  (GLIDE text-transformer MLP, xf.py:52-59; SDv2 text encoder MLP) */
+#define MDX_EPI_QUICKGELU 3 /* out = x * sigmoid(1.702 x), x = acc + bias  (Wukong text encoder, WK text_encoder.py:67-74) */
 #define MDX_OUT_ROWMAJOR 0   /* out[m * out_ld + n] */
 #define MDX_OUT_TRANSPOSED 1 /* out[(b * N + n) * out_ld + tok]: V^T for mdx_attention_f16 */
 
@@ -179,6 +180,12 @@ int mdx_glide_superres_input_f16(const float* x, const float* low, void* out, in
 int mdx_glide_step_f32(const float* x, const void* out_c, const void* out_u, int ld, float guidance_scale,
                        const float* coef8, int mode, float noise_scale, const float* noise, float* x_next,
                        float* pred_x0, int B, int H, int W, mdx_stream_t s);
+
+/* Causal self-attention (key j visible to query i iff j <= i): the text encoder's triu(-inf) mask
+ * (ldm/modules/encoders/text_encoder.py:136-139, MultiheadAttention :43-66).  Same arguments; Nq must equal Nk. */
+int mdx_attention_causal_f16(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld, const void* vt,
+                             long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads, int D, int Nq,
+                             int Nk, float scale, mdx_stream_t s);
 
 /* ---- VAE decoder attention (AutoencoderKL.decode -> Decoder.mid.attn_1, ldm/modules/diffusionmodules/model.py:151-206):
  * one head of d = C = 512, scores materialised as in the reference: S = Q K^T and O = P V run through mdx_gemm_f16. */

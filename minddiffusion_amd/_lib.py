@@ -33,7 +33,7 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
-EPI_NONE, EPI_GEGLU, EPI_GELU = 0, 1, 2
+EPI_NONE, EPI_GEGLU, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3
 OUT_ROWMAJOR, OUT_TRANSPOSED = 0, 1
 
 # name -> (restype, argtypes); also the list the CPU test checks against include/mdx.h
@@ -52,6 +52,8 @@ SIGNATURES = {
     "mdx_gemm_workspace_bytes": (c_size_t, [ctypes.POINTER(GemmDesc)]),
     "mdx_gemm_check": (c_int, [ctypes.POINTER(GemmDesc)]),
     "mdx_attention_f16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,
+                                  c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "mdx_attention_causal_f16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,
                                   c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "mdx_timestep_embedding_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "mdx_dense_small_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

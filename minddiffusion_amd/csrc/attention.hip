@@ -31,6 +31,7 @@ struct AttnParams {
     int B, heads, Nq, Nk;
     float scale_log2;  // scale * log2(e)
     unsigned k_bytes, vt_bytes;  // per-batch extents for the buffer descriptors
+    int causal;                  // 1: key j is visible to query i only if j <= i (text encoder, text_encoder.py:136-139)
 };
 
 constexpr int BQ = 128;
@@ -140,14 +141,15 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
                 acc_s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], acc_s[kt], 0, 0, 0);
             }
         }
-        if constexpr (MASK) {   // keys beyond Nk (last tile only)
+        if constexpr (MASK) {   // keys beyond Nk (last tile) and, for causal attention, keys after this lane's query
             const int key0 = t * BKV;
+            const int kmax = p.causal ? min(p.Nk - 1, q0 + l31) : p.Nk - 1;   // last visible key of this lane's query
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= p.Nk) acc_s[kt][r] = -INFINITY;
+                    if (key > kmax) acc_s[kt][r] = -INFINITY;
                 }
         }
         // ---- online softmax (one query per lane, keys split between lane and lane^32)
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc_s[kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);           // finite: every tile has >= 1 valid key
+        const float m_new = fmaxf(m_run, mx);           // finite: tile 0 always has a visible key (key 0), so m_run is
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);  // first tile: exp2(-inf) = 0
         const float mb = m_new * p.scale_log2;
         float psum = 0.f;
@@ -198,8 +200,11 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
     const bool ragged = (p.Nk % BKV) != 0;
-    const int nfull = ragged ? ntiles - 1 : ntiles;   // tiles that need no key masking
+    int ntl = ntiles;
+    if (p.causal) ntl = min(ntiles, (blockIdx.x * BQ + BQ - 1) / BKV + 1);   // tiles wholly in the future are skipped
+    const int nfull = p.causal ? 0 : (ragged ? ntl - 1 : ntl);                 // leading tiles that need no masking
 
+    // tile t lives in LDS buffer t & 1; tile t + 1 is staged while tile t is computed
     stage_tile(0, 0);
     __syncthreads();
     int t = 0;
@@ -207,22 +212,18 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         stage_tile(t + 1, 1);
         tile(B0{}, std::false_type{}, t);
         __syncthreads();
-        if (t + 2 < ntiles) stage_tile(t + 2, 0);
+        if (t + 2 < ntl) stage_tile(t + 2, 0);
         tile(B1{}, std::false_type{}, t + 1);
         __syncthreads();
     }
-    // remaining 0..2 tiles: (full)? (masked)?
-    if (t < nfull) {            // one more full tile in buffer 0
-        if (t + 1 < ntiles) stage_tile(t + 1, 1);
-        tile(B0{}, std::false_type{}, t);
-        __syncthreads();
-        ++t;
-        if (t < ntiles) {       // masked tail in buffer 1
-            tile(B1{}, std::true_type{}, t);
-            __syncthreads();
+    for (; t < ntl; ++t) {      // the (masked) tail: one tile for a ragged Nk, every tile for causal attention
+        if (t + 1 < ntl) stage_tile(t + 1, (t + 1) & 1);
+        const bool masked = t >= nfull;
+        if (t & 1) {
+            if (masked) tile(B1{}, std::true_type{}, t); else tile(B1{}, std::false_type{}, t);
+        } else {
+            if (masked) tile(B0{}, std::true_type{}, t); else tile(B0{}, std::false_type{}, t);
         }
-    } else if (t < ntiles) {    // masked tail in buffer 0
-        tile(B0{}, std::true_type{}, t);
         __syncthreads();
     }
 
@@ -270,9 +271,9 @@ void launch_attn(const AttnParams& p, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int mdx_attention_f16(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld,
-                                 const void* vt, long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads,
-                                 int D, int Nq, int Nk, float scale, mdx_stream_t s) {
+static int attention_impl(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld, const void* vt,
+                          long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads, int D, int Nq, int Nk,
+                          float scale, int causal, mdx_stream_t s) {
     MDX_REQUIRE(q && k && vt && o, "mdx_attention_f16: null pointer");
     MDX_REQUIRE(D == 40 || D == 64 || D == 80 || D == 160, "mdx_attention_f16: head dim %d not supported (40/64/80/160)", D);
     MDX_REQUIRE(B > 0 && heads > 0 && Nq > 0 && Nk > 0, "mdx_attention_f16: bad extents");
@@ -287,6 +288,7 @@ extern "C" int mdx_attention_f16(const void* q, long q_bs, int q_ld, const void*
     p.q_ld = q_ld; p.k_ld = k_ld; p.vt_ld = vt_ld; p.o_ld = o_ld;
     p.B = B; p.heads = heads; p.Nq = Nq; p.Nk = Nk;
     p.scale_log2 = scale * 1.4426950408889634f;
+    p.causal = causal;
     const size_t kbytes = ((size_t)(Nk - 1) * k_ld + D) * 2;
     const size_t vbytes = ((size_t)(D - 1) * vt_ld + vt_ld) * 2;
     MDX_REQUIRE(kbytes <= 0x80000000ull && vbytes <= 0x80000000ull, "mdx_attention_f16: K/V extent too large");
@@ -302,4 +304,17 @@ extern "C" int mdx_attention_f16(const void* q, long q_bs, int q_ld, const void*
     }
     MDX_LAUNCH_CHECK("mdx_attention_f16");
     return MDX_OK;
+}
+
+extern "C" int mdx_attention_f16(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld,
+                                 const void* vt, long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads,
+                                 int D, int Nq, int Nk, float scale, mdx_stream_t s) {
+    return attention_impl(q, q_bs, q_ld, k, k_bs, k_ld, vt, vt_bs, vt_ld, o, o_bs, o_ld, B, heads, D, Nq, Nk, scale, 0, s);
+}
+
+extern "C" int mdx_attention_causal_f16(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld,
+                                        const void* vt, long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B,
+                                        int heads, int D, int Nq, int Nk, float scale, mdx_stream_t s) {
+    MDX_REQUIRE(Nq == Nk, "mdx_attention_causal_f16: causal self-attention needs Nq == Nk (got %d, %d)", Nq, Nk);
+    return attention_impl(q, q_bs, q_ld, k, k_bs, k_ld, vt, vt_bs, vt_ld, o, o_bs, o_ld, B, heads, D, Nq, Nk, scale, 1, s);
 }

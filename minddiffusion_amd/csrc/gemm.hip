@@ -268,6 +268,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     if (p.epilogue == MDX_EPI_GELU) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] = gelu_tanh_f(f[e]);
+                    } else if (p.epilogue == MDX_EPI_QUICKGELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = quick_gelu_f(f[e]);
                     }
                     epilogue_apply_row8(p, f, m, n, xa);
                 }
@@ -769,6 +772,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
             if (p.epilogue == MDX_EPI_GELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = gelu_tanh_f(f[e]);
+            } else if (p.epilogue == MDX_EPI_QUICKGELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = quick_gelu_f(f[e]);
             }
         }
         if (p.out_mode == MDX_OUT_TRANSPOSED) {
@@ -822,7 +828,8 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     p.K = d->ksize * d->ksize * p.cin;
     p.epilogue = d->epilogue;
     p.out_mode = d->out_mode;
-    MDX_REQUIRE(p.epilogue == MDX_EPI_NONE || p.epilogue == MDX_EPI_GEGLU || p.epilogue == MDX_EPI_GELU, "mdx_gemm_f16: bad epilogue");
+    MDX_REQUIRE(p.epilogue == MDX_EPI_NONE || p.epilogue == MDX_EPI_GEGLU || p.epilogue == MDX_EPI_GELU ||
+                    p.epilogue == MDX_EPI_QUICKGELU, "mdx_gemm_f16: bad epilogue");
     MDX_REQUIRE(p.out_mode == MDX_OUT_ROWMAJOR || p.out_mode == MDX_OUT_TRANSPOSED, "mdx_gemm_f16: bad out_mode");
     if (p.epilogue == MDX_EPI_GEGLU) {
         MDX_REQUIRE(p.N % 128 == 0, "mdx_gemm_f16: GEGLU needs N %% 128 == 0");

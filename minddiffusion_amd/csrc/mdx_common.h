@@ -39,6 +39,9 @@ void mdx_set_error(const char* fmt, ...);
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // ops.GeLU == tanh approximation: 0.5 x (1 + tanh(sqrt(2/pi)(x + 0.044715 x^3)))
+// x * sigmoid(1.702 x): CLIP's QuickGELU (wukong-huahua/ldm/modules/encoders/text_encoder.py:67-74)
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
     // tanh(u) = 1 - 2/(exp(2u)+1); stable for large |u|

@@ -32,8 +32,8 @@ class AutoencoderKL:
                                      strict=strict)
 
     def decode(self, z):
-        """autoencoder.py:65-68."""
-        return self.decoder(z)
+        """autoencoder.py:65-68.  Returns a fresh tensor (the decoder's own output buffer is reused by the next call)."""
+        return self.decoder(z).clone()
 
     def encode(self, x):
         raise NotImplementedError("AutoencoderKL.encode is not on the txt2img path (autoencoder.py:70-78)")

@@ -5,7 +5,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, EPI_NONE, EPI_GEGLU, EPI_GELU, OUT_ROWMAJOR, OUT_TRANSPOSED  # noqa: F401
+from ._lib import GemmDesc, EPI_NONE, EPI_GEGLU, EPI_GELU, EPI_QUICKGELU, OUT_ROWMAJOR, OUT_TRANSPOSED  # noqa: F401
 
 f16 = torch.float16
 f32 = torch.float32
@@ -246,12 +246,14 @@ def gemm(a, w, N, B, H, W, c1, out=None, **kw):
     return out
 
 
-def attention(q_ptr, k_ptr, vt_ptr, o_ptr, B, heads, D, Nq, Nk, scale, q_bs, q_ld, k_bs, k_ld, vt_bs, vt_ld, o_bs, o_ld):
+def attention(q_ptr, k_ptr, vt_ptr, o_ptr, B, heads, D, Nq, Nk, scale, q_bs, q_ld, k_bs, k_ld, vt_bs, vt_ld, o_bs, o_ld,
+              causal=False):
     """Raw-pointer form (q/k may be column slices of one fused projection buffer); see include/mdx.h."""
-    _lib.check(_lib.load().mdx_attention_f16(ctypes.c_void_p(q_ptr), q_bs, q_ld, ctypes.c_void_p(k_ptr), k_bs, k_ld,
-                                             ctypes.c_void_p(vt_ptr), vt_bs, vt_ld, ctypes.c_void_p(o_ptr), o_bs, o_ld,
-                                             B, heads, D, Nq, Nk, float(scale), _stream()),
-               "mdx_attention_f16")
+    lib = _lib.load()
+    fn = lib.mdx_attention_causal_f16 if causal else lib.mdx_attention_f16
+    _lib.check(fn(ctypes.c_void_p(q_ptr), q_bs, q_ld, ctypes.c_void_p(k_ptr), k_bs, k_ld, ctypes.c_void_p(vt_ptr), vt_bs,
+                  vt_ld, ctypes.c_void_p(o_ptr), o_bs, o_ld, B, heads, D, Nq, Nk, float(scale), _stream()),
+               "mdx_attention_causal_f16" if causal else "mdx_attention_f16")
 
 
 def timestep_embedding(t, dim, max_period=10000.0, out=None):

@@ -345,6 +345,42 @@ def test_attention(ops, B, heads, Nq, Nk, spike, D):
     check(f"attention_B{B}_h{heads}_q{Nq}_k{Nk}_d{D}_spike{int(spike)}", out, ref, rel_l2=2e-3, max_abs=2e-2)
 
 
+@pytest.mark.parametrize("B,heads,N,D", [(2, 2, 80, 64), (1, 3, 77, 64), (2, 1, 200, 64), (1, 2, 384, 64), (1, 8, 80, 40)])
+def test_attention_causal(ops, B, heads, N, D):
+    """mdx_attention_causal_f16: key j is visible to query i iff j <= i (text_encoder.py:136-139); N spans one tile,
+    a ragged tail and several 128-query blocks (blocks skip the key tiles that lie wholly in their future)."""
+    C = heads * D
+    rng = np.random.RandomState(N + heads + D)
+    q, k, v = (h16(rng.standard_normal((B, N, C))) for _ in range(3))
+    qt, kt, vt_ = [torch.tensor(t).float().reshape(B, N, heads, D).permute(0, 2, 1, 3) for t in (q, k, v)]
+    sc = torch.matmul(qt, kt.transpose(2, 3)) * D ** -0.5 + torch.triu(torch.full((N, N), float("-inf")), 1)
+    ref = torch.matmul(torch.softmax(sc, -1), vt_).permute(0, 2, 1, 3).reshape(B, N, C)
+    ld = (N + 7) // 8 * 8
+    vt = np.zeros((B, C, ld), np.float32)
+    vt[:, :, :N] = v.transpose(0, 2, 1)
+    qd, kd, vtd = dev16(q), dev16(k), dev16(vt)
+    out = torch.empty((B, N, C), dtype=torch.float16, device=DEV)
+    ops.attention(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), out.data_ptr(), B, heads, D, N, N, D ** -0.5,
+                  N * C, C, N * C, C, C * ld, ld, N * C, C, causal=True)
+    check(f"attention_causal_B{B}_h{heads}_N{N}_d{D}", out, ref, rel_l2=2e-3, max_abs=2e-2)
+    # row 0 attends to key 0 only
+    assert float((out[:, 0].float().cpu() - torch.tensor(v[:, 0].astype(np.float32))).abs().max()) < 2e-3
+
+
+def test_gemm_quick_gelu_epilogue(ops):
+    """MDX_EPI_QUICKGELU: x * sigmoid(1.702 x) (Wukong text encoder MLP), direct and split-K paths."""
+    rng = np.random.RandomState(5)
+    M, N, K = 160, 256, 512
+    a = h16(rng.standard_normal((M, K)))
+    w = h16(rng.standard_normal((N, K)) / math.sqrt(K) * 2)
+    bv = rng.standard_normal(N).astype(np.float32)
+    x = torch.tensor(a).float() @ torch.tensor(w).float().T + torch.tensor(bv)
+    ref = x * torch.sigmoid(1.702 * x)
+    for sk in (1, 2):
+        out = ops.gemm(dev16(a), pack_dense(w), N, 1, M, 1, K, bias=dev32(bv), epilogue=ops.EPI_QUICKGELU, splitk=sk)
+        check(f"gemm_quick_gelu_s{sk}", out, ref, rel_l2=1e-3)
+
+
 def test_attention_fused_qk_layout(ops):
     """q and k as column slices of one [M, 2C] projection buffer (how the UNet calls it)."""
     B, heads, N, D = 2, 2, 128, 64

@@ -1,0 +1,82 @@
+"""GPU parity of the text-conditioning transformer: TextEncoder / FrozenCLIPEmbedder_ZH on the HIP
+kernels vs the fp32 CPU oracle (oracle/text_encoder.py), same seeded weights and token ids.
+
+Tolerance: fp16 storage + fp32 accumulation through up to 23 residual layers vs all-fp32: rel-L2 <= 5e-3 on the final
+LayerNorm output (values are O(1))."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import check
+from oracle import text_encoder as OT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(cfg, params, graph=True):
+    from minddiffusion_amd.ldm.modules.encoders.text_encoder import TextEncoder
+    enc = TextEncoder(context_length=cfg["context_length"], vocab_size=cfg["vocab_size"], output_dim=cfg["width"],
+                      width=cfg["width"], layers=cfg["layers"], heads=cfg["heads"], act=cfg["act"], device=DEV,
+                      use_graph=graph)
+    enc.load_state_dict(params, prefix="transformer.")
+    return enc
+
+
+@pytest.mark.parametrize("act,graph", [("gelu_tanh", False), ("gelu_tanh", True), ("quick_gelu", True)])
+def test_tiny_text_encoder(act, graph):
+    cfg = dict(OT.SD2_TEXT, vocab_size=100, width=128, layers=3, heads=2, act=act)
+    params = OT.init_params(cfg, seed=1)
+    enc = _build(cfg, params, graph)
+    for B in (1, 3):
+        tok = np.random.RandomState(B).randint(0, 100, (B, 77))
+        ref = OT.encode_tokens(params, tok, cfg)
+        got = enc(tok)
+        assert tuple(got.shape) == (B, 77, 128) and got.dtype == torch.float16
+        check(f"tiny_text_encoder_{act}_graph{int(graph)}_B{B}", got, ref, rel_l2=5e-3, max_abs=5e-2)
+    # causality survives the 77 -> 80 padding: changing later tokens leaves earlier outputs bit-identical
+    tok = np.random.RandomState(9).randint(0, 100, (2, 77))
+    a = enc(tok)
+    tok2 = tok.copy()
+    tok2[:, 40:] = 7
+    b = enc(tok2)              # a fresh tensor per call: `a` must still hold the first result
+    assert torch.equal(a[:, :40], b[:, :40]) and not torch.equal(a[:, 40:], b[:, 40:])
+
+
+def test_get_learned_conditioning_through_embedder():
+    """LatentDiffusion.get_learned_conditioning -> cond_stage_model.encode(list[str]) (ddpm.py / modules.py:34-37) with an
+    injected tokenizer; without one, encode() must fail loudly."""
+    from minddiffusion_amd._lib import MdxError
+    from minddiffusion_amd.configs import SD2_LDM, TINY_UNET
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from minddiffusion_amd.ldm.modules.encoders.modules import FrozenCLIPEmbedder_ZH
+    cfg = dict(OT.SD2_TEXT, vocab_size=100, width=64, layers=2, heads=1)
+    params = OT.init_params(cfg, seed=2)
+    fake_tok = lambda texts: np.stack([np.array([(ord(ch) % 97) + 1 for ch in (t + " " * 77)[:77]]) for t in texts])
+    emb = FrozenCLIPEmbedder_ZH(tokenizer=fake_tok, device=DEV, vocab_size=100, width=64, layers=2, heads=1)
+    emb.load_state_dict(params)
+    model = LatentDiffusion(unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                                         "params": dict(TINY_UNET)}, **SD2_LDM)
+    model.cond_stage_model = emb
+    prompts = ["a photo of a cat", ""]
+    c = model.get_learned_conditioning(prompts)
+    ref = OT.encode_tokens(params, fake_tok(prompts), cfg)
+    check("get_learned_conditioning", c, ref, rel_l2=5e-3, max_abs=5e-2)
+    with pytest.raises(MdxError):
+        FrozenCLIPEmbedder_ZH(device=DEV, vocab_size=100, width=64, layers=2, heads=1).encode(["x"])
+
+
+def test_full_sd2_text_encoder():
+    """The shipped SDv2 configuration (modules.py:29: 77 tokens, vocab 49408, width 1024, 23 layers, 16 heads; 340 M
+    parameters) on a [cond; uncond] pair of prompts."""
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    cfg = dict(OT.SD2_TEXT)
+    params = OT.init_params(cfg, seed=3)
+    enc = _build(cfg, params)
+    tok = np.random.RandomState(4).randint(0, cfg["vocab_size"], (2, 77))
+    tok[1, 5:] = 49407      # a short prompt padded with the end token, like the tokenizer would
+    ref = OT.encode_tokens(params, tok, cfg)
+    got = enc(tok)
+    check("sd2_text_encoder_B2", got, ref, rel_l2=5e-3, max_abs=1e-1)
