@@ -122,11 +122,36 @@ struct PatchRows {
     __device__ __forceinline__ int operator()(int row) const { return base + (row >> 4) * W + (row & 15); }
 };
 
+// The row-major epilogue's bias columns of this thread, fetched BEFORE the K loop: biases are cold in HBM (1.7 GB of
+// weights stream through the caches between two uses), and a 1-3 us miss at the start of the epilogue was the largest
+// single item of a small GEMM's fixed cost (tools/gemm_trace.py).  [0..7] plain / GEGLU 'a' columns, [8..15] gate.
+template <int BN, bool SWAP, int NW>
+__device__ __forceinline__ void gemm_bias_prefetch(const GemmParams& p, const int n0, float (&bpre)[16]) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bpre[e] = 0.f;
+    if constexpr (SWAP) {
+        if (!p.bias) return;
+        const int tid = threadIdx.x;
+        const bool geglu = p.epilogue == MDX_EPI_GEGLU;
+        const int n = n0 + (geglu ? (tid & 7) : (tid % (BN / 8))) * 8;
+        if (n >= p.N) return;
+        const float4* b4 = reinterpret_cast<const float4*>(p.bias + n);
+        const float4 x0 = b4[0], x1 = b4[1];
+        bpre[0] = x0.x; bpre[1] = x0.y; bpre[2] = x0.z; bpre[3] = x0.w;
+        bpre[4] = x1.x; bpre[5] = x1.y; bpre[6] = x1.z; bpre[7] = x1.w;
+        if (geglu) {
+            const float4 g0 = b4[16], g1 = b4[17];
+            bpre[8] = g0.x; bpre[9] = g0.y; bpre[10] = g0.z; bpre[11] = g0.w;
+            bpre[12] = g1.x; bpre[13] = g1.y; bpre[14] = g1.z; bpre[15] = g1.w;
+        }
+    }
+}
+
 // Fused epilogue shared by the GEMM kernels.  SWAP: accumulators hold C^T (col = lane&31 -> m), staged through LDS
 // and stored row-major with bias / rowbias / residual / GEGLU / GELU; !SWAP: split-K partial slab or transposed store.
 template <int BM, int BN, bool SWAP, int NW, class RowMap>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / (16 * NW)][BN / 64], char* smem,
-                                              const RowMap rm, const int n0, const int split) {
+                                              const RowMap rm, const int n0, const int split, const float (&bpre)[16]) {
     constexpr int NT = NW * 64;           // threads per block
     constexpr int WROWS = BM / (NW / 2);  // rows of the block tile owned by one wave row (waves are (NW/2) x 2)
     constexpr int TM = WROWS / 32;
@@ -206,7 +231,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         Row8Extras xa;
         if (plain) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bb[e] = (p.bias && n < p.N) ? p.bias[n + e] : 0.f;
+            for (int e = 0; e < 8; ++e) bb[e] = bpre[e];   // fetched before the K loop (gemm_bias_prefetch)
             const int m = rm(r0);
             if (m < p.M && n < p.N) xa = epilogue_prefetch_row8(p, m, n);
         }
@@ -223,6 +248,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 }
             }
         __syncthreads();
+        trace_mark(p, 5);
         if (p.epilogue == MDX_EPI_GEGLU) {
             if constexpr (BN == 128) {
                 // tile = 64 'a' columns | 64 'gate' columns -> 64 outputs at column n0/2
@@ -232,8 +258,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 float ba[8], bg[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    ba[e] = (p.bias && pn < p.N) ? p.bias[pn + e] : 0.f;
-                    bg[e] = (p.bias && pn < p.N) ? p.bias[pn + 64 + e] : 0.f;
+                    ba[e] = bpre[e];
+                    bg[e] = bpre[8 + e];
                 }
 #pragma unroll
                 for (int pass = 0; pass < BM / (NT / 8); ++pass) {
@@ -251,31 +277,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 }
             }
         } else {
+            // one copy of the store loop per activation, selected by a (uniform) branch: left as a per-element `if` the
+            // compiler evaluates BOTH GELUs for every output and selects -- measured 1.5 us of every GEMM's epilogue
+            auto store_rows = [&](auto act) {
 #pragma unroll
-            for (int pass = 0; pass < BM / RPP; ++pass) {
-                const int row = r0 + pass * RPP;
-                const int m = rm(row);
-                Row8Extras xn;
-                if (pass + 1 < BM / RPP) {
-                    const int m2 = rm(row + RPP);
-                    if (m2 < p.M && n < p.N) xn = epilogue_prefetch_row8(p, m2, n);
-                }
-                if (m < p.M && n < p.N) {
-                    const f16x8 v = *reinterpret_cast<const f16x8*>(&stg[row * SLD + chunk * 8]);
-                    float f[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = (float)v[e] + bb[e];
-                    if (p.epilogue == MDX_EPI_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] = gelu_tanh_f(f[e]);
-                    } else if (p.epilogue == MDX_EPI_QUICKGELU) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] = quick_gelu_f(f[e]);
+                for (int pass = 0; pass < BM / RPP; ++pass) {
+                    const int row = r0 + pass * RPP;
+                    const int m = rm(row);
+                    Row8Extras xn;
+                    if (pass + 1 < BM / RPP) {
+                        const int m2 = rm(row + RPP);
+                        if (m2 < p.M && n < p.N) xn = epilogue_prefetch_row8(p, m2, n);
                     }
-                    epilogue_apply_row8(p, f, m, n, xa);
+                    if (m < p.M && n < p.N) {
+                        const f16x8 v = *reinterpret_cast<const f16x8*>(&stg[row * SLD + chunk * 8]);
+                        float f[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = act((float)v[e] + bb[e]);
+                        epilogue_apply_row8(p, f, m, n, xa);
+                    }
+                    xa = xn;
                 }
-                xa = xn;
-            }
+            };
+            const int epi = __builtin_amdgcn_readfirstlane(p.epilogue);
+            if (epi == MDX_EPI_NONE)
+                store_rows([](float x) { return x; });
+            else if (epi == MDX_EPI_GELU)
+                store_rows([](float x) { return gelu_tanh_f(x); });
+            else
+                store_rows([](float x) { return quick_gelu_f(x); });
         }
     }
 }
@@ -472,6 +502,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
     //                 done reading stage (t-1)%NS) -> issue tile t+NS-1 into stage (t-1)%NS -> compute tile t.
     constexpr int LPT = AJ + BJ;  // DMA instructions per wave per K tile
     const int nt = kt_end - kt_begin;
+    float bpre[16];
+    gemm_bias_prefetch<BN, SWAP, NW>(p, n0, bpre);
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i)
         if (i < nt) stage_tile(kt_begin + i, i);
@@ -523,7 +555,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
     }
     __syncthreads();  // all waves done with the ring before the epilogue reuses it
     trace_mark(p, 3);
-    gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{m0}, n0, split);
+    gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{m0}, n0, split, bpre);
     trace_mark(p, 4);
 }
 
@@ -644,6 +676,9 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     const int swz_b = (l31 >> 1) & 7;
     const int b_row_off = 2 * HALO_BYTES + (wn * (BN / 2) + l31) * 128;
 
+    float bpre[16];
+    gemm_bias_prefetch<BN, SWAP, NW>(p, n0, bpre);
+
     // prologue: whole halo of the first chunk + the first NSB-1 weight tiles
 #pragma unroll
     for (int q = 0; q < HJ; ++q) dma_halo(q, c_begin, 0);
@@ -710,7 +745,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     }
     __syncthreads();
     trace_mark(p, 3);
-    gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split);
+    gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split, bpre);
     trace_mark(p, 4);
 }
 

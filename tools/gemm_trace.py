@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("MDX_LIBRARY", os.path.join(ROOT, "minddiffusion_amd", "libmdx_trace.so"))
 
 
-def trace_one(ops, lib, name, B, H, W, cin, cout, ks, sk, reps=3):
+def trace_one(ops, lib, name, B, H, W, cin, cout, ks, sk, reps=3, flush_caches=True):
     dev = torch.device("cuda:0")
     K = ks * ks * cin
     M = B * H * W
@@ -34,7 +34,11 @@ def trace_one(ops, lib, name, B, H, W, cin, cout, ks, sk, reps=3):
         need = ops.gemm_workspace_bytes(d)
         wsp = torch.empty(max(need, 16) // 4, device=dev, dtype=torch.float32)
         d.workspace, d.workspace_bytes = wsp.data_ptr(), wsp.numel() * 4
-        flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev).fill_(r)   # push the weights out of L2/MALL
+        flush = None
+        if flush_caches:
+            flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev).fill_(r)   # push everything out of L2/MALL
+        else:
+            ops.gemm_run(d)                                                            # warm run: operands + output resident
         torch.cuda.synchronize()
         tbuf.zero_()
         lib.mdx_probe_gemm_trace(ctypes.c_void_p(tbuf.data_ptr()), ctypes.c_size_t(tbuf.numel() * 8))
@@ -42,9 +46,11 @@ def trace_one(ops, lib, name, B, H, W, cin, cout, ks, sk, reps=3):
         lib.mdx_probe_gemm_trace(None, 0)
         torch.cuda.synchronize()
         t = tbuf.view(-1, 8).cpu()
+        t5 = t[t[:, 0] != 0][:, 5].double() / 100.0
         t = t[t[:, 0] != 0][:, :5].double() / 100.0   # us
         t0 = t[:, 0].min()
         t = t - t0
+        stg = (t5 - t0 - t[:, 3]) if float(t5.max()) > 0 else None    # epilogue: accumulators staged in LDS (slot 5)
         res.append(t)
         del flush
     t = res[-1]
@@ -56,13 +62,14 @@ def trace_one(ops, lib, name, B, H, W, cin, cout, ks, sk, reps=3):
         print(f"   {nm:18s} mean {c.mean():7.2f}  min {c.min():7.2f}  max {c.max():7.2f}")
     d = t[:, 1:] - t[:, :-1]
     print("   per-block phase durations (mean us): setup %.2f | first-tile wait %.2f | main loop %.2f | epilogue %.2f"
-          % tuple(d.mean(0).tolist()))
+          % tuple(d.mean(0).tolist()) + ("" if stg is None else "  (of which LDS staging + barrier %.2f)" % float(stg.mean())))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--split", type=int, default=0)
+    ap.add_argument("--warm", action="store_true", help="do not flush the caches: operands and output stay resident")
     args = ap.parse_args()
     from minddiffusion_amd import ops, _lib
     lib = _lib.load()
@@ -72,7 +79,7 @@ def main():
               ("conv32_640_640", 32, 32, 640, 640, 3), ("conv64_320_320", 64, 64, 320, 320, 3),
               ("ff2_16_5120_1280", 16, 16, 5120, 1280, 1), ("geglu32_640", 32, 32, 640, 5120, 1)]
     for name, H, W, cin, cout, ks in shapes:
-        trace_one(ops, lib, name, B, H, W, cin, cout, ks, args.split)
+        trace_one(ops, lib, name, B, H, W, cin, cout, ks, args.split, flush_caches=not args.warm)
 
 
 if __name__ == "__main__":
