@@ -10,6 +10,8 @@
 // never materialised.
 #include "mdx_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int GN_MAX_C = 8192;
@@ -218,6 +220,154 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
     }
 }
 
+// Single-launch GroupNorm for the small tensors of the deep UNet levels (HW <= 256): grid (column blocks, B), 1024 threads.
+// A block owns the MINIMAL column block of whole groups and whole 16-B chunks (L chunk columns) for ALL pixels of one
+// sample, so statistics never leave the block: pass 1 accumulates {sum, sumsq} with eight independent 16-B loads in
+// flight per thread (the tensor is short -- latency, not bandwidth, is the cost), fixed-order LDS folds give mean /
+// rstd per group (deterministic), pass 2 re-reads the (L2-resident) slab, applies scale/shift (+FiLM) (+SiLU) and
+// stores.  One launch instead of gn_stats + gn_apply for ~30 of the 61 GroupNorms of a UNet evaluation.
+constexpr int GNF_THREADS = 1024;
+constexpr int GNF_FOLD = 16;
+
+__global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [trows][chs][2] partials, then the folds
+    const int b = blockIdx.y, cb = blockIdx.x;
+    const int col0 = cb * p.cw;
+    const int cols = min(p.cw, p.CC - col0);
+    const int chs = cols * 8;
+    const int tid = threadIdx.x;
+    const int trows = GNF_THREADS / cols;
+    const int tc = tid % cols, tr = tid / cols;
+    const bool active = tr < trows;
+    if (active) {
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+        int pix = tr;
+        for (; pix + 7 * trows < p.HW; pix += 8 * trows) {
+            f16x8 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = gn_load(p, b, pix + u * trows, col0 + tc);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[u][e];
+                    s[e] += f;
+                    q[e] += f * f;
+                }
+        }
+        for (; pix < p.HW; pix += trows) {
+            const f16x8 v = gn_load(p, b, pix, col0 + tc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                s[e] += f;
+                q[e] += f * f;
+            }
+        }
+        float* dst = red + ((size_t)tr * chs + tc * 8) * 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dst[e * 2] = s[e];
+            dst[e * 2 + 1] = q[e];
+        }
+    }
+    __syncthreads();
+    // fold the trows partial rows per channel in two fixed-order levels (trows -> GNF_FOLD -> 1)
+    float* f16p = red + (size_t)GNF_THREADS * 8 * 2;      // [GNF_FOLD][chs][2]
+    float* csum = f16p + (size_t)GNF_FOLD * 512 * 2;      // [chs][2]
+    for (int i = tid; i < GNF_FOLD * chs; i += GNF_THREADS) {
+        const int g16 = i / chs, c = i - g16 * chs;
+        float s = 0.f, q = 0.f;
+        for (int r = g16; r < trows; r += GNF_FOLD) {
+            s += red[((size_t)r * chs + c) * 2];
+            q += red[((size_t)r * chs + c) * 2 + 1];
+        }
+        f16p[(g16 * chs + c) * 2] = s;
+        f16p[(g16 * chs + c) * 2 + 1] = q;
+    }
+    __syncthreads();
+    for (int c = tid; c < chs; c += GNF_THREADS) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int g16 = 0; g16 < GNF_FOLD; ++g16) {
+            s += f16p[(g16 * chs + c) * 2];
+            q += f16p[(g16 * chs + c) * 2 + 1];
+        }
+        csum[c * 2] = s;
+        csum[c * 2 + 1] = q;
+    }
+    __syncthreads();
+    // per-group mean / rstd (8 lanes per group, fixed shuffle order), then per-channel scale / shift
+    float* gstat = csum + 512 * 2;                         // [groups in block][2]
+    float* ss = gstat + 64 * 2;                            // [chs][2]
+    const int ng = chs / p.cpg;
+    {
+        const int g = tid >> 3, j = tid & 7;
+        float s = 0.f, q = 0.f;
+        if (g < ng) {
+            for (int c = g * p.cpg + j; c < (g + 1) * p.cpg; c += 8) {
+                s += csum[c * 2];
+                q += csum[c * 2 + 1];
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s += __shfl_xor(s, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        if (g < ng && j == 0) {
+            const float inv = 1.0f / ((float)p.cpg * (float)p.HW);
+            const float mean = s * inv;
+            float var = q * inv - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            gstat[g * 2] = mean;
+            gstat[g * 2 + 1] = rsqrtf(var + p.eps);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < chs; c += GNF_THREADS) {
+        const int g = c / p.cpg;
+        float a = p.gamma[col0 * 8 + c] * gstat[g * 2 + 1];
+        float sh = p.beta[col0 * 8 + c] - gstat[g * 2] * a;
+        if (p.scale) {   // (x_hat*gamma + beta) * (1 + scale) + shift
+            const float m1 = 1.0f + p.scale[(size_t)b * p.mod_ld + col0 * 8 + c];
+            a *= m1;
+            sh = sh * m1 + p.shift[(size_t)b * p.mod_ld + col0 * 8 + c];
+        }
+        ss[c * 2] = a;
+        ss[c * 2 + 1] = sh;
+    }
+    __syncthreads();
+    if (!active) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = ss[(tc * 8 + e) * 2];
+        sh[e] = ss[(tc * 8 + e) * 2 + 1];
+    }
+    auto apply = [&](const f16x8& v, int pix) {
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = (float)v[e] * sc[e] + sh[e];
+            if (p.silu) f = silu_f(f);
+            o[e] = (f16)f;
+        }
+        *reinterpret_cast<f16x8*>(p.y + ((size_t)b * p.HW + pix) * p.C + (col0 + tc) * 8) = o;
+    };
+    int pix = tr;
+    for (; pix + 7 * trows < p.HW; pix += 8 * trows) {
+        f16x8 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = gn_load(p, b, pix + u * trows, col0 + tc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) apply(v[u], pix + u * trows);
+    }
+    for (; pix < p.HW; pix += trows) apply(gn_load(p, b, pix, col0 + tc), pix);
+}
+
 int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
 // Fill the launch geometry: column blocks of whole groups (<= 64 chunk columns), <= 64 pixel slabs per sample,
@@ -337,9 +487,33 @@ static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const 
     p.scale = scale;
     p.shift = shift;
     p.mod_ld = mod_ld;
+    hipStream_t st = (hipStream_t)s;
+    {
+        // fused single-launch path when one block can walk all pixels of its column block quickly: <= 64 KiB per block,
+        // i.e. the 16x16 and 8x8 latent levels (measured per shape: 8.7 vs 12.4 us at HW = 256, 7.5 vs 10.7 at HW = 64;
+        // at HW >= 1024 the few, long blocks lose to the two-launch slab scheme)
+        static const char* envf = getenv("MDX_GN_FUSED");
+        const int lcm = p.cpg / gcd_i(p.cpg, 8) * 8;
+        const int L = lcm / 8;
+        if (!(envf && atoi(envf) == 0) && L <= 64 && (size_t)HW * L * 16 <= (64u << 10)) {
+            p.cw = L > p.CC ? p.CC : L;
+            p.ncb = (p.CC + p.cw - 1) / p.cw;
+            p.nblk = 1;
+            p.pix = HW;
+            constexpr size_t lds = ((size_t)GNF_THREADS * 8 * 2 + (size_t)GNF_FOLD * 512 * 2 + 512 * 2 + 64 * 2 + 512 * 2) * sizeof(float);
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(gn_fused_kernel, dim3(p.ncb, B), dim3(GNF_THREADS), lds, st, p);
+            MDX_LAUNCH_CHECK("mdx_groupnorm_f16(fused)");
+            return MDX_OK;
+        }
+    }
     gn_geometry(p);
     MDX_REQUIRE((p.cw * 8) % p.cpg == 0 || p.ncb == 1, "mdx_groupnorm_f16: internal geometry error");
-    hipStream_t st = (hipStream_t)s;
     dim3 grid(p.nblk, p.ncb, B);
     MDX_REQUIRE(p.cw <= 64, "mdx_groupnorm_f16: %d channels per group is not supported", p.cpg);
     const int cols = p.cw;
