@@ -102,6 +102,10 @@ typedef struct mdx_gemm_desc {
     size_t workspace_bytes;
     long out_bs;          /* row-major only: element stride between samples (0 = dense); lets a projection write
                              into a token sub-range of a larger [B][tokens][C] buffer (GLIDE text|image keys) */
+    void* out2;           /* split output (n_split > 0): columns [0, n_split) go row-major to `out` as usual, columns      */
+    int out2_ld;          /* [n_split, N) go TRANSPOSED to out2[(b * (N - n_split) + n - n_split) * out2_ld + tok]:      */
+    int n_split;          /* q|k and V^T of a self-attention in ONE launch (attention.py:108-112).  Multiple of 128;
+                             bias only (no rowbias / residual / epilogue / out_bs). */
 } mdx_gemm_desc;
 
 #define MDX_EPI_NONE 0

@@ -30,6 +30,7 @@ class GemmDesc(ctypes.Structure):
         ("epilogue", c_int), ("out_mode", c_int), ("splitk", c_int),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("out_bs", c_long),
+        ("out2", c_void_p), ("out2_ld", c_int), ("n_split", c_int),
     ]
 
 

@@ -32,9 +32,10 @@ struct GemmParams {
     const float* rowbias;
     const f16* residual;
     f16* out;
+    f16* out2;       // transposed destination of the columns n >= n_split (0 = none): q|k row-major + V^T in ONE launch
     float* ws;
     int c1, c2, cin;
-    int rowbias_ld, residual_ld, out_ld;
+    int rowbias_ld, residual_ld, out_ld, out2_ld, n_split;
     long out_bs;   // element stride between samples of a row-major output (0 = dense [M][out_ld])
     int B, H, W, Ho, Wo, HoWo, M, N, K;
     int ksize, stride, upsample, pad;
@@ -249,7 +250,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             }
         __syncthreads();
         trace_mark(p, 5);
-        if (p.epilogue == MDX_EPI_GEGLU) {
+        if (p.n_split && n0 >= p.n_split) {
+            // a V tile of the merged q|k|v projection: out2[(b * Nv + n - n_split) * out2_ld + tok], 8 consecutive tokens
+            // per 16-B store, gathered column-wise from the staged [m][n] tile (2-byte LDS reads; small next to a launch)
+            constexpr int CPT = BM / 8;
+            constexpr int RPT = NT / CPT;
+            const int mchunk = tid % CPT, nr0 = tid / CPT;
+            const int m = rm(mchunk * 8);
+            const int nv = p.N - p.n_split;
+#pragma unroll
+            for (int pass = 0; pass < BN / RPT; ++pass) {
+                const int nrow = nr0 + pass * RPT;
+                const int nn = n0 + nrow;
+                if (nn < p.N && m < p.M) {
+                    const float bbv = p.bias ? p.bias[nn] : 0.f;
+                    f16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (f16)((float)stg[(mchunk * 8 + e) * SLD + nrow] + bbv);
+                    const int b = m / p.HoWo;
+                    const int tok = m - b * p.HoWo;
+                    *reinterpret_cast<f16x8*>(p.out2 + ((size_t)b * nv + (nn - p.n_split)) * p.out2_ld + tok) = v;
+                }
+            }
+        } else if (p.epilogue == MDX_EPI_GEGLU) {
             if constexpr (BN == 128) {
                 // tile = 64 'a' columns | 64 'gate' columns -> 64 outputs at column n0/2
                 const int chunk = tid & 7, r0 = tid >> 3;
@@ -817,6 +840,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
             const int tok = m - b * p.HoWo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) p.out[((size_t)b * p.N + oc + e) * p.out_ld + tok] = (f16)f[e];
+        } else if (p.n_split && oc >= p.n_split) {
+            const int b = m / p.HoWo;
+            const int tok = m - b * p.HoWo;
+            const int nv = p.N - p.n_split;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p.out2[((size_t)b * nv + (oc - p.n_split + e)) * p.out2_ld + tok] = (f16)f[e];
         } else {
             epilogue_apply_row8(p, f, m, oc, xtra);
         }
@@ -839,6 +868,9 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     p.rowbias = d->rowbias;
     p.residual = (const f16*)d->residual;
     p.out = (f16*)d->out;
+    p.out2 = (f16*)d->out2;
+    p.out2_ld = d->out2_ld;
+    p.n_split = d->n_split;
     p.ws = (float*)d->workspace;
     p.c1 = d->c1;
     p.c2 = d->c2;
@@ -873,6 +905,14 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     if (p.out_mode == MDX_OUT_TRANSPOSED) {
         MDX_REQUIRE(p.HoWo % 8 == 0 && p.out_ld % 8 == 0, "mdx_gemm_f16: transposed store needs tokens %% 8 == 0");
         MDX_REQUIRE(!p.rowbias && !p.residual, "mdx_gemm_f16: transposed store takes bias only");
+    }
+    if (p.n_split) {
+        MDX_REQUIRE(p.out2 && p.n_split > 0 && p.n_split < p.N && p.n_split % 128 == 0,
+                    "mdx_gemm_f16: n_split must be a multiple of 128 inside (0, N) with out2 set");
+        MDX_REQUIRE(p.out_mode == MDX_OUT_ROWMAJOR && p.epilogue == MDX_EPI_NONE && !p.rowbias && !p.residual && !p.out_bs,
+                    "mdx_gemm_f16: the split row-major | transposed output takes bias only");
+        MDX_REQUIRE(p.HoWo % 8 == 0 && p.out2_ld % 8 == 0 && p.out2_ld >= p.HoWo,
+                    "mdx_gemm_f16: transposed part needs tokens %% 8 == 0 and out2_ld >= tokens");
     }
     if (p.rowbias) MDX_REQUIRE(p.rowbias_ld % 4 == 0, "mdx_gemm_f16: rowbias_ld must be a multiple of 4");
     if (p.residual) MDX_REQUIRE(p.residual_ld % 8 == 0, "mdx_gemm_f16: residual_ld must be a multiple of 8");

@@ -20,6 +20,8 @@ There is no CPU path: every op is a HIP kernel from libmdx.so.
 import ctypes
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -294,10 +296,14 @@ class UNetModel:
                     w[pre + n + ".w"] = self._pack_dense(wt.reshape(wt.shape[0], wt.shape[1]))  # 1x1 conv == Dense in NHWC
                     w[pre + n + ".b"] = self._dev(P[pre + n + ".bias"], f32)
                 t = pre + "transformer_blocks.0."
-                # self-attention: fused [q | k] projection, separate (transposed-store) v projection
-                w[t + "attn1.qk.w"] = self._pack_dense(torch.cat([self._dev(P[t + "attn1.to_q.weight"], f16),
-                                                                  self._dev(P[t + "attn1.to_k.weight"], f16)], 0))
-                w[t + "attn1.v.w"] = self._pack_dense(P[t + "attn1.to_v.weight"])
+                # self-attention: ONE [q | k | v] projection launch; the q|k columns are stored row-major and the v columns
+                # transposed (mdx_gemm_desc.n_split), which needs 2 * inner to be a multiple of 128
+                wq, wk, wv = (self._dev(P[t + f"attn1.to_{n}.weight"], f16) for n in "qkv")
+                if (2 * wq.shape[0]) % 128 == 0 and os.environ.get("MDX_UNET_QKV_MERGE", "1") != "0":
+                    w[t + "attn1.qkv.w"] = self._pack_dense(torch.cat([wq, wk, wv], 0))
+                else:   # fall back to a [q | k] launch and a transposed-store v launch
+                    w[t + "attn1.qk.w"] = self._pack_dense(torch.cat([wq, wk], 0))
+                    w[t + "attn1.v.w"] = self._pack_dense(wv)
                 w[t + "attn2.q.w"] = self._pack_dense(P[t + "attn2.to_q.weight"])
                 w[t + "attn2.k.w"] = self._pack_dense(P[t + "attn2.to_k.weight"])
                 w[t + "attn2.v.w"] = self._pack_dense(P[t + "attn2.to_v.weight"])
@@ -472,9 +478,14 @@ class UNetModel:
             # --- attn1 (self)
             ln = A.get((B, n, inner))
             emit(lambda ln=ln, tok=tok: ops.layernorm(tok, w[t + "norm1.g"], w[t + "norm1.b"], 1e-5, out=ln), "layernorm")
-            qk = dense(main, ln, B, n, inner, 2 * inner, w[t + "attn1.qk.w"])
             vt = A.get((B, inner, n))
-            dense(main, ln, B, n, inner, inner, w[t + "attn1.v.w"], out=vt, out_ld=n, out_mode=ops.OUT_TRANSPOSED)
+            if (t + "attn1.qkv.w") in w:
+                qk = A.get((B, n, 2 * inner))
+                add_gemm(main, a=ln, w=w[t + "attn1.qkv.w"], N=3 * inner, B=B, H=n, W=1, c1=inner, out=qk,
+                         out_ld=2 * inner, out2=vt, out2_ld=n, n_split=2 * inner)
+            else:
+                qk = dense(main, ln, B, n, inner, 2 * inner, w[t + "attn1.qk.w"])
+                dense(main, ln, B, n, inner, inner, w[t + "attn1.v.w"], out=vt, out_ld=n, out_mode=ops.OUT_TRANSPOSED)
             o = ln  # reuse: ln is dead after the projections
             emit(lambda qk=qk, vt=vt, o=o: ops.attention(
                 qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,

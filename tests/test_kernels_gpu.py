@@ -300,6 +300,32 @@ def test_gemm_transposed_store(ops, B, T, K, N, pad, splitk):
     check(f"gemm_transposed_B{B}_T{T}_K{K}_N{N}_s{splitk}", out, ref, rel_l2=1e-3)
 
 
+@pytest.mark.parametrize("B,T,C,splitk", [(2, 64, 64, 1), (2, 256, 320, 1), (1, 1024, 640, 1), (2, 64, 320, 3), (2, 128, 128, 2)])
+def test_gemm_split_rowmajor_transposed_output(ops, B, T, C, splitk):
+    """mdx_gemm_desc.n_split: [q | k] columns row-major and the v columns transposed (V^T for the attention kernel) from
+    ONE launch over the concatenated [q; k; v] weight (attention.py:108-112), direct and split-K paths."""
+    rng = np.random.RandomState(T + C + splitk)
+    a = h16(rng.standard_normal((B * T, C)))
+    w = h16(rng.standard_normal((3 * C, C)) / math.sqrt(C))
+    bv = rng.standard_normal(3 * C).astype(np.float32)
+    full = torch.tensor(a).float() @ torch.tensor(w).float().T + torch.tensor(bv)
+    qk = torch.empty((B, T, 2 * C), dtype=torch.float16, device=DEV)
+    vt = torch.zeros((B, C, T), dtype=torch.float16, device=DEV)
+    d = ops.make_gemm_desc(dev16(a), pack_dense(w), 3 * C, B, T, 1, C, qk, 2 * C, bias=dev32(bv), splitk=splitk,
+                           out2=vt, out2_ld=T, n_split=2 * C)
+    keep = d.a, d.w, d.bias
+    need = ops.gemm_workspace_bytes(d)
+    ws = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=DEV)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    # keep the operand tensors alive across the launch
+    a_d, w_d, b_d = dev16(a), pack_dense(w), dev32(bv)
+    d.a, d.w, d.bias = a_d.data_ptr(), w_d.data_ptr(), b_d.data_ptr()
+    ops.gemm_run(d)
+    torch.cuda.synchronize()
+    check(f"gemm_split_qk_B{B}_T{T}_C{C}_s{splitk}", qk.reshape(B * T, 2 * C), full[:, : 2 * C], rel_l2=1e-3)
+    check(f"gemm_split_vt_B{B}_T{T}_C{C}_s{splitk}", vt, full[:, 2 * C:].reshape(B, T, C).permute(0, 2, 1), rel_l2=1e-3)
+
+
 # --------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, heads):
     b, n, c = q.shape
