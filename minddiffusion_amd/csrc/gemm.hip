@@ -931,6 +931,8 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
 
 int pick_bn(const GemmParams& p) {
     if (p.epilogue == MDX_EPI_GEGLU) return 128;
+    static const char* envbn = getenv("MDX_GEMM_BN");
+    if (envbn && (atoi(envbn) == 64 || atoi(envbn) == 128)) return atoi(envbn);
     if (p.N % 128 == 0) return 128;
     if (p.N % 64 == 0 || p.N < 128) return 64;
     return (p.N % 128 > 64) ? 128 : 64;
