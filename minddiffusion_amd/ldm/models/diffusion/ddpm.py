@@ -24,14 +24,25 @@ class DiffusionWrapper:
                                 if isinstance(diff_model_config, dict) else diff_model_config)
         self.conditioning_key = conditioning_key
         assert self.conditioning_key in [None, "concat", "crossattn", "hybrid", "adm"]
-        if self.conditioning_key != "crossattn":
-            raise NotImplementedError("only conditioning_key='crossattn' is on the hot path "
-                                      "(hybrid/concat = inpainting, SURVEY 2.1 row 16: next)")
+        if self.conditioning_key not in ("crossattn", "hybrid"):
+            raise NotImplementedError("only 'crossattn' (txt2img) and 'hybrid' (inpainting, WK ddpm.py:368-371) are used by "
+                                      "the reference's CLIs")
 
     def construct(self, x, t, c_concat=None, c_crossattn=None):
-        return self.diffusion_model(x, t, context=c_crossattn)
+        if self.conditioning_key == "hybrid":                       # WK ddpm.py:368-371
+            if c_concat is None:
+                raise MdxError("hybrid conditioning needs c_concat (mask + masked-image latent)")
+            x = torch.cat([x, _first(c_concat).to(x.dtype)], 1)
+        return self.diffusion_model(x, t, context=_first(c_crossattn))
 
     __call__ = construct
+
+
+def _first(c):
+    """The reference wraps conditionings in lists (ddpm.py:299-304); unwrap a single tensor."""
+    while isinstance(c, (list, tuple)):
+        c = c[0]
+    return c
 
 
 class LatentDiffusion:
@@ -76,23 +87,29 @@ class LatentDiffusion:
     def unet(self):
         return self.model.diffusion_model
 
-    # ---- ddpm.py:290-306 (positional cond) and WK ddpm.py:276-278 (keywords)
-    def apply_model(self, x_noisy, t, cond=None, return_ids=False, c_concat=None, c_crossattn=None):
-        if cond is None:
-            cond = c_crossattn
+    # ---- ddpm.py:290-306 (positional cond) and WK ddpm.py:276-278 (keywords); dict = hybrid conditioning (inpaint.py:84)
+    def _split_cond(self, cond, c_concat=None, c_crossattn=None):
         if isinstance(cond, dict):
-            cond = cond.get("c_crossattn")
-        if isinstance(cond, (list, tuple)):
-            cond = cond[0]
-        if cond is None:
+            c_concat = cond.get("c_concat", c_concat)
+            c_crossattn = cond.get("c_crossattn", c_crossattn)
+        elif cond is not None:
+            c_crossattn = cond
+        c_crossattn, c_concat = _first(c_crossattn), _first(c_concat)
+        if c_crossattn is None:
             raise MdxError("apply_model: a cross-attention conditioning tensor is required")
-        if c_concat is not None:
-            raise NotImplementedError("c_concat (inpainting / hybrid conditioning) is not on the hot path yet")
-        return self.model(x_noisy, t, c_crossattn=cond)
+        if (c_concat is not None) != (self.model.conditioning_key == "hybrid"):
+            raise MdxError(f"apply_model: conditioning_key={self.model.conditioning_key!r} "
+                           f"{'needs' if c_concat is None else 'does not take'} c_concat")
+        return c_concat, c_crossattn
+
+    def apply_model(self, x_noisy, t, cond=None, return_ids=False, c_concat=None, c_crossattn=None):
+        c_concat, c_crossattn = self._split_cond(cond, c_concat, c_crossattn)
+        return self.model(x_noisy, t, c_concat=c_concat, c_crossattn=c_crossattn)
 
     def apply_model_nhwc(self, x_noisy, t, cond):
         """Fast path used by the samplers: returns the UNet's static NHWC fp16 eps buffer [B, H*W, 8]
-        (valid until the next call) so the fused sampler-step kernel can consume it without a layout pass."""
+        (valid until the next call) so the fused sampler-step kernel can consume it without a layout pass.
+        `x_noisy` already carries the c_concat channels for hybrid conditioning (the sampler writes them once)."""
         return self.unet.forward_nhwc(x_noisy, t, cond)
 
     # ---- ddpm.py:197-200
@@ -110,7 +127,24 @@ class LatentDiffusion:
                            "pass precomputed conditioning tensors [B,77,context_dim] instead")
         return self.cond_stage_model.encode(c)
 
+    def encode_first_stage(self, x):
+        raise NotImplementedError("the VAE encoder (img2img / inpainting pre-processing, WK ddpm.py:296-303) is not built; "
+                                  "pass the masked-image latent in c_concat directly")
+
     def decode_first_stage(self, z, predict_cids=False):
         if self.first_stage_model is None:
             raise MdxError("no VAE attached (first_stage_model is out of the hot-path scope)")
         return self.first_stage_model.decode(1. / self.scale_factor * z)
+
+
+class LatentInpaintDiffusion(LatentDiffusion):
+    """WK ldm/models/diffusion/ddpm.py:339-352: hybrid conditioning -- the UNet sees cat(x, mask, masked-image latent)
+    (9 channels, configs/wukong-huahua_inpaint_inference.yaml) plus the text cross-attention context."""
+
+    def __init__(self, concat_keys=("mask", "masked_image"), masked_image_key="masked_image", finetune_keys=None,
+                 *args, **kwargs):
+        kwargs.setdefault("conditioning_key", "hybrid")
+        super().__init__(*args, **kwargs)
+        self.masked_image_key = masked_image_key
+        assert self.masked_image_key in concat_keys
+        self.concat_keys = concat_keys

@@ -87,7 +87,8 @@ class _SamplerBase:
                                   score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, x_T=x_T,
                                   log_every_t=log_every_t,
                                   unconditional_guidance_scale=unconditional_guidance_scale,
-                                  unconditional_conditioning=unconditional_conditioning, verbose=verbose)
+                                  unconditional_conditioning=unconditional_conditioning, verbose=verbose,
+                                  blend_noises=kwargs.get("blend_noises"))
 
     # ---- model call: prefer the NHWC fast path of our LatentDiffusion; any object with the reference's
     #      apply_model(x, t, cond) -> NCHW eps still works (its output is re-laid-out by a HIP kernel).
@@ -103,13 +104,21 @@ class _SamplerBase:
     def plms_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None, timesteps=None,
                       quantize_denoised=False, mask=None, x0=None, img_callback=None, log_every_t=100,
                       temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
-                      unconditional_guidance_scale=1., unconditional_conditioning=None, verbose=True):
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, verbose=True, blend_noises=None):
         if ddim_use_original_steps or timesteps is not None:
             raise NotImplementedError("ddim_use_original_steps / timesteps subsets are not used by the reference's CLIs")
-        if mask is not None or x0 is not None:
-            raise NotImplementedError("mask/x0 blending is the inpainting path (WK/inpaint.py): SURVEY 8(f) 'next'")
+        if mask is not None and x0 is None:
+            raise ValueError("mask blending needs x0 (plms.py:154)")
         if quantize_denoised or score_corrector is not None or noise_dropout > 0.:
             raise NotImplementedError("quantize_x0 / score_corrector / noise_dropout are never set by the reference's CLIs")
+        # hybrid (inpainting) conditioning: {"c_concat": mask + masked-image latent, "c_crossattn": text} (inpaint.py:84-88,
+        # WK plms.py:188-205); the concat part is the same for the cond and uncond halves
+        c_cat = None
+        if isinstance(cond, dict) and "c_concat" in cond:
+            c_cat = _first_tensor(cond["c_concat"])
+            cond = cond["c_crossattn"]
+            if isinstance(unconditional_conditioning, dict):
+                unconditional_conditioning = unconditional_conditioning["c_crossattn"]
         cond = _first_tensor(cond)
         uc = _first_tensor(unconditional_conditioning) if unconditional_conditioning is not None else None
         if not (isinstance(cond, torch.Tensor) and cond.is_cuda):
@@ -127,13 +136,21 @@ class _SamplerBase:
             print(f"Running {type(self).__name__} Sampling with {total_steps} timesteps")
         scale = float(unconditional_guidance_scale)
         use_cfg = not (uc is None or scale == 1.)
-        if use_cfg:
-            c_in = torch.cat([uc.to(cond.dtype), cond], 0).contiguous()   # built ONCE (plms.py:194 rebuilds it per step)
-            x_in = torch.empty((2 * b,) + tuple(shape[1:]), device=dev, dtype=torch.float32)
-        else:
-            c_in = cond.contiguous()
-            x_in = None
         nb = 2 * b if use_cfg else b
+        c_in = torch.cat([uc.to(cond.dtype), cond], 0).contiguous() if use_cfg else cond.contiguous()   # built ONCE
+        x_in = None                                                  # (plms.py:194 rebuilds the concat every step)
+        cx = shape[1]
+        if use_cfg or c_cat is not None:
+            ccat = 0 if c_cat is None else int(c_cat.shape[1])
+            x_in = torch.empty((nb, cx + ccat) + tuple(shape[2:]), device=dev, dtype=torch.float32)
+            if c_cat is not None:                                    # DiffusionWrapper 'hybrid': cat(x, c_concat), written once
+                cc = c_cat.to(device=dev, dtype=torch.float32)
+                x_in[:b, cx:] = cc
+                if use_cfg:
+                    x_in[b:, cx:] = cc
+        if mask is not None:
+            mask = torch.as_tensor(mask).to(device=dev, dtype=torch.float32)
+            x0 = torch.as_tensor(x0).to(device=dev, dtype=torch.float32)
         # per-step timestep vectors, fp32 on the device (the UNet's sinusoid takes float timesteps, util.py:111-131)
         t_all = torch.as_tensor(np.ascontiguousarray(time_range), dtype=torch.float32, device=dev)
         t_all = t_all[:, None].expand(total_steps, nb).contiguous()
@@ -148,10 +165,14 @@ class _SamplerBase:
 
         def model_eps(x, t_row):
             if use_cfg:
-                x_in[:b].copy_(x)
-                x_in[b:].copy_(x)
+                x_in[:b, :cx].copy_(x)
+                x_in[b:, :cx].copy_(x)
                 eps, keep = self._eps_nhwc(x_in, t_row, c_in)
                 return eps[:b], eps[b:], keep           # batch = [uncond ; cond] (plms.py:192-195)
+            if x_in is not None:
+                x_in[:, :cx].copy_(x)
+                eps, keep = self._eps_nhwc(x_in, t_row, c_in)
+                return None, eps, keep
             eps, keep = self._eps_nhwc(x, t_row, c_in)
             return None, eps, keep
 
@@ -167,6 +188,14 @@ class _SamplerBase:
 
         for i, step_t in enumerate(time_range):
             index = total_steps - i - 1
+            if mask is not None:                                     # plms.py:153-157 (WK: q_sample gets explicit noise)
+                ts = torch.full((b,), int(step_t), device=dev, dtype=torch.long)
+                if blend_noises is not None:                          # tests inject the draws to compare with the oracle
+                    noise = torch.as_tensor(blend_noises[i]).to(device=dev, dtype=torch.float32)
+                else:
+                    noise = torch.randn(x0.shape, device=dev, dtype=torch.float32, generator=self.generator)
+                img_orig = self.model.q_sample(x0, ts, noise)
+                img = img_orig * mask + (1. - mask) * img
             eps_u, eps_c, _keep = model_eps(img, t_all[i])
             if not self.multistep:
                 step(img, eps_u, eps_c, index, (1., 0., 0., 0.), [], None, x_next, pred_x0)

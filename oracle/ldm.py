@@ -438,7 +438,12 @@ class ModelOracle:
         self.calls = 0
 
     def apply_model(self, x, t, cond):
+        """ddpm.py:290-306; a dict is the hybrid (inpainting) conditioning of WK ddpm.py:368-371: the UNet input is
+        cat(x, c_concat) and the context is c_crossattn."""
         self.calls += 1
+        if isinstance(cond, dict):
+            x = torch.cat([x, cond["c_concat"]], 1)
+            cond = cond["c_crossattn"]
         return self.unet(x, t, cond)
 
     def q_sample(self, x0, t, noise):
@@ -450,7 +455,7 @@ class ModelOracle:
 
 def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0.0,
            unconditional_guidance_scale=1.0, unconditional_conditioning=None, noise_fn=None,
-           temperature=1.0, log_every_t=100):
+           temperature=1.0, log_every_t=100, mask=None, x0=None, blend_noises=None):
     """PLMSSampler.sample/plms_sampling/p_sample_plms (plms.py:69-247).
 
     sampler='ddim' applies get_x_prev_and_pred_x0 (plms.py:210-228) with e'=e_t each step
@@ -465,8 +470,22 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
     b = batch_size
     img = torch.as_tensor(x_T, dtype=torch.float32)
     assert tuple(img.shape) == (b,) + tuple(shape)
+    # dict conditioning = hybrid (WK inpaint.py:84-88): {"c_concat": [B,5,h,w], "c_crossattn": [B,T,D]}; the uncond dict
+    # carries the SAME c_concat (inpaint.py:87-88), WK plms.py:188-205 concatenates key by key
+    c_cat = None
+    if isinstance(conditioning, dict):
+        c_cat = torch.as_tensor(conditioning["c_concat"], dtype=torch.float32)
+        conditioning = conditioning["c_crossattn"]
+        if isinstance(unconditional_conditioning, dict):
+            unconditional_conditioning = unconditional_conditioning["c_crossattn"]
     cond = torch.as_tensor(conditioning, dtype=torch.float32)
     uc = None if unconditional_conditioning is None else torch.as_tensor(unconditional_conditioning, dtype=torch.float32)
+    if mask is not None:
+        mask = torch.as_tensor(mask, dtype=torch.float32)
+        x0 = torch.as_tensor(x0, dtype=torch.float32)
+
+    def wrap(c, n):
+        return c if c_cat is None else {"c_concat": torch.cat([c_cat] * n, 0), "c_crossattn": c}
     time_range = np.flip(ts)
     total = len(ts)
     intermediates = {"x_inter": [img], "pred_x0": [img]}
@@ -475,10 +494,10 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
 
     def get_model_output(x, t):  # plms.py:188-203
         if uc is None or scale == 1.0:
-            return model.apply_model(x, t, cond)
+            return model.apply_model(x, t, wrap(cond, 1))
         x_in = torch.cat([x, x], 0)
         t_in = torch.cat([t, t], 0)
-        c_in = torch.cat([uc, cond], 0)
+        c_in = wrap(torch.cat([uc, cond], 0), 2)
         e_u, e_c = model.apply_model(x_in, t_in, c_in).chunk(2, dim=0)
         return e_u + scale * (e_c - e_u)
 
@@ -499,6 +518,9 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
         index = total - i - 1
         t = torch.full((b,), int(step), dtype=torch.int64)
         t_next = torch.full((b,), int(time_range[min(i + 1, total - 1)]), dtype=torch.int64)
+        if mask is not None:   # plms.py:153-157 (WK: q_sample(x0, ts, randn)); blend_noises[i] injects the draw
+            img_orig = model.q_sample(x0, t, torch.as_tensor(blend_noises[i], dtype=torch.float32))
+            img = img_orig * mask + (1.0 - mask) * img
         e_t = get_model_output(img, t)
         if sampler == "ddim":
             e_prime = e_t

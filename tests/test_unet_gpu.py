@@ -147,6 +147,46 @@ def test_tiny_dpm_solver_trajectory(S, scale):
     check(f"tiny_dpm_solver_S{S}_scale{scale}", got, ref, rel_l2=1e-2, max_rel=1e-2)
 
 
+@pytest.mark.parametrize("blend", [False, True])
+def test_tiny_inpaint_hybrid_trajectory(blend):
+    """Wukong inpainting path: LatentInpaintDiffusion with 'hybrid' conditioning -- the UNet sees
+    cat(x, mask, masked-image latent) = 9 channels (WK ddpm.py:339-371, inpaint.py:65-106) -- driven by PLMS with dict
+    conditioning; `blend` additionally exercises the mask / x0 blend of plms.py:153-157 with injected noise."""
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentInpaintDiffusion
+    from minddiffusion_amd.ldm.models.diffusion.plms import PLMSSampler
+    cfg = dict(_tiny_cfg(), in_channels=9)
+    params = O.init_params(_oracle_cfg(cfg), seed=6)
+    net = _build(cfg, params, True)
+    model = LatentInpaintDiffusion(unet_config=net, linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    assert model.model.conditioning_key == "hybrid" and model.masked_image_key in model.concat_keys
+    omodel = O.ModelOracle(O.UNetOracle(_oracle_cfg(cfg), params))
+    B, H, W, T, S = 2, 8, 8, 6, 5
+    rng = np.random.RandomState(8)
+    x_T = rng.randn(B, 4, H, W).astype(np.float32)
+    c = rng.randn(B, T, cfg["context_dim"]).astype(np.float32)
+    uc = np.repeat(rng.randn(1, T, cfg["context_dim"]).astype(np.float32), B, 0)
+    m = (rng.rand(B, 1, H, W) > 0.5).astype(np.float32)                      # inpaint.py:76-78: resized mask
+    masked_latent = rng.randn(B, 4, H, W).astype(np.float32)                 # encode_first_stage(masked image)
+    c_cat = np.concatenate([m, masked_latent], 1)
+    noises = [rng.randn(B, 4, H, W).astype(np.float32) for _ in range(S)]
+    kw = dict(mask=m, x0=masked_latent, blend_noises=noises) if blend else dict(x0=masked_latent)
+    ref, _ = O.sample(omodel, S, B, (4, H, W), {"c_concat": c_cat, "c_crossattn": c}, x_T, "plms",
+                      unconditional_guidance_scale=7.5,
+                      unconditional_conditioning={"c_concat": c_cat, "c_crossattn": uc},
+                      **({k: v for k, v in kw.items() if k != "x0"} if not blend else kw))
+    dev = lambda a: torch.tensor(a, device=DEV)
+    got, _ = PLMSSampler(model).sample(S, B, (4, H, W), conditioning={"c_concat": dev(c_cat), "c_crossattn": dev(c)},
+                                       x_T=dev(x_T), unconditional_guidance_scale=7.5,
+                                       unconditional_conditioning={"c_concat": dev(c_cat), "c_crossattn": dev(uc)},
+                                       verbose=False, **{k: (dev(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+    check(f"tiny_inpaint_hybrid_blend{int(blend)}", got, ref, rel_l2=1e-2, max_rel=1e-2)
+    # the single-call surface too: keyword form of WK ddpm.py:276-278
+    t = torch.full((B,), 500.0, device=DEV)
+    e = model.apply_model(dev(x_T), t, c_concat=[dev(c_cat)], c_crossattn=[dev(c)])
+    eo = omodel.apply_model(torch.tensor(x_T), torch.full((B,), 500.0), {"c_concat": torch.tensor(c_cat), "c_crossattn": torch.tensor(c)})
+    check("tiny_inpaint_apply_model", e, eo, rel_l2=5e-3, max_abs=5e-2)
+
+
 def test_ddim_eta_runs_and_plms_rejects_eta():
     from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
     from minddiffusion_amd.ldm.models.diffusion.plms import PLMSSampler
