@@ -219,6 +219,39 @@ def test_sd2_full_size_single_step():
     check("sd2_full_single_step_B1_64x64", got, ref, rel_l2=5e-3, max_abs=5e-2)
 
 
+def test_sd2_768_single_step():
+    """BASELINE config 3 building block: the SDv2 UNet on a 96x96 latent (768x768 px): levels 96/48/24/12, so the
+    24x24 and 12x12 convs fall off the 8x16-patch HALO kernel onto the generic implicit-GEMM path, and the
+    self-attention runs over N = 9216 tokens (2.15 TFLOP on the CPU oracle)."""
+    from minddiffusion_amd.configs import SD2_UNET
+    import os
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    params = O.init_params(O.SD2_UNET, seed=1)
+    net = _build(dict(SD2_UNET), params, True)
+    oracle = O.UNetOracle(O.SD2_UNET, params)
+    x = np.random.RandomState(43).randn(1, 4, 96, 96).astype(np.float32)
+    ctx = np.random.RandomState(2).randn(1, 77, 1024).astype(np.float32)
+    ref = oracle(x, torch.tensor([661.0]), ctx)
+    got = net(torch.tensor(x, device=DEV), torch.tensor([661.0], device=DEV), torch.tensor(ctx, device=DEV))
+    check("sd2_full_single_step_B1_96x96", got, ref, rel_l2=5e-3, max_abs=5e-2)
+
+
+def test_wukong_full_size_single_step():
+    """BASELINE config 2 building block: the Wukong-Huahua UNet (num_heads = 8 => head dims 40 / 80 / 160, 1x1-conv
+    proj_in / proj_out, context_dim 768) on a 64x64 latent, one evaluation vs the fp32 CPU oracle."""
+    from minddiffusion_amd.configs import WUKONG_UNET
+    import os
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    params = O.init_params(O.WUKONG_UNET, seed=2)
+    net = _build(dict(WUKONG_UNET), params, True)
+    oracle = O.UNetOracle(O.WUKONG_UNET, params)
+    x = np.random.RandomState(44).randn(1, 4, 64, 64).astype(np.float32)
+    ctx = np.random.RandomState(3).randn(1, 77, 768).astype(np.float32)
+    ref = oracle(x, torch.tensor([301.0]), ctx)
+    got = net(torch.tensor(x, device=DEV), torch.tensor([301.0], device=DEV), torch.tensor(ctx, device=DEV))
+    check("wukong_full_single_step_B1_64x64", got, ref, rel_l2=5e-3, max_abs=5e-2)
+
+
 def test_plan_buffers_survive_allocator_churn():
     """Regression: GEMM descriptors hold raw device pointers, so the plan must own its activation buffers
     (they used to be freed with the planning arena and recycled by the caching allocator)."""
