@@ -5,17 +5,23 @@
 // Replaces the reference's nn.Conv2d / nn.Dense call sites (include/mdx.h cites them).
 //
 // Design (MI355X-first):
-//  * 256 threads = 4 wave64 (2x2), block tile 128 x BN (BN = 128 | 64), BK = 64, MFMA 32x32x16 f16.
+//  * gemm_kernel: 256 threads = 4 wave64 (2x2), block tile {128,64} x {128,64}, BK = 64, MFMA 32x32x16 f16.
+//    conv3x3_halo_kernel: stride-1 3x3 convs on 8x16-pixel patches whose 10x18 halo is DMA'd once per 64-channel
+//    chunk and serves all nine taps (6x fewer activation bytes through the DMA path).
 //  * Both operand tiles go HBM -> LDS with `buffer_load_dwordx4 ... lds` (16 B per lane, no VGPR
 //    round trip).  The im2col gather, zero padding, stride-2, nearest-2x upsample and the
 //    two-source channel concat are all folded into the per-lane SOURCE offset; out-of-range
 //    offsets rely on the buffer descriptor's bounds check returning zeros.
 //  * LDS image is lane-linear per DMA (8 rows x 128 B); the bank-conflict XOR swizzle
-//    (chunk ^= (row>>1)&7) is applied on the source side and again on the ds_read_b128 side.
-//  * Double-buffered LDS, one barrier per K tile.
+//    (chunk ^= (row>>1)&7; halo: keyed on the halo column) is applied on the source side and again on the
+//    ds_read_b128 side.  Weights are stored tile-major and pre-swizzled so each DMA reads 1 KiB contiguous.
+//  * 2-5 stage LDS ring, counted `s_waitcnt vmcnt(N)` + raw `s_barrier` (DMAs stay in flight across the
+//    barrier), fragments of k-step s+1 prefetched during the MFMAs of k-step s, XCD-aware tile order.
 //  * Epilogue is staged through LDS so that global stores are full 16-B / 128-B-row coalesced;
-//    bias, per-sample time-embedding bias, residual add, GEGLU and the transposed (V^T) store
-//    are fused there.  Small-M layers use split-K (fp32 slabs + a fused reduce/epilogue kernel).
+//    bias (fetched before the K loop), per-sample time-embedding bias, residual add, GEGLU / GELU / QuickGELU, the
+//    transposed (V^T) store and the split q|k row-major + V^T output are fused there.
+//  * choose_tiling picks the tile height and the split-K factor per shape from a measured cost model;
+//    split-K = fp32 slabs + a fused reduce/epilogue kernel (fixed slab order: deterministic).
 #include "mdx_common.h"
 
 #include <stdlib.h>

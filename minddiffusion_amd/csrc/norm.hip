@@ -1,11 +1,13 @@
 // GroupNorm(32)(+SiLU) and LayerNorm on NHWC / token-major fp16 for gfx950.  HBM-bound kernels:
 // 16-byte coalesced accesses, fp32 statistics, wavefront (64-lane) shuffle reductions.
 //
-// GroupNorm is two launches:
+// GroupNorm is two launches for tensors of >= 1024 pixels per sample:
 //   gn_stats : every block reduces a slab of pixels to per-(sample, group) partial {sum, sumsq}
 //              (deterministic: partials are written, not atomically added)
 //   gn_apply : every block first folds the partials into per-channel scale/shift in LDS, then
-//              streams y = silu(x * scale_c + shift_c).
+//              streams y = silu(x * scale_c + shift_c)
+// and ONE launch (gn_fused_kernel: a block owns a whole-group column block of a sample) for the small
+// tensors of the deep UNet levels, where the second launch costs more than the work.
 // The input may be the channel concat of two tensors (UNet skip connections): the concat is
 // never materialised.
 #include "mdx_common.h"
