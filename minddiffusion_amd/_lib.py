@@ -88,6 +88,11 @@ def load():
         raise MdxError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C minddiffusion_amd/csrc`.")
+    # PyTorch owns the device memory and the streams we are handed, so this library must run on the SAME HIP runtime
+    # instance: torch bundles its own libamdhip64 -- import it first so that the dynamic loader resolves libmdx.so's
+    # dependency to the copy already in the process (loading /opt/rocm's copy first gives two runtimes, and the second
+    # one reports "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
