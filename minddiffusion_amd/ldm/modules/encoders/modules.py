@@ -18,6 +18,13 @@ class FrozenCLIPEmbedder_ZH:
         self.transformer = TextEncoder(context_length=max_length, vocab_size=vocab_size, output_dim=width, width=width,
                                        layers=layers, heads=heads, act=act, device=device)
 
+    @classmethod
+    def wukong(cls, max_length=77, use_fp16=False, tokenizer=None, device=None):
+        """The Wukong-Huahua embedder (wukong-huahua/ldm/modules/encoders/modules.py:24-30): width 768, 12 layers, 12 heads,
+        QuickGELU = x * sigmoid(1.702 x) (its text_encoder.py:67-74); WordPiece tokenizer to be supplied by the caller."""
+        return cls(max_length=max_length, use_fp16=use_fp16, tokenizer=tokenizer, device=device, vocab_size=49408,
+                   width=768, layers=12, heads=12, act="quick_gelu")
+
     def parameter_shapes(self):
         return self.transformer.parameter_shapes("transformer.")
 

@@ -18,7 +18,8 @@ import torch
 import torch.nn.functional as F
 
 SD2_TEXT = dict(context_length=77, vocab_size=49408, width=1024, layers=23, heads=16, act="gelu_tanh")
-WK_TEXT = dict(context_length=77, vocab_size=21128, width=768, layers=12, heads=12, act="quick_gelu")
+# wukong-huahua/ldm/modules/encoders/modules.py:30: width 768, 12 layers, 12 heads; real QuickGELU (text_encoder.py:67-74)
+WK_TEXT = dict(context_length=77, vocab_size=49408, width=768, layers=12, heads=12, act="quick_gelu")
 
 
 def param_shapes(cfg=SD2_TEXT, prefix="transformer."):

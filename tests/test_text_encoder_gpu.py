@@ -80,3 +80,17 @@ def test_full_sd2_text_encoder():
     ref = OT.encode_tokens(params, tok, cfg)
     got = enc(tok)
     check("sd2_text_encoder_B2", got, ref, rel_l2=5e-3, max_abs=1e-1)
+
+
+def test_full_wukong_text_encoder():
+    """The Wukong-Huahua configuration (width 768, 12 layers, 12 heads, real QuickGELU) through FrozenCLIPEmbedder_ZH.wukong."""
+    from minddiffusion_amd.ldm.modules.encoders.modules import FrozenCLIPEmbedder_ZH
+    cfg = dict(OT.WK_TEXT)
+    params = OT.init_params(cfg, seed=5)
+    emb = FrozenCLIPEmbedder_ZH.wukong(device=DEV)
+    assert emb.parameter_shapes() == OT.param_shapes(cfg)
+    emb.load_state_dict(params)
+    tok = np.random.RandomState(6).randint(0, cfg["vocab_size"], (2, 77))
+    ref = OT.encode_tokens(params, tok, cfg)
+    got = emb(tok)
+    check("wukong_text_encoder_B2", got, ref, rel_l2=5e-3, max_abs=1e-1)
