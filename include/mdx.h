@@ -106,6 +106,8 @@ typedef struct mdx_gemm_desc {
     int out2_ld;          /* [n_split, N) go TRANSPOSED to out2[(b * (N - n_split) + n - n_split) * out2_ld + tok]:      */
     int n_split;          /* q|k and V^T of a self-attention in ONE launch (attention.py:108-112).  Multiple of 128;
                              bias only (no rowbias / residual / epilogue / out_bs). */
+    int asym_pad;         /* 3x3 stride-2 only: zero-pad bottom / right instead of all around (VAE Encoder Downsample,
+                             ldm/modules/diffusionmodules/model.py:55-78) */
 } mdx_gemm_desc;
 
 #define MDX_EPI_NONE 0
@@ -199,6 +201,12 @@ int mdx_pack_b_operand_f16(const void* src, long src_ld, int rows, int K, void* 
 /* In place: x[r][0..cols) = softmax(scale * x[r][0..cols)) for fp16 scores (P.Softmax(axis=2), model.py:192-194);
  * fp32 max / sum.  cols % 8 == 0, cols <= 16384. */
 int mdx_softmax_rows_f16(void* x, long ld, int rows, int cols, float scale, mdx_stream_t s);
+
+/* AutoencoderKL.encode's DiagonalGaussianDistribution sample (autoencoder.py:70-78): moments NHWC fp16 [B][HW][ld] =
+ * [mean (zc) | logvar (zc) | ..]; out NCHW fp32 [B][zc][HW] = mean + exp(0.5 * clip(logvar, -30, 20)) * noise
+ * (noise NCHW fp32, or NULL for the mode). */
+int mdx_vae_gaussian_sample_f32(const void* moments, int ld, const float* noise, float* out, int B, int zc, int HW,
+                                mdx_stream_t s);
 
 /* ---- probes used by tests to pin hardware layout assumptions (not on the hot path) */
 int mdx_probe_mfma_32x32x16_f16(const void* a, const void* b, float* c, mdx_stream_t s);

@@ -30,7 +30,7 @@ class GemmDesc(ctypes.Structure):
         ("epilogue", c_int), ("out_mode", c_int), ("splitk", c_int),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("out_bs", c_long),
-        ("out2", c_void_p), ("out2_ld", c_int), ("n_split", c_int),
+        ("out2", c_void_p), ("out2_ld", c_int), ("n_split", c_int), ("asym_pad", c_int),
     ]
 
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     "mdx_glide_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_float, c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mdx_pack_b_operand_f16": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]),
+    "mdx_vae_gaussian_sample_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mdx_softmax_rows_f16": (c_int, [c_void_p, c_long, c_int, c_int, c_float, c_void_p]),
     "mdx_probe_mfma_32x32x16_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdx_probe_gemm_trace": (c_int, [c_void_p, c_size_t]),

@@ -891,10 +891,15 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     p.ksize = d->ksize;
     p.stride = d->stride;
     p.upsample = d->upsample ? 1 : 0;
-    p.pad = d->ksize == 3 ? 1 : 0;
+    // asym_pad: zero padding on the bottom / right only (VAE Encoder Downsample: nn.Pad((0,1),(0,1)) + valid 3x3 stride 2,
+    // ldm/modules/diffusionmodules/model.py:55-78) -- the taps start AT the output pixel instead of one before it
+    MDX_REQUIRE(!d->asym_pad || (d->ksize == 3 && d->stride == 2 && !d->upsample),
+                "mdx_gemm_f16: asym_pad applies to the 3x3 stride-2 conv only");
+    p.pad = d->ksize == 3 ? (d->asym_pad ? 0 : 1) : 0;
+    const int pad_hi = d->ksize == 3 ? 1 : 0;
     const int Hs = p.upsample ? 2 * d->H : d->H, Ws = p.upsample ? 2 * d->W : d->W;
-    p.Ho = (Hs + 2 * p.pad - d->ksize) / d->stride + 1;
-    p.Wo = (Ws + 2 * p.pad - d->ksize) / d->stride + 1;
+    p.Ho = (Hs + p.pad + pad_hi - d->ksize) / d->stride + 1;
+    p.Wo = (Ws + p.pad + pad_hi - d->ksize) / d->stride + 1;
     p.HoWo = p.Ho * p.Wo;
     p.M = d->B * p.HoWo;
     p.N = d->N;

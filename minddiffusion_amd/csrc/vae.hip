@@ -83,7 +83,36 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(f16* __restrict__ x, 
     }
 }
 
+// DiagonalGaussianDistribution sample of AutoencoderKL.encode (autoencoder.py:70-78): moments NHWC fp16 [B][HW][ld]
+// = [mean (zc) | logvar (zc) | pad]; z = mean + exp(0.5 * clip(logvar, -30, 20)) * noise, NCHW fp32 out (noise NULL: mean).
+__global__ __launch_bounds__(256) void gaussian_sample_kernel(const f16* __restrict__ mom, const float* __restrict__ noise,
+                                                              float* __restrict__ out, int B, int zc, int HW, int ld) {
+    const size_t total = (size_t)B * zc * HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int pix = (int)(i % HW);
+        const size_t bc = i / HW;
+        const int c = (int)(bc % zc), b = (int)(bc / zc);
+        const f16* m = mom + ((size_t)b * HW + pix) * ld;
+        const float mean = (float)m[c];
+        float lv = (float)m[zc + c];
+        lv = fminf(fmaxf(lv, -30.0f), 20.0f);
+        out[i] = noise ? mean + __expf(0.5f * lv) * noise[i] : mean;
+    }
+}
+
 }  // namespace
+
+extern "C" int mdx_vae_gaussian_sample_f32(const void* moments, int ld, const float* noise, float* out, int B, int zc,
+                                           int HW, mdx_stream_t s) {
+    MDX_REQUIRE(moments && out && B > 0 && zc > 0 && HW > 0 && ld >= 2 * zc, "mdx_vae_gaussian_sample_f32: bad arguments");
+    const size_t total = (size_t)B * zc * HW;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gaussian_sample_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const f16*)moments, noise, out, B,
+                       zc, HW, ld);
+    MDX_LAUNCH_CHECK("mdx_vae_gaussian_sample_f32");
+    return MDX_OK;
+}
 
 extern "C" int mdx_pack_b_operand_f16(const void* src, long src_ld, int rows, int K, void* dst, mdx_stream_t s) {
     MDX_REQUIRE(src && dst, "mdx_pack_b_operand_f16: null pointer");

@@ -127,9 +127,13 @@ class LatentDiffusion:
                            "pass precomputed conditioning tensors [B,77,context_dim] instead")
         return self.cond_stage_model.encode(c)
 
-    def encode_first_stage(self, x):
-        raise NotImplementedError("the VAE encoder (img2img / inpainting pre-processing, WK ddpm.py:296-303) is not built; "
-                                  "pass the masked-image latent in c_concat directly")
+    def encode_first_stage(self, x):                      # WK ddpm.py:270-271
+        if self.first_stage_model is None:
+            raise MdxError("no VAE attached (first_stage_model)")
+        return self.first_stage_model.encode(x)
+
+    def get_first_stage_encoding(self, z):                # WK ddpm.py:273-274
+        return self.scale_factor * z
 
     def decode_first_stage(self, z, predict_cids=False):
         if self.first_stage_model is None:

@@ -19,6 +19,132 @@ from .openaimodel import _Arena
 f16, f32 = torch.float16, torch.float32
 
 
+def _run_plan(net, P):
+    """Replay the plan as one hipGraph (captured on first use), or eagerly if capture is unavailable."""
+    if net.use_graph and not P.graph_failed:
+        if P.graph is None:
+            try:
+                for op in P.main:
+                    op()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for op in P.main:
+                        op()
+                P.graph = g
+            except Exception as e:  # pragma: no cover - depends on the runtime
+                P.graph, P.graph_failed = None, True
+                import warnings
+                warnings.warn(f"hipGraph capture failed, running eagerly: {e}")
+        if P.graph is not None:
+            P.graph.replay()
+            return
+    for op in P.main:
+        op()
+
+
+class _PlanBuilder:
+    """Emits the C-ABI call list of a VAE net on arena buffers (shared by Decoder and Encoder)."""
+
+    def __init__(self, net, P, B):
+        self.net, self.P, self.B = net, P, B
+        self.dev, self.w = net.device, net.w
+        self.A = _Arena(self.dev)
+        self.main, self.meta, self.descs = [], [], []
+        self.gn_need = 4
+
+    def emit(self, fn, kind, flops=0, info=""):
+        self.main.append(fn)
+        self.meta.append({"kind": kind, "flops": int(flops), "launches": 1, "info": info})
+
+    def gemm(self, **kw):
+        d = ops.make_gemm_desc(**kw)
+        self.descs.append(d)
+        ks, up, st = kw.get("ksize", 1), kw.get("upsample", 0), kw.get("stride", 1)
+        m_rows = kw["B"] * kw["H"] * kw["W"] * (4 if up else 1) // (st * st)
+        kdim = ks * ks * kw["c1"]
+        self.emit(lambda d=d: ops.gemm_run(d), "gemm", 2 * m_rows * kw["N"] * kdim,
+                  f"M={m_rows} N={kw['N']} K={kdim} k{ks}s{st}u{up}")
+
+    def gn(self, x, g, b, silu, out):
+        Bq, HW, C = x.shape
+        self.gn_need = max(self.gn_need, ops.groupnorm_ws_floats(Bq, HW, C))
+        P = self.P
+        self.emit(lambda: ops.groupnorm(x, None, g, b, 1e-6, silu, ws=P.gn_ws, out=out), "groupnorm", 0, f"B={Bq} HW={HW} C={C}")
+
+    def conv3(self, src, cin, cout, wt, bias, h, wd, upsample=0, residual=None, n_store=None, stride=1, asym_pad=0):
+        ho, wo = (2 * h, 2 * wd) if upsample else (h // stride, wd // stride)
+        n_store = n_store or cout
+        out = self.A.get((self.B, ho * wo, n_store))
+        self.gemm(a=src, w=wt, N=n_store, B=self.B, H=h, W=wd, c1=cin, out=out, out_ld=n_store, bias=bias, residual=residual,
+                  residual_ld=n_store if residual is not None else 0, ksize=3, upsample=upsample, stride=stride,
+                  asym_pad=asym_pad)
+        return out
+
+    def conv1(self, src, tokens, cin, cout, wt, bias, residual=None, out=None, out_ld=None, out_mode=ops.OUT_ROWMAJOR):
+        if out is None:
+            out, out_ld = self.A.get((self.B, tokens, cout)), cout
+        self.gemm(a=src, w=wt, N=cout, B=self.B, H=tokens, W=1, c1=cin, out=out, out_ld=out_ld, bias=bias, residual=residual,
+                  residual_ld=cout if residual is not None else 0, out_mode=out_mode)
+        return out
+
+    def resblock(self, pre, x, cin, cout, h, wd):          # ResnetBlock.construct model.py:128-148, temb = None
+        A, w, B = self.A, self.w, self.B
+        hw = h * wd
+        a = A.get((B, hw, cin))
+        self.gn(x, w[pre + "norm1.g"], w[pre + "norm1.b"], True, a)
+        h1 = self.conv3(a, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd)
+        A.release(a)
+        a2 = A.get((B, hw, cout))
+        self.gn(h1, w[pre + "norm2.g"], w[pre + "norm2.b"], True, a2)
+        A.release(h1)
+        skip = x if cin == cout else self.conv1(x, hw, cin, cout, w[pre + "nin.w"], w[pre + "nin.b"])
+        out = self.conv3(a2, cout, cout, w[pre + "conv2.w"], w[pre + "conv2.b"], h, wd, residual=skip)
+        A.release(a2)
+        if skip is not x:
+            A.release(skip)
+        return out
+
+    def attnblock(self, pre, x, c, h, wd):                 # AttnBlock.construct model.py:182-206
+        A, w, B = self.A, self.w, self.B
+        hw = h * wd
+        if hw % 8:
+            raise MdxError("VAE attention needs h*w % 8 == 0")
+        hn = A.get((B, hw, c))
+        self.gn(x, w[pre + "norm.g"], w[pre + "norm.b"], False, hn)
+        q = self.conv1(hn, hw, c, c, w[pre + "q.w"], w[pre + "q.b"])
+        k = self.conv1(hn, hw, c, c, w[pre + "k.w"], w[pre + "k.b"])
+        vt = A.get((B, c, hw))                         # V^T [b][c][hw]: the GEMM stores it transposed
+        self.conv1(hn, hw, c, c, w[pre + "v.w"], w[pre + "v.b"], out=vt, out_ld=hw, out_mode=ops.OUT_TRANSPOSED)
+        A.release(hn)
+        o = A.get((B, hw, c))
+        kp = A.get((((hw + 63) // 64) * ((c + 63) // 64) * 4096,))     # packed K   (rows = keys, K = c)
+        vp = A.get((((c + 63) // 64) * ((hw + 63) // 64) * 4096,))     # packed V^T (rows = c,    K = keys)
+        s = A.get((hw, hw))                            # scores of ONE image (the reference holds all B at once)
+        scale = float(int(c) ** (-0.5))
+        for b in range(B):
+            self.emit(lambda b=b: ops.pack_b_operand(k[b], out=kp), "small")
+            self.gemm(a=q[b], w=kp, N=hw, B=1, H=hw, W=1, c1=c, out=s, out_ld=hw)                  # w_ = bmm(q, k)
+            self.emit(lambda: ops.softmax_rows(s, scale), "small")                                   # * c^-0.5, Softmax
+            self.emit(lambda b=b: ops.pack_b_operand(vt[b], out=vp), "small")
+            self.gemm(a=s, w=vp, N=c, B=1, H=hw, W=1, c1=hw, out=o[b], out_ld=c)                    # h_ = bmm(v, w_^T)
+        for t in (q, k, vt, kp, vp, s):
+            A.release(t)
+        out = self.conv1(o, hw, c, c, w[pre + "proj_out.w"], w[pre + "proj_out.b"], residual=x)
+        A.release(o)
+        return out
+
+    def finish(self):
+        P = self.P
+        need = max([ops.gemm_workspace_bytes(d) for d in self.descs] + [16])
+        P.gemm_ws = torch.empty(need // 4, dtype=f32, device=self.dev)
+        for d in self.descs:
+            d.workspace, d.workspace_bytes = P.gemm_ws.data_ptr(), P.gemm_ws.numel() * 4
+        P.gn_ws = torch.empty(self.gn_need, dtype=f32, device=self.dev)
+        P.main, P.meta, P.descs, P.arena = self.main, self.meta, self.descs, self.A
+        P.activation_bytes = self.A.total
+
+
 class Decoder:
     def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
                  resamp_with_conv=True, in_channels, resolution, z_channels, give_pre_end=False, tanh_out=False,
@@ -150,128 +276,46 @@ class Decoder:
             raise MdxError("Decoder: load_state_dict() must be called before decode")
         dev, w = self.device, self.w
         P = Decoder._Plan()
-        A = _Arena(dev)
-        main, meta, descs = [], [], []
-        gn_need = [4]
-
-        def emit(fn, kind, flops=0, info=""):
-            main.append(fn)
-            meta.append({"kind": kind, "flops": int(flops), "launches": 1, "info": info})
-
-        def gemm(**kw):
-            d = ops.make_gemm_desc(**kw)
-            descs.append(d)
-            ks, up = kw.get("ksize", 1), kw.get("upsample", 0)
-            m_rows = kw["B"] * kw["H"] * kw["W"] * (4 if up else 1)
-            kdim = ks * ks * kw["c1"]
-            emit(lambda d=d: ops.gemm_run(d), "gemm", 2 * m_rows * kw["N"] * kdim, f"M={m_rows} N={kw['N']} K={kdim} k{ks}u{up}")
-
-        def gn(x, g, b, silu, out):
-            Bq, HW, C = x.shape
-            gn_need[0] = max(gn_need[0], ops.groupnorm_ws_floats(Bq, HW, C))
-            emit(lambda: ops.groupnorm(x, None, g, b, 1e-6, silu, ws=P.gn_ws, out=out), "groupnorm", 0, f"B={Bq} HW={HW} C={C}")
-
-        def conv3(src, cin, cout, wt, bias, h, wd, upsample=0, residual=None, n_store=None):
-            ho, wo = (2 * h, 2 * wd) if upsample else (h, wd)
-            n_store = n_store or cout
-            out = A.get((B, ho * wo, n_store))
-            gemm(a=src, w=wt, N=n_store, B=B, H=h, W=wd, c1=cin, out=out, out_ld=n_store, bias=bias, residual=residual,
-                 residual_ld=n_store if residual is not None else 0, ksize=3, upsample=upsample)
-            return out
-
-        def conv1(src, tokens, cin, cout, wt, bias, residual=None, out=None, out_ld=None, out_mode=ops.OUT_ROWMAJOR):
-            if out is None:
-                out, out_ld = A.get((B, tokens, cout)), cout
-            gemm(a=src, w=wt, N=cout, B=B, H=tokens, W=1, c1=cin, out=out, out_ld=out_ld, bias=bias, residual=residual,
-                 residual_ld=cout if residual is not None else 0, out_mode=out_mode)
-            return out
-
-        def resblock(pre, x, cin, cout, h, wd):          # ResnetBlock.construct model.py:128-148, temb = None
-            hw = h * wd
-            a = A.get((B, hw, cin))
-            gn(x, w[pre + "norm1.g"], w[pre + "norm1.b"], True, a)
-            h1 = conv3(a, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd)
-            A.release(a)
-            a2 = A.get((B, hw, cout))
-            gn(h1, w[pre + "norm2.g"], w[pre + "norm2.b"], True, a2)
-            A.release(h1)
-            skip = x if cin == cout else conv1(x, hw, cin, cout, w[pre + "nin.w"], w[pre + "nin.b"])
-            out = conv3(a2, cout, cout, w[pre + "conv2.w"], w[pre + "conv2.b"], h, wd, residual=skip)
-            A.release(a2)
-            if skip is not x:
-                A.release(skip)
-            return out
-
-        def attnblock(pre, x, c, h, wd):                 # AttnBlock.construct model.py:182-206
-            hw = h * wd
-            if hw % 8:
-                raise MdxError("Decoder: attention needs h*w % 8 == 0")
-            hn = A.get((B, hw, c))
-            gn(x, w[pre + "norm.g"], w[pre + "norm.b"], False, hn)
-            q = conv1(hn, hw, c, c, w[pre + "q.w"], w[pre + "q.b"])
-            k = conv1(hn, hw, c, c, w[pre + "k.w"], w[pre + "k.b"])
-            vt = A.get((B, c, hw))                         # V^T [b][c][hw]: the GEMM stores it transposed
-            conv1(hn, hw, c, c, w[pre + "v.w"], w[pre + "v.b"], out=vt, out_ld=hw, out_mode=ops.OUT_TRANSPOSED)
-            A.release(hn)
-            o = A.get((B, hw, c))
-            kp = A.get((((hw + 63) // 64) * ((c + 63) // 64) * 4096,))     # packed K   (rows = keys, K = c)
-            vp = A.get((((c + 63) // 64) * ((hw + 63) // 64) * 4096,))     # packed V^T (rows = c,    K = keys)
-            s = A.get((hw, hw))                            # scores of ONE image (the reference holds all B at once)
-            scale = float(int(c) ** (-0.5))
-            for b in range(B):
-                emit(lambda b=b: ops.pack_b_operand(k[b], out=kp), "small")
-                gemm(a=q[b], w=kp, N=hw, B=1, H=hw, W=1, c1=c, out=s, out_ld=hw)                  # w_ = bmm(q, k)
-                emit(lambda: ops.softmax_rows(s, scale), "small")                                   # * c^-0.5, Softmax
-                emit(lambda b=b: ops.pack_b_operand(vt[b], out=vp), "small")
-                gemm(a=s, w=vp, N=c, B=1, H=hw, W=1, c1=hw, out=o[b], out_ld=c)                    # h_ = bmm(v, w_^T)
-            for t in (q, k, vt, kp, vp, s):
-                A.release(t)
-            out = conv1(o, hw, c, c, w[pre + "proj_out.w"], w[pre + "proj_out.b"], residual=x)
-            A.release(o)
-            return out
-
+        pb = _PlanBuilder(self, P, B)
+        A = pb.A
         P.z_static = torch.zeros((B, self.z_channels, H, W), dtype=f32, device=dev)
         zin = A.get((B, H * W, self.zc_pad))
-        emit(lambda: ops.nchw_to_nhwc(P.z_static, self.zc_pad, out=zin), "small")
+        pb.emit(lambda: ops.nchw_to_nhwc(P.z_static, self.zc_pad, out=zin), "small")
         hcur = zin
         if "pq.w" in w:                                  # AutoencoderKL.post_quant_conv (1x1)
-            hcur = conv1(zin, H * W, self.zc_pad, self.zc_pad, w["pq.w"], w["pq.b"])
+            hcur = pb.conv1(zin, H * W, self.zc_pad, self.zc_pad, w["pq.w"], w["pq.b"])
             A.release(zin)
         seq, first, last = self._structure()
         h, wd = H, W
-        nxt = conv3(hcur, self.zc_pad, first, w["conv_in.w"], w["conv_in.b"], h, wd)
+        nxt = pb.conv3(hcur, self.zc_pad, first, w["conv_in.w"], w["conv_in.b"], h, wd)
         A.release(hcur)
         hcur = nxt
         for pre, kind, cin, cout in seq:
             if kind == "res":
-                nxt = resblock(pre, hcur, cin, cout, h, wd)
+                nxt = pb.resblock(pre, hcur, cin, cout, h, wd)
             elif kind == "attn":
-                nxt = attnblock(pre, hcur, cin, h, wd)
+                nxt = pb.attnblock(pre, hcur, cin, h, wd)
             else:                                        # Upsample model.py:45-52: nearest x2 folded into the gather
-                nxt = conv3(hcur, cin, cin, w[pre + "conv.w"], w[pre + "conv.b"], h, wd, upsample=1)
+                nxt = pb.conv3(hcur, cin, cin, w[pre + "conv.w"], w[pre + "conv.b"], h, wd, upsample=1)
                 h, wd = 2 * h, 2 * wd
             A.release(hcur)
             hcur = nxt
         a = A.get((B, h * wd, last))
-        gn(hcur, w["norm_out.g"], w["norm_out.b"], True, a)
+        pb.gn(hcur, w["norm_out.g"], w["norm_out.b"], True, a)
         A.release(hcur)
-        y = conv3(a, last, self.out_ch, w["conv_out.w"], w["conv_out.b"], h, wd, n_store=self.out_pad)
+        y = pb.conv3(a, last, self.out_ch, w["conv_out.w"], w["conv_out.b"], h, wd, n_store=self.out_pad)
         A.release(a)
         P.out_nchw = torch.empty((B, self.out_ch, h, wd), dtype=f32, device=dev)
-        emit(lambda: ops.nhwc_to_nchw(y, self.out_ch, h, wd, out=P.out_nchw), "small")
-
-        need = max([ops.gemm_workspace_bytes(d) for d in descs] + [16])
-        P.gemm_ws = torch.empty(need // 4, dtype=f32, device=dev)
-        for d in descs:
-            d.workspace, d.workspace_bytes = P.gemm_ws.data_ptr(), P.gemm_ws.numel() * 4
-        P.gn_ws = torch.empty(gn_need[0], dtype=f32, device=dev)
-        P.main, P.meta, P.descs, P.arena = main, meta, descs, A
+        pb.emit(lambda: ops.nhwc_to_nchw(y, self.out_ch, h, wd, out=P.out_nchw), "small")
+        pb.finish()
         P.out_hw = (h, wd)
-        P.activation_bytes = A.total
         self._plans[key] = P
         return P
 
     # ------------------------------------------------------------------ run
+    def _run(self, P):
+        _run_plan(self, P)
+
     def construct(self, z):
         """model.py:408-440.  z [B, z_channels, h, w] fp32 on the GPU -> image [B, out_ch, 8h, 8w] fp32 (a buffer
         owned by the plan, overwritten by the next call)."""
@@ -282,26 +326,172 @@ class Decoder:
             raise MdxError(f"Decoder: expected {self.z_channels} latent channels, got {C}")
         P = self._plan(B, H, W)
         P.z_static.copy_(z)
-        if self.use_graph and not P.graph_failed:
-            if P.graph is None:
-                try:
-                    for op in P.main:
-                        op()
-                    torch.cuda.synchronize()
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        for op in P.main:
-                            op()
-                    P.graph = g
-                except Exception as e:  # pragma: no cover - depends on the runtime
-                    P.graph, P.graph_failed = None, True
-                    import warnings
-                    warnings.warn(f"hipGraph capture failed, running eagerly: {e}")
-            if P.graph is not None:
-                P.graph.replay()
-                return P.out_nchw
-        for op in P.main:
-            op()
+        _run_plan(self, P)
         return P.out_nchw
+
+    __call__ = construct
+
+
+class Encoder:
+    """model.py:216-318: conv_in, per level `num_res_blocks` ResnetBlocks (+ Downsample except at the last level: zero
+    pad bottom/right + valid 3x3 stride 2 -> mdx_gemm_desc.asym_pad), the mid block with its single-head attention,
+    GroupNorm + swish, conv_out to 2 * z_channels moments.  Same planned execution as Decoder."""
+
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution, z_channels, double_z=True, use_linear_attn=False,
+                 attn_type="vanilla", device=None, use_graph=True, **ignore_kwargs):
+        if attn_type != "vanilla" or use_linear_attn or not resamp_with_conv or not double_z:
+            raise NotImplementedError("only the shipped configuration (vanilla attention, conv resampling, double_z) is built")
+        self.ch, self.ch_mult, self.num_res_blocks = ch, tuple(ch_mult), num_res_blocks
+        self.attn_resolutions, self.resolution = tuple(attn_resolutions), resolution
+        self.in_channels, self.z_channels = in_channels, z_channels
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()
+                                                                                   if torch.cuda.is_available() else 0)
+        self.use_graph = use_graph
+        self.cin_pad, self.mom_pad = 8, (2 * z_channels + 7) // 8 * 8
+        self.w = None
+        self._plans = {}
+
+    _dev, _vec, _conv_w = Decoder._dev, Decoder._vec, Decoder._conv_w
+
+    def _structure(self):
+        nres = len(self.ch_mult)
+        in_mult = (1,) + self.ch_mult
+        curr_res = self.resolution
+        seq = []
+        block_in = self.ch
+        for lvl in range(nres):
+            block_in, block_out = self.ch * in_mult[lvl], self.ch * self.ch_mult[lvl]
+            for i in range(self.num_res_blocks):
+                seq.append((f"down.{lvl}.block.{i}.", "res", block_in, block_out))
+                block_in = block_out
+                if curr_res in self.attn_resolutions:
+                    seq.append((f"down.{lvl}.attn.{i}.", "attn", block_in, block_in))
+            if lvl != nres - 1:                  # model.py:301-302: the last level's Downsample exists but never runs
+                seq.append((f"down.{lvl}.downsample.", "down", block_in, block_in))
+                curr_res //= 2
+        seq += [("mid.block_1.", "res", block_in, block_in), ("mid.attn_1.", "attn", block_in, block_in),
+                ("mid.block_2.", "res", block_in, block_in)]
+        return seq, self.ch, block_in
+
+    def parameter_shapes(self, prefix=""):
+        seq, first, last = self._structure()
+        s = {prefix + "conv_in.weight": (first, self.in_channels, 3, 3), prefix + "conv_in.bias": (first,)}
+        for pre, kind, cin, cout in seq:
+            p = prefix + pre
+            if kind == "res":
+                s[p + "norm1.gamma"] = (cin,); s[p + "norm1.beta"] = (cin,)
+                s[p + "conv1.weight"] = (cout, cin, 3, 3); s[p + "conv1.bias"] = (cout,)
+                s[p + "norm2.gamma"] = (cout,); s[p + "norm2.beta"] = (cout,)
+                s[p + "conv2.weight"] = (cout, cout, 3, 3); s[p + "conv2.bias"] = (cout,)
+                if cin != cout:
+                    s[p + "nin_shortcut.weight"] = (cout, cin, 1, 1); s[p + "nin_shortcut.bias"] = (cout,)
+            elif kind == "attn":
+                s[p + "norm.gamma"] = (cin,); s[p + "norm.beta"] = (cin,)
+                for n in ("q", "k", "v", "proj_out"):
+                    s[p + n + ".weight"] = (cin, cin, 1, 1); s[p + n + ".bias"] = (cin,)
+            else:
+                s[p + "conv.weight"] = (cin, cin, 3, 3); s[p + "conv.bias"] = (cin,)
+        s[prefix + "norm_out.gamma"] = (last,); s[prefix + "norm_out.beta"] = (last,)
+        s[prefix + "conv_out.weight"] = (2 * self.z_channels, last, 3, 3); s[prefix + "conv_out.bias"] = (2 * self.z_channels,)
+        return s
+
+    def load_state_dict(self, params, prefix="", quant=None, strict=True):
+        """`quant` = (weight [2*embed, 2*zc, 1, 1], bias) of AutoencoderKL.quant_conv, applied after conv_out (autoencoder.py:72)."""
+        shapes = self.parameter_shapes(prefix)
+        missing = [k for k in shapes if k not in params]
+        if missing and strict:
+            raise MdxError(f"Encoder.load_state_dict: missing {len(missing)} parameters, e.g. {missing[:3]}")
+        for k, shp in shapes.items():
+            if k in params and tuple(np.shape(params[k])) != tuple(shp):
+                raise MdxError(f"Encoder.load_state_dict: {k} has shape {tuple(np.shape(params[k]))}, expected {shp}")
+        g = lambda k: params[prefix + k]
+        w = {}
+        seq, first, last = self._structure()
+        w["conv_in.w"] = self._conv_w(g("conv_in.weight"), cin_pad=self.cin_pad)
+        w["conv_in.b"] = self._vec(g("conv_in.bias"))
+        for pre, kind, cin, cout in seq:
+            if kind == "res":
+                for n in ("norm1", "norm2"):
+                    w[pre + n + ".g"], w[pre + n + ".b"] = self._vec(g(pre + n + ".gamma")), self._vec(g(pre + n + ".beta"))
+                for n in ("conv1", "conv2"):
+                    w[pre + n + ".w"], w[pre + n + ".b"] = self._conv_w(g(pre + n + ".weight")), self._vec(g(pre + n + ".bias"))
+                if cin != cout:
+                    w[pre + "nin.w"] = self._conv_w(g(pre + "nin_shortcut.weight"))
+                    w[pre + "nin.b"] = self._vec(g(pre + "nin_shortcut.bias"))
+            elif kind == "attn":
+                w[pre + "norm.g"], w[pre + "norm.b"] = self._vec(g(pre + "norm.gamma")), self._vec(g(pre + "norm.beta"))
+                for n in ("q", "k", "v", "proj_out"):
+                    w[pre + n + ".w"], w[pre + n + ".b"] = self._conv_w(g(pre + n + ".weight")), self._vec(g(pre + n + ".bias"))
+            else:
+                w[pre + "conv.w"], w[pre + "conv.b"] = self._conv_w(g(pre + "conv.weight")), self._vec(g(pre + "conv.bias"))
+        w["norm_out.g"], w["norm_out.b"] = self._vec(g("norm_out.gamma")), self._vec(g("norm_out.beta"))
+        w["conv_out.w"] = self._conv_w(g("conv_out.weight"), cout_pad=self.mom_pad)
+        w["conv_out.b"] = self._vec(g("conv_out.bias"), self.mom_pad)
+        if quant is not None:
+            qw, qb = quant
+            qw = qw if isinstance(qw, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(qw))
+            w["q.w"] = ops.pack_conv_weight(qw.to(self.device), self.mom_pad, self.mom_pad)
+            w["q.b"] = self._vec(qb, self.mom_pad)
+        self.w = w
+        self._plans.clear()
+
+    _Plan = Decoder._Plan
+
+    def _plan(self, B, H, W):
+        key = (B, H, W)
+        if key in self._plans:
+            return self._plans[key]
+        if self.w is None:
+            raise MdxError("Encoder: load_state_dict() must be called before encode")
+        nres = len(self.ch_mult)
+        if H % (1 << (nres - 1)) or W % (1 << (nres - 1)):
+            raise MdxError(f"Encoder: image {H}x{W} is not divisible by 2^{nres - 1}")
+        dev, w = self.device, self.w
+        P = Decoder._Plan()
+        pb = _PlanBuilder(self, P, B)
+        A = pb.A
+        P.x_static = torch.zeros((B, self.in_channels, H, W), dtype=f32, device=dev)
+        xin = A.get((B, H * W, self.cin_pad))
+        pb.emit(lambda: ops.nchw_to_nhwc(P.x_static, self.cin_pad, out=xin), "small")
+        seq, first, last = self._structure()
+        h, wd = H, W
+        hcur = pb.conv3(xin, self.cin_pad, first, w["conv_in.w"], w["conv_in.b"], h, wd)
+        A.release(xin)
+        for pre, kind, cin, cout in seq:
+            if kind == "res":
+                nxt = pb.resblock(pre, hcur, cin, cout, h, wd)
+            elif kind == "attn":
+                nxt = pb.attnblock(pre, hcur, cin, h, wd)
+            else:                                        # Downsample model.py:70-75
+                nxt = pb.conv3(hcur, cin, cin, w[pre + "conv.w"], w[pre + "conv.b"], h, wd, stride=2, asym_pad=1)
+                h, wd = h // 2, wd // 2
+            A.release(hcur)
+            hcur = nxt
+        a = A.get((B, h * wd, last))
+        pb.gn(hcur, w["norm_out.g"], w["norm_out.b"], True, a)
+        A.release(hcur)
+        mom = pb.conv3(a, last, 2 * self.z_channels, w["conv_out.w"], w["conv_out.b"], h, wd, n_store=self.mom_pad)
+        A.release(a)
+        if "q.w" in w:                                   # AutoencoderKL.quant_conv (1x1) on the moments
+            mom = pb.conv1(mom, h * wd, self.mom_pad, self.mom_pad, w["q.w"], w["q.b"])
+        P.moments = mom                                  # NHWC fp16 [B, h*w, mom_pad] = [mean | logvar | pad]
+        pb.finish()
+        P.out_hw = (h, wd)
+        self._plans[key] = P
+        return P
+
+    def construct(self, x):
+        """model.py:293-318 (+ quant_conv when loaded).  x [B, in_channels, H, W] fp32 on the GPU -> the plan's moments
+        buffer, NHWC fp16 [B, (H/8)*(W/8), mom_pad] (mean | logvar), overwritten by the next call."""
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            raise MdxError("Encoder: x must be a CUDA(HIP) tensor (no CPU fallback)")
+        B, C, H, W = x.shape
+        if C != self.in_channels:
+            raise MdxError(f"Encoder: expected {self.in_channels} image channels, got {C}")
+        P = self._plan(B, H, W)
+        P.x_static.copy_(x)
+        _run_plan(self, P)
+        return P.moments
 
     __call__ = construct

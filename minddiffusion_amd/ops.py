@@ -184,7 +184,7 @@ def pack_conv_weight(w4d, cin_pad=None, cout_pad=None):
 
 def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, rowbias=None, rowbias_ld=0,
                    residual=None, residual_ld=0, ksize=1, stride=1, upsample=0, epilogue=EPI_NONE,
-                   out_mode=OUT_ROWMAJOR, splitk=0, workspace=None, out_bs=0, out2=None, out2_ld=0, n_split=0):
+                   out_mode=OUT_ROWMAJOR, splitk=0, workspace=None, out_bs=0, out2=None, out2_ld=0, n_split=0, asym_pad=0):
     d = GemmDesc()
     d.a = a.data_ptr()
     d.a2 = 0 if a2 is None else a2.data_ptr()
@@ -204,7 +204,7 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
     d.workspace_bytes = 0 if workspace is None else workspace.numel() * workspace.element_size()
     d.out_bs = int(out_bs)
     d.out2 = 0 if out2 is None else out2.data_ptr()
-    d.out2_ld, d.n_split = int(out2_ld), int(n_split)
+    d.out2_ld, d.n_split, d.asym_pad = int(out2_ld), int(n_split), int(asym_pad)
     return d
 
 
@@ -318,3 +318,11 @@ def softmax_rows(x2d, scale):
     _lib.check(_lib.load().mdx_softmax_rows_f16(_ptr(x2d), x2d.stride(0), rows, cols, float(scale), _stream()),
                "mdx_softmax_rows_f16")
     return x2d
+
+
+def vae_gaussian_sample(moments, zc, noise, out):
+    """moments NHWC fp16 [B, HW, ld]; noise / out NCHW fp32 [B, zc, h, w] (noise None -> the mode)."""
+    B, HW, ld = moments.shape
+    _lib.check(_lib.load().mdx_vae_gaussian_sample_f32(_ptr(moments), ld, _ptr(noise), _ptr(out), B, zc, HW, _stream()),
+               "mdx_vae_gaussian_sample_f32")
+    return out

@@ -1,10 +1,10 @@
 """TEST INFRASTRUCTURE ONLY (see oracle/__init__.py) -- PARITY UNPINNED by the reference (no tests / fixtures; MindSpore
 cannot run here).
 
-fp32 PyTorch-CPU restatement of the VAE decode path, SURVEY.md 8(f) item 1:
-    AutoencoderKL.decode              /root/reference/vision/stablediffusionv2/ldm/models/autoencoder.py:65-68
-    Decoder / ResnetBlock / AttnBlock / Upsample / Normalize / nonlinearity
-                                      .../ldm/modules/diffusionmodules/model.py:21-52, 80-206, 321-440
+fp32 PyTorch-CPU restatement of the VAE, SURVEY.md 8(f) items 1 and 4:
+    AutoencoderKL.decode / .encode    /root/reference/vision/stablediffusionv2/ldm/models/autoencoder.py:65-78
+    Decoder / Encoder / ResnetBlock / AttnBlock / Upsample / Downsample / Normalize / nonlinearity
+                                      .../ldm/modules/diffusionmodules/model.py:21-78, 80-206, 216-440
     LatentDiffusion.decode_first_stage .../ldm/models/diffusion/ddpm.py:286-288  (z / scale_factor)
 Parameter names are the MindSpore Cell attribute paths (GroupNorm: gamma / beta; Conv2d: weight / bias).
 """
@@ -39,12 +39,38 @@ def _levels(dd):
     return seq, ch * mult[-1], block_in
 
 
+def _enc_levels(dd):
+    """Encoder execution order (model.py:293-312): (prefix, kind, cin, cout); kinds: res | attn | down."""
+    ch, mult, nrb = dd["ch"], tuple(dd["ch_mult"]), dd["num_res_blocks"]
+    in_mult = (1,) + mult
+    curr_res = dd["resolution"]
+    seq, block_in = [], ch
+    for lvl in range(len(mult)):
+        block_in, block_out = ch * in_mult[lvl], ch * mult[lvl]
+        for i in range(nrb):
+            seq.append((f"encoder.down.{lvl}.block.{i}.", "res", block_in, block_out))
+            block_in = block_out
+            if curr_res in tuple(dd["attn_resolutions"]):
+                seq.append((f"encoder.down.{lvl}.attn.{i}.", "attn", block_in, block_in))
+        if lvl != len(mult) - 1:
+            seq.append((f"encoder.down.{lvl}.downsample.", "down", block_in, block_in))
+            curr_res //= 2
+    seq += [("encoder.mid.block_1.", "res", block_in, block_in), ("encoder.mid.attn_1.", "attn", block_in, block_in),
+            ("encoder.mid.block_2.", "res", block_in, block_in)]
+    return seq, ch, block_in
+
+
 def param_shapes(dd=SD_VAE, embed_dim=4):
     seq, first, last = _levels(dd)
     zc = dd["z_channels"]
     s = {"post_quant_conv.weight": (zc, embed_dim, 1, 1), "post_quant_conv.bias": (zc,),
          "decoder.conv_in.weight": (first, zc, 3, 3), "decoder.conv_in.bias": (first,)}
-    for pre, kind, cin, cout in seq:
+    eseq, efirst, elast = _enc_levels(dd)
+    s["quant_conv.weight"] = (2 * embed_dim, 2 * zc, 1, 1); s["quant_conv.bias"] = (2 * embed_dim,)
+    s["encoder.conv_in.weight"] = (efirst, dd["in_channels"], 3, 3); s["encoder.conv_in.bias"] = (efirst,)
+    s["encoder.norm_out.gamma"] = (elast,); s["encoder.norm_out.beta"] = (elast,)
+    s["encoder.conv_out.weight"] = (2 * zc, elast, 3, 3); s["encoder.conv_out.bias"] = (2 * zc,)
+    for pre, kind, cin, cout in seq + eseq:
         if kind == "res":
             s[pre + "norm1.gamma"] = (cin,); s[pre + "norm1.beta"] = (cin,)
             s[pre + "conv1.weight"] = (cout, cin, 3, 3); s[pre + "conv1.bias"] = (cout,)
@@ -130,3 +156,29 @@ def decode(p, z, dd=SD_VAE):
             h = _conv(p, pre + "conv.", F.interpolate(h, scale_factor=2, mode="nearest"), 1)
     h = _swish(_norm(p, "decoder.norm_out.", h))
     return _conv(p, "decoder.conv_out.", h, 1)
+
+
+def encode_moments(p, x, dd=SD_VAE):
+    """Encoder.construct model.py:293-318 followed by quant_conv (autoencoder.py:71-72).  x [B, 3, H, W] fp32."""
+    x = torch.as_tensor(x, dtype=torch.float32)
+    seq, _, _ = _enc_levels(dd)
+    h = _conv(p, "encoder.conv_in.", x, 1)
+    for pre, kind, cin, cout in seq:
+        if kind == "res":
+            h = resnet_block(p, pre, h, cin, cout)
+        elif kind == "attn":
+            h = attn_block(p, pre, h)
+        else:                                   # Downsample model.py:70-75: pad bottom / right by one, valid 3x3 stride 2
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), _t(p, pre + "conv.weight"), _t(p, pre + "conv.bias"), stride=2)
+    h = _swish(_norm(p, "encoder.norm_out.", h))
+    h = _conv(p, "encoder.conv_out.", h, 1)
+    return _conv(p, "quant_conv.", h, 0)
+
+
+def encode(p, x, noise, dd=SD_VAE):
+    """AutoencoderKL.encode autoencoder.py:70-78 with the N(0,1) draw injected (noise None: the mode)."""
+    mean, logvar = encode_moments(p, x, dd).chunk(2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    if noise is None:
+        return mean
+    return mean + torch.exp(0.5 * logvar) * torch.as_tensor(noise, dtype=torch.float32)

@@ -207,7 +207,7 @@ def test_vae_decoder_names_structure_and_plan_on_host():
     from minddiffusion_amd.ldm.models.autoencoder import AutoencoderKL
     full = AutoencoderKL(ddconfig=SD_VAE_DDCONFIG, embed_dim=4, device="cpu")
     assert full.parameter_shapes() == OV.param_shapes(OV.SD_VAE, 4)
-    assert sum(int(np.prod(s)) for s in full.parameter_shapes().values()) == 49_490_199
+    assert sum(int(np.prod(s)) for s in full.parameter_shapes().values()) == 83_653_863   # the SD VAE, encoder + decoder
     dd = dict(TINY_VAE_DDCONFIG)
     vae = AutoencoderKL(ddconfig=dd, embed_dim=4, device="cpu")
     assert vae.parameter_shapes() == OV.param_shapes(dd, 4)
@@ -220,5 +220,8 @@ def test_vae_decoder_names_structure_and_plan_on_host():
     assert kinds.count("gemm") == len(P.descs) and len(P.descs) >= 20
     for d in P.descs:
         assert lib.mdx_gemm_check(ctypes.byref(d)) == 0, lib.mdx_last_error()
-    with pytest.raises(NotImplementedError):
-        vae.encode(None)
+    Pe = vae.encoder._plan(2, 32, 32)
+    assert Pe.out_hw == (16, 16) and tuple(Pe.moments.shape) == (2, 256, 8)
+    for d in Pe.descs:
+        assert lib.mdx_gemm_check(ctypes.byref(d)) == 0, lib.mdx_last_error()
+    assert any(d.asym_pad == 1 and d.stride == 2 for d in Pe.descs)
