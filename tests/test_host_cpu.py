@@ -225,3 +225,44 @@ def test_vae_decoder_names_structure_and_plan_on_host():
     for d in Pe.descs:
         assert lib.mdx_gemm_check(ctypes.byref(d)) == 0, lib.mdx_last_error()
     assert any(d.asym_pad == 1 and d.stride == 2 for d in Pe.descs)
+
+
+def test_mindspore_checkpoint_reader_roundtrip(tmp_path):
+    """MindSpore .ckpt wire format: writer -> reader round trip incl. fp16 / int payloads, a
+    parameter split over several same-tag slices, concatenated messages, prefix stripping and the LatentDiffusion split.
+    A hand-assembled message pins the field numbers independently of our own writer."""
+    from minddiffusion_amd import ms_checkpoint as C
+    rng = np.random.RandomState(0)
+    params = {
+        "model.diffusion_model.time_embed.0.weight": rng.standard_normal((8, 4)).astype(np.float32),
+        "model.diffusion_model.input_blocks.0.0.conv.bias": rng.standard_normal(7).astype(np.float16),
+        "first_stage_model.decoder.conv_in.weight": rng.standard_normal((3, 2, 3, 3)).astype(np.float32),
+        "cond_stage_model.transformer.embedding_table": rng.standard_normal((5, 6)).astype(np.float32),
+        "global_step": np.array([123456789012], dtype=np.int64),
+        "scalar": np.array(2.5, dtype=np.float32),
+    }
+    path = str(tmp_path / "m.ckpt")
+    C.save_checkpoint(params, path, slice_bytes=40)          # forces multi-slice parameters
+    got = C.load_checkpoint(path)
+    assert list(got) == list(params)
+    for k, v in params.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape
+        np.testing.assert_array_equal(got[k], v)
+    unet = C.load_checkpoint(path, strip_prefix=C.UNET_PREFIX)
+    assert sorted(unet) == ["input_blocks.0.0.conv.bias", "time_embed.0.weight"]
+    u, v, t = C.load_latent_diffusion(path)
+    assert "time_embed.0.weight" in u and "decoder.conv_in.weight" in v and "transformer.embedding_table" in t
+    # hand-assembled: Checkpoint{ value{ tag="w", tensor{ dims=[2,2] (packed), tensor_type="Float32", content } } }
+    content = np.arange(4, dtype=np.float32).tobytes()
+    tensor = bytes([0x0A, 0x02, 0x02, 0x02]) + bytes([0x12, 7]) + b"Float32" + bytes([0x1A, 16]) + content
+    value = bytes([0x0A, 1]) + b"w" + bytes([0x12, len(tensor)]) + tensor
+    raw = bytes([0x0A, len(value)]) + value
+    p2 = str(tmp_path / "h.ckpt")
+    open(p2, "wb").write(raw)
+    np.testing.assert_array_equal(C.load_checkpoint(p2)["w"], np.arange(4, dtype=np.float32).reshape(2, 2))
+    # bfloat16 payloads widen to float32
+    bf = (np.array([1.0, -2.5, 3.0], np.float32).view(np.uint32) >> 16).astype(np.uint16).tobytes()
+    tensor = bytes([0x08, 3]) + bytes([0x12, 8]) + b"BFloat16" + bytes([0x1A, len(bf)]) + bf
+    value = bytes([0x0A, 1]) + b"b" + bytes([0x12, len(tensor)]) + tensor
+    open(p2, "wb").write(bytes([0x0A, len(value)]) + value)
+    np.testing.assert_array_equal(C.load_checkpoint(p2)["b"], np.array([1.0, -2.5, 3.0], np.float32))
