@@ -21,6 +21,7 @@ import ctypes
 import math
 
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -105,6 +106,7 @@ class UNetModel:
         self.w = None          # packed device weights
         self._plans = {}
         self._ctx_key = None
+        self._ctx_ref = None
         self.use_graph = True
         self.max_context_len = 80  # 77 CLIP tokens rounded up to a multiple of 8 (V^T rows are 16-B chunked)
         self.last_launch_count = 0
@@ -341,6 +343,7 @@ class UNetModel:
         self.w = w
         self._plans = {}
         self._ctx_key = None
+        self._ctx_ref = None
         return self
 
     def weight_bytes(self):
@@ -606,8 +609,11 @@ class UNetModel:
     def _ensure_context(self, P, context):
         """Project the text context through every attn2.to_k / to_v once per context tensor: it is constant
         across the sampling loop (the reference recomputes it at 16 sites x 51 calls)."""
+        # The cache is tied to the tensor OBJECT (weak reference) and its version counter, not to its address: a later
+        # conditioning tensor can be allocated at the same address with the same version, and must not hit the cache.
         key = (context.data_ptr(), context._version, tuple(context.shape), context.dtype, id(P))
-        if key == self._ctx_key:
+        alive = self._ctx_ref() if self._ctx_ref is not None else None
+        if key == self._ctx_key and alive is context:
             return
         Bc, T, Dc = context.shape
         if Bc != P.B or Dc != self.context_dim:
@@ -620,6 +626,7 @@ class UNetModel:
         for op in P.ctxops:
             op()
         self._ctx_key = key
+        self._ctx_ref = weakref.ref(context)
         # the attention ops read P.ctx_len at call time; a captured graph bakes it in
         if P.graph is not None and getattr(P, "graph_ctx_len", None) != T:
             P.graph = None

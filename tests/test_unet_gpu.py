@@ -252,6 +252,30 @@ def test_wukong_full_size_single_step():
     check("wukong_full_single_step_B1_64x64", got, ref, rel_l2=5e-3, max_abs=5e-2)
 
 
+def test_context_cache_is_not_fooled_by_address_reuse():
+    """The cross-attention K/V cache is keyed on the conditioning tensor OBJECT: a new prompt whose tensor lands at the
+    same address (the caching allocator hands freed blocks back) with the same version counter must be re-projected."""
+    cfg = _tiny_cfg()
+    params = O.init_params(_oracle_cfg(cfg), seed=11)
+    net = _build(cfg, params, True)
+    oracle = O.UNetOracle(_oracle_cfg(cfg), params)
+    x, _ = _inputs(2, 8, 8, 5, cfg["context_dim"], seed=3)
+    ts = np.full((2,), 400.0, np.float32)
+    xd, td = torch.tensor(x, device=DEV), torch.tensor(ts, device=DEV)
+    rng = np.random.RandomState(5)
+    ca = rng.randn(2, 5, cfg["context_dim"]).astype(np.float32)
+    cb = rng.randn(2, 5, cfg["context_dim"]).astype(np.float32)
+    ctx = torch.tensor(ca, device=DEV)
+    ptr = ctx.data_ptr()
+    out_a = net(xd, td, ctx).clone()
+    del ctx
+    ctx2 = torch.tensor(cb, device=DEV)            # same size: the allocator normally returns the same block
+    same_block = ctx2.data_ptr() == ptr
+    out_b = net(xd, td, ctx2).clone()
+    check(f"context_cache_reuse_sameblock{int(same_block)}", out_b, oracle(x, torch.tensor(ts), cb), rel_l2=5e-3, max_abs=5e-2)
+    assert not torch.equal(out_a, out_b)
+
+
 def test_plan_buffers_survive_allocator_churn():
     """Regression: GEMM descriptors hold raw device pointers, so the plan must own its activation buffers
     (they used to be freed with the planning arena and recycled by the caching allocator)."""
