@@ -108,6 +108,18 @@ typedef struct mdx_gemm_desc {
                              bias only (no rowbias / residual / epilogue / out_bs). */
     int asym_pad;         /* 3x3 stride-2 only: zero-pad bottom / right instead of all around (VAE Encoder Downsample,
                              ldm/modules/diffusionmodules/model.py:55-78) */
+    /* nn.LayerNorm folded into the two GEMMs around it (BasicTransformerBlock, attention.py:176-185):
+     *   LN(x) W^T + b  =  rstd_m * ( x (gamma (.) W)^T  -  mean_m * S )  +  (W beta + b),   S[n] = sum_k (gamma (.) W)[n][k]
+     * PRODUCER (the GEMM that writes the token rows x; row-major, N % 64 == 0): stats_out[m][N / 64][2] fp32 receives
+     * {sum, sum of squares} of every 64-column slice of the fp16 row it stores.
+     * CONSUMER (dense 1x1 GEMM over those rows, K = the producer's N): `w` holds fp16(gamma (.) W), `bias` holds
+     * W beta + b, ln_stats = the producer's stats_out, ln_nt = K / 64, ln_s = S computed from the fp16 weights.
+     * The correction is applied to the fp32 accumulators (or to the split-K sum) before bias / activation. */
+    float* stats_out;
+    const float* ln_stats;
+    const float* ln_s;
+    int ln_nt;
+    float ln_eps;
 } mdx_gemm_desc;
 
 #define MDX_EPI_NONE 0

@@ -42,6 +42,14 @@ struct GemmParams {
     float* ws;
     int c1, c2, cin;
     int rowbias_ld, residual_ld, out_ld, out2_ld, n_split;
+    // LayerNorm folded into the GEMMs around it (mdx.h): the PRODUCER of the token stream writes per-row {sum, sumsq}
+    // partials of the fp16 values it stores, one pair per N tile; the CONSUMER multiplies the raw tokens by gamma (.) W
+    // and turns acc into rstd * (acc - mean * S[n]) in the accumulator registers before the usual epilogue.
+    float* stats_out;        // producer: [M][N / 64][2]
+    const float* ln_stats;   // consumer: [M][ln_nt][2] written by the producer
+    const float* ln_s;       // consumer: S[n] = sum_k (gamma (.) W)[n][k], fp32 [N]
+    int ln_nt;
+    float ln_eps;
     long out_bs;   // element stride between samples of a row-major output (0 = dense [M][out_ld])
     int B, H, W, Ho, Wo, HoWo, M, N, K;
     int ksize, stride, upsample, pad;
@@ -84,7 +92,7 @@ __device__ __forceinline__ Row8Extras epilogue_prefetch_row8(const GemmParams& p
     return x;
 }
 
-__device__ __forceinline__ void epilogue_apply_row8(const GemmParams& p, float (&f)[8], int m, int n, const Row8Extras& x) {
+__device__ __forceinline__ f16x8 epilogue_apply_row8(const GemmParams& p, float (&f)[8], int m, int n, const Row8Extras& x) {
     if (p.rowbias) {
         f[0] += x.r0.x; f[1] += x.r0.y; f[2] += x.r0.z; f[3] += x.r0.w;
         f[4] += x.r1.x; f[5] += x.r1.y; f[6] += x.r1.z; f[7] += x.r1.w;
@@ -102,6 +110,7 @@ __device__ __forceinline__ void epilogue_apply_row8(const GemmParams& p, float (
         row = (size_t)b * p.out_bs + (size_t)(m - b * p.HoWo) * p.out_ld;
     }
     *reinterpret_cast<f16x8*>(p.out + row + n) = o;
+    return o;
 }
 
 __device__ __forceinline__ void epilogue_store_row8(const GemmParams& p, float (&f)[8], int m, int n) {
@@ -226,6 +235,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         // row-major store: C^T layout (col = lane&31 -> m, 4 consecutive n per register group)
         constexpr int SLD = BN + 8;
         f16* stg = reinterpret_cast<f16*>(smem);
+        if (p.ln_stats) {
+            // LayerNorm fold: acc holds raw_tokens x (gamma (.) W)^T.  Per row mean / rstd from the producer's partials and
+            // S[n] of this tile go through LDS (behind the staging area), then every accumulator becomes
+            // rstd_m * (acc - mean_m * S_n) in fp32 -- BEFORE the fp16 staging, so the cancellation costs no precision.
+            float* lnrow = reinterpret_cast<float*>(smem + (size_t)BM * SLD * 2);      // [BM][2] mean, rstd
+            float* lns = lnrow + 2 * BM;                                               // [BN]
+            for (int r = tid; r < BM; r += NT) {
+                const int m = rm(r);
+                float su = 0.f, sq = 0.f;
+                if (m < p.M) {
+                    const float2* st = reinterpret_cast<const float2*>(p.ln_stats) + (size_t)m * p.ln_nt;
+                    for (int j = 0; j < p.ln_nt; ++j) {
+                        const float2 v = st[j];
+                        su += v.x;
+                        sq += v.y;
+                    }
+                }
+                const float inv = 1.0f / (float)p.K;
+                const float mean = su * inv;
+                float var = sq * inv - mean * mean;
+                var = var < 0.f ? 0.f : var;
+                lnrow[2 * r] = mean;
+                lnrow[2 * r + 1] = rsqrtf(var + p.ln_eps);
+            }
+            for (int c = tid; c < BN; c += NT) lns[c] = (n0 + c < p.N) ? p.ln_s[n0 + c] : 0.f;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m_l = wm * WROWS + i * 32 + l31;
+                const float mean = lnrow[2 * m_l], rstd = lnrow[2 * m_l + 1];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n_l = wn * (BN / 2) + j * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+                        acc[i][j][r] = rstd * (acc[i][j][r] - mean * lns[n_l]);
+                    }
+            }
+        }
         // plain (non-GEGLU) store: thread -> (row r0 + pass * RPP, 8 columns at n).  Its global loads (bias, and the
         // first pass's time-embedding row / residual) are issued BEFORE the staging barrier so that their latency
         // overlaps the accumulator -> LDS pass; later passes prefetch one pass ahead.
@@ -318,12 +366,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         const int m2 = rm(row + RPP);
                         if (m2 < p.M && n < p.N) xn = epilogue_prefetch_row8(p, m2, n);
                     }
+                    float su = 0.f, sq = 0.f;
                     if (m < p.M && n < p.N) {
                         const f16x8 v = *reinterpret_cast<const f16x8*>(&stg[row * SLD + chunk * 8]);
                         float f[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] = act((float)v[e] + bb[e]);
-                        epilogue_apply_row8(p, f, m, n, xa);
+                        const f16x8 o = epilogue_apply_row8(p, f, m, n, xa);
+                        if (p.stats_out) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float t = (float)o[e];    // statistics of the fp16 values actually stored
+                                su += t;
+                                sq += t * t;
+                            }
+                        }
+                    }
+                    if (p.stats_out) {   // 8 aligned lanes hold one 64-column slice of a row: fixed-order xor tree
+#pragma unroll
+                        for (int off = 4; off >= 1; off >>= 1) {
+                            su += __shfl_xor(su, off, 64);
+                            sq += __shfl_xor(sq, off, 64);
+                        }
+                        if ((chunk & 7) == 0 && m < p.M && n < p.N)
+                            reinterpret_cast<float2*>(p.stats_out)[(size_t)m * (p.N >> 6) + (n >> 6)] = make_float2(su, sq);
                     }
                     xa = xn;
                 }
@@ -816,23 +882,57 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
         // time-embedding row / residual first: their latency overlaps the slab loads instead of following them
         Row8Extras xtra;
         if (p.out_mode != MDX_OUT_TRANSPOSED) xtra = epilogue_prefetch_row8(p, m, oc);
+        // LayerNorm fold (consumer side): the 8 lanes of a 64-column slice share the row, so each adds every 8th of the
+        // producer's partials and an xor tree finishes {sum, sumsq}; N % 64 == 0 keeps the groups whole.
+        const bool ln = p.ln_stats != nullptr;
+        float mean = 0.f, rstd = 1.f;
+        if (ln) {
+            const float2* stp = reinterpret_cast<const float2*>(p.ln_stats) + (size_t)m * p.ln_nt;
+            float su = 0.f, sq = 0.f;
+            for (int j = threadIdx.x & 7; j < p.ln_nt; j += 8) {
+                const float2 v = stp[j];
+                su += v.x;
+                sq += v.y;
+            }
+#pragma unroll
+            for (int off = 4; off >= 1; off >>= 1) {
+                su += __shfl_xor(su, off, 64);
+                sq += __shfl_xor(sq, off, 64);
+            }
+            const float inv = 1.0f / (float)p.K;
+            mean = su * inv;
+            float var = sq * inv - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            rstd = rsqrtf(var + p.ln_eps);
+        }
         float f[8];
         if (geglu) {
             const int pa = (oc >> 6) * 128 + (oc & 63);
             float a[8], g[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                a[e] = p.bias ? p.bias[pa + e] : 0.f;
-                g[e] = p.bias ? p.bias[pa + 64 + e] : 0.f;
+                a[e] = (p.bias && !ln) ? p.bias[pa + e] : 0.f;
+                g[e] = (p.bias && !ln) ? p.bias[pa + 64 + e] : 0.f;
             }
             splitk_sum8(p, p.ws + (size_t)m * p.N + pa, slab, a);
             splitk_sum8(p, p.ws + (size_t)m * p.N + pa + 64, slab, g);
+            if (ln) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    a[e] = rstd * (a[e] - mean * p.ln_s[pa + e]) + (p.bias ? p.bias[pa + e] : 0.f);
+                    g[e] = rstd * (g[e] - mean * p.ln_s[pa + 64 + e]) + (p.bias ? p.bias[pa + 64 + e] : 0.f);
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = a[e] * gelu_tanh_f(g[e]);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = p.bias ? p.bias[oc + e] : 0.f;
+            for (int e = 0; e < 8; ++e) f[e] = (p.bias && !ln) ? p.bias[oc + e] : 0.f;
             splitk_sum8(p, p.ws + (size_t)m * p.N + oc, slab, f);
+            if (ln) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = rstd * (f[e] - mean * p.ln_s[oc + e]) + (p.bias ? p.bias[oc + e] : 0.f);
+            }
             if (p.epilogue == MDX_EPI_GELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = gelu_tanh_f(f[e]);
@@ -853,7 +953,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 #pragma unroll
             for (int e = 0; e < 8; ++e) p.out2[((size_t)b * nv + (oc - p.n_split + e)) * p.out2_ld + tok] = (f16)f[e];
         } else {
-            epilogue_apply_row8(p, f, m, oc, xtra);
+            const f16x8 o = epilogue_apply_row8(p, f, m, oc, xtra);
+            if (p.stats_out) {   // producer side of the LayerNorm fold, as in gemm_epilogue
+                float su = 0.f, sq = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = (float)o[e];
+                    su += t;
+                    sq += t * t;
+                }
+#pragma unroll
+                for (int off = 4; off >= 1; off >>= 1) {
+                    su += __shfl_xor(su, off, 64);
+                    sq += __shfl_xor(sq, off, 64);
+                }
+                if ((threadIdx.x & 7) == 0)
+                    reinterpret_cast<float2*>(p.stats_out)[(size_t)m * (p.N >> 6) + (oc >> 6)] = make_float2(su, sq);
+            }
         }
     }
 }
@@ -875,6 +991,11 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     p.residual = (const f16*)d->residual;
     p.out = (f16*)d->out;
     p.out2 = (f16*)d->out2;
+    p.stats_out = d->stats_out;
+    p.ln_stats = d->ln_stats;
+    p.ln_s = d->ln_s;
+    p.ln_nt = d->ln_nt;
+    p.ln_eps = d->ln_eps;
     p.out2_ld = d->out2_ld;
     p.n_split = d->n_split;
     p.ws = (float*)d->workspace;
@@ -925,6 +1046,14 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
         MDX_REQUIRE(p.HoWo % 8 == 0 && p.out2_ld % 8 == 0 && p.out2_ld >= p.HoWo,
                     "mdx_gemm_f16: transposed part needs tokens %% 8 == 0 and out2_ld >= tokens");
     }
+    if (p.ln_stats) {
+        MDX_REQUIRE(p.ln_s && p.ln_nt * 64 == p.K && p.ksize == 1 && p.c2 == 0 && p.stride == 1 && !p.upsample &&
+                        p.out_mode == MDX_OUT_ROWMAJOR && p.N % (p.epilogue == MDX_EPI_GEGLU ? 128 : 64) == 0,
+                    "mdx_gemm_f16: LayerNorm fold needs ln_s, ln_nt == K / 64, N %% 64 == 0 and a dense row-major GEMM");
+    }
+    if (p.stats_out)
+        MDX_REQUIRE(p.out_mode == MDX_OUT_ROWMAJOR && p.epilogue != MDX_EPI_GEGLU && !p.n_split && p.N % 64 == 0,
+                    "mdx_gemm_f16: row statistics are produced by plain row-major stores with N %% 64 == 0 only");
     if (p.rowbias) MDX_REQUIRE(p.rowbias_ld % 4 == 0, "mdx_gemm_f16: rowbias_ld must be a multiple of 4");
     if (p.residual) MDX_REQUIRE(p.residual_ld % 8 == 0, "mdx_gemm_f16: residual_ld must be a multiple of 8");
     MDX_REQUIRE(p.out_ld % 8 == 0 && p.out_bs % 8 == 0 && p.out_bs >= 0, "mdx_gemm_f16: out_ld / out_bs must be multiples of 8");

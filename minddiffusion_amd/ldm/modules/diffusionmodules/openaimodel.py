@@ -301,12 +301,23 @@ class UNetModel:
                 # self-attention: ONE [q | k | v] projection launch; the q|k columns are stored row-major and the v columns
                 # transposed (mdx_gemm_desc.n_split), which needs 2 * inner to be a multiple of 128
                 wq, wk, wv = (self._dev(P[t + f"attn1.to_{n}.weight"], f16) for n in "qkv")
+                for n in ("norm1", "norm2", "norm3"):
+                    w[t + n + ".g"] = self._dev(P[t + n + ".gamma"], f32)
+                    w[t + n + ".b"] = self._dev(P[t + n + ".beta"], f32)
+                # LayerNorm fold (mdx_gemm_desc.ln_stats): norm1/2/3 disappear into the GEMMs around them -- the consumer
+                # weights become gamma (.) W, with S = row sums and W beta (+ b) as the bias (ops.fold_layernorm)
+                fold = inner % 64 == 0 and os.environ.get("MDX_UNET_LN_FOLD", "1") != "0"
+
+                def put(name, wt, norm, bias=None):
+                    if fold:
+                        wt, w[name + ".s"], w[name + ".cb"] = ops.fold_layernorm(wt, w[t + norm + ".g"], w[t + norm + ".b"], bias)
+                    w[name + ".w"] = self._pack_dense(wt)
                 if (2 * wq.shape[0]) % 128 == 0 and os.environ.get("MDX_UNET_QKV_MERGE", "1") != "0":
-                    w[t + "attn1.qkv.w"] = self._pack_dense(torch.cat([wq, wk, wv], 0))
+                    put(t + "attn1.qkv", torch.cat([wq, wk, wv], 0), "norm1")
                 else:   # fall back to a [q | k] launch and a transposed-store v launch
                     w[t + "attn1.qk.w"] = self._pack_dense(torch.cat([wq, wk], 0))
                     w[t + "attn1.v.w"] = self._pack_dense(wv)
-                w[t + "attn2.q.w"] = self._pack_dense(P[t + "attn2.to_q.weight"])
+                put(t + "attn2.q", self._dev(P[t + "attn2.to_q.weight"], f16), "norm2")
                 w[t + "attn2.k.w"] = self._pack_dense(P[t + "attn2.to_k.weight"])
                 w[t + "attn2.v.w"] = self._pack_dense(P[t + "attn2.to_v.weight"])
                 for a in ("attn1", "attn2"):
@@ -318,15 +329,11 @@ class UNetModel:
                 half = 4 * inner
                 assert half % 64 == 0
                 nt = half // 64
-                w[t + "ff1.w"] = self._pack_dense(
-                    torch.stack([gw[:half].reshape(nt, 64, inner), gw[half:].reshape(nt, 64, inner)], 1)
-                    .reshape(2 * half, inner))
                 w[t + "ff1.b"] = torch.stack([gb[:half].reshape(nt, 64), gb[half:].reshape(nt, 64)], 1).reshape(-1).contiguous()
+                put(t + "ff1", torch.stack([gw[:half].reshape(nt, 64, inner), gw[half:].reshape(nt, 64, inner)], 1)
+                    .reshape(2 * half, inner), "norm3", w[t + "ff1.b"])
                 w[t + "ff2.w"] = self._pack_dense(P[t + "ff.net.2.weight"])
                 w[t + "ff2.b"] = self._dev(P[t + "ff.net.2.bias"], f32)
-                for n in ("norm1", "norm2", "norm3"):
-                    w[t + n + ".g"] = self._dev(P[t + n + ".gamma"], f32)
-                    w[t + n + ".b"] = self._dev(P[t + n + ".beta"], f32)
             elif kind == "down":
                 w[pre + "w"] = self._pack_conv(P[pre + "op.conv.weight"])
                 w[pre + "b"] = self._dev(P[pre + "op.conv.bias"], f32)
@@ -434,15 +441,25 @@ class UNetModel:
             return out, ho, wo
 
         def dense(oplist, src, rows_b, tokens, cin, nout, wt, bias=None, residual=None, epilogue=ops.EPI_NONE,
-                  out=None, out_ld=None, out_mode=ops.OUT_ROWMAJOR, src2=None, c2=0, arena=True):
+                  out=None, out_ld=None, out_mode=ops.OUT_ROWMAJOR, src2=None, c2=0, arena=True, **fold):
             cols = nout // 2 if epilogue == ops.EPI_GEGLU else nout
             if out is None:
                 out = A.get((rows_b, tokens, cols))
                 out_ld = cols
             add_gemm(oplist, a=src, w=wt, N=nout, B=rows_b, H=tokens, W=1, c1=cin - c2, out=out, out_ld=out_ld,
                      a2=src2, c2=c2, bias=bias, residual=residual, residual_ld=cols if residual is not None else 0,
-                     epilogue=epilogue, out_mode=out_mode)
+                     epilogue=epilogue, out_mode=out_mode, **fold)
             return out
+
+        ln_stats = {}
+
+        def stats_buf(rows, width):
+            """{sum, sumsq} per 64-column slice of a token row: written by the GEMM that produces the rows, read by the
+            GEMM that consumes LayerNorm(rows) (mdx_gemm_desc.stats_out / ln_stats).  One buffer per shape: the stream is
+            in order and every consumer runs before the next producer."""
+            if (rows, width) not in ln_stats:
+                ln_stats[(rows, width)] = torch.zeros((rows, width // 64, 2), dtype=f32, device=dev)
+            return ln_stats[(rows, width)]
 
         def resblock(pre, x, x2, cin, cout, h, wd):
             """ResBlock.construct openaimodel.py:176-205; x2 = skip tensor of the (virtual) concat."""
@@ -476,16 +493,24 @@ class UNetModel:
             t = pre + "transformer_blocks.0."
             a = A.get((B, n, ch))
             add_gn(x, None, w[pre + "norm.g"], w[pre + "norm.b"], 1e-6, False, a)
-            tok = dense(main, a, B, n, ch, inner, w[pre + "proj_in.w"], bias=w[pre + "proj_in.b"])
+            # LayerNorm fold: `st` receives the row statistics from each producer of the token stream
+            st = stats_buf(B * n, inner) if (t + "attn2.q.s") in w else None
+            fold1 = st is not None and (t + "attn1.qkv.s") in w
+
+            def consumer(name):   # kwargs of a GEMM that consumes LN(rows) with folded weights
+                return dict(bias=w[name + ".cb"], ln_stats=st, ln_s=w[name + ".s"], ln_eps=1e-5)
+            tok = dense(main, a, B, n, ch, inner, w[pre + "proj_in.w"], bias=w[pre + "proj_in.b"],
+                        stats_out=st if fold1 else None)
             A.release(a)
             # --- attn1 (self)
             ln = A.get((B, n, inner))
-            emit(lambda ln=ln, tok=tok: ops.layernorm(tok, w[t + "norm1.g"], w[t + "norm1.b"], 1e-5, out=ln), "layernorm")
+            if not fold1:
+                emit(lambda ln=ln, tok=tok: ops.layernorm(tok, w[t + "norm1.g"], w[t + "norm1.b"], 1e-5, out=ln), "layernorm")
             vt = A.get((B, inner, n))
             if (t + "attn1.qkv.w") in w:
                 qk = A.get((B, n, 2 * inner))
-                add_gemm(main, a=ln, w=w[t + "attn1.qkv.w"], N=3 * inner, B=B, H=n, W=1, c1=inner, out=qk,
-                         out_ld=2 * inner, out2=vt, out2_ld=n, n_split=2 * inner)
+                add_gemm(main, a=tok if fold1 else ln, w=w[t + "attn1.qkv.w"], N=3 * inner, B=B, H=n, W=1, c1=inner, out=qk,
+                         out_ld=2 * inner, out2=vt, out2_ld=n, n_split=2 * inner, **(consumer(t + "attn1.qkv") if fold1 else {}))
             else:
                 qk = dense(main, ln, B, n, inner, 2 * inner, w[t + "attn1.qk.w"])
                 dense(main, ln, B, n, inner, inner, w[t + "attn1.v.w"], out=vt, out_ld=n, out_mode=ops.OUT_TRANSPOSED)
@@ -494,11 +519,14 @@ class UNetModel:
                 qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
                 n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner),
                 "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
-            tok2 = dense(main, o, B, n, inner, inner, w[t + "attn1.o.w"], bias=w[t + "attn1.o.b"], residual=tok)
+            tok2 = dense(main, o, B, n, inner, inner, w[t + "attn1.o.w"], bias=w[t + "attn1.o.b"], residual=tok, stats_out=st)
             A.release(qk); A.release(vt); A.release(tok)
             # --- attn2 (cross): K / V^T of the context are produced by the context plan
-            emit(lambda ln=ln, tok2=tok2: ops.layernorm(tok2, w[t + "norm2.g"], w[t + "norm2.b"], 1e-5, out=ln), "layernorm")
-            q2 = dense(main, ln, B, n, inner, inner, w[t + "attn2.q.w"])
+            if st is None:
+                emit(lambda ln=ln, tok2=tok2: ops.layernorm(tok2, w[t + "norm2.g"], w[t + "norm2.b"], 1e-5, out=ln), "layernorm")
+                q2 = dense(main, ln, B, n, inner, inner, w[t + "attn2.q.w"])
+            else:
+                q2 = dense(main, tok2, B, n, inner, inner, w[t + "attn2.q.w"], **consumer(t + "attn2.q"))
             kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
             vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
             ctx_kv[pre] = (kc, vtc)
@@ -506,11 +534,14 @@ class UNetModel:
                 q2.data_ptr(), kc.data_ptr(), vtc.data_ptr(), o.data_ptr(), B, heads, dh, n, P.ctx_len, scale,
                 n * inner, inner, TC * inner, inner, inner * TC, TC, n * inner, inner),
                 "attention", 4 * B * heads * n * 77 * dh, 1, f"cross B={B} h={heads} N={n} d={dh}")
-            tok3 = dense(main, o, B, n, inner, inner, w[t + "attn2.o.w"], bias=w[t + "attn2.o.b"], residual=tok2)
+            tok3 = dense(main, o, B, n, inner, inner, w[t + "attn2.o.w"], bias=w[t + "attn2.o.b"], residual=tok2, stats_out=st)
             A.release(q2); A.release(tok2)
             # --- feed-forward (GEGLU fused in the first GEMM's epilogue)
-            emit(lambda ln=ln, tok3=tok3: ops.layernorm(tok3, w[t + "norm3.g"], w[t + "norm3.b"], 1e-5, out=ln), "layernorm")
-            g = dense(main, ln, B, n, inner, 8 * inner, w[t + "ff1.w"], bias=w[t + "ff1.b"], epilogue=ops.EPI_GEGLU)
+            if st is None:
+                emit(lambda ln=ln, tok3=tok3: ops.layernorm(tok3, w[t + "norm3.g"], w[t + "norm3.b"], 1e-5, out=ln), "layernorm")
+                g = dense(main, ln, B, n, inner, 8 * inner, w[t + "ff1.w"], bias=w[t + "ff1.b"], epilogue=ops.EPI_GEGLU)
+            else:
+                g = dense(main, tok3, B, n, inner, 8 * inner, w[t + "ff1.w"], epilogue=ops.EPI_GEGLU, **consumer(t + "ff1"))
             tok4 = dense(main, g, B, n, 4 * inner, inner, w[t + "ff2.w"], bias=w[t + "ff2.b"], residual=tok3)
             A.release(g); A.release(tok3); A.release(ln)
             out = dense(main, tok4, B, n, inner, ch, w[pre + "proj_out.w"], bias=w[pre + "proj_out.b"], residual=x)
@@ -599,6 +630,7 @@ class UNetModel:
         P.main, P.ctxops, P.descs, P.meta = main, ctxops, descs, meta
         assert len(main) == len(meta)
         P.arena_bytes = A.total
+        P.ln_stats = ln_stats
         P.arena = A   # owns the activation buffers (descriptors only hold raw device pointers)
         P.graph = None
         P.graph_failed = False

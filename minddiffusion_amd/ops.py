@@ -184,7 +184,8 @@ def pack_conv_weight(w4d, cin_pad=None, cout_pad=None):
 
 def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, rowbias=None, rowbias_ld=0,
                    residual=None, residual_ld=0, ksize=1, stride=1, upsample=0, epilogue=EPI_NONE,
-                   out_mode=OUT_ROWMAJOR, splitk=0, workspace=None, out_bs=0, out2=None, out2_ld=0, n_split=0, asym_pad=0):
+                   out_mode=OUT_ROWMAJOR, splitk=0, workspace=None, out_bs=0, out2=None, out2_ld=0, n_split=0, asym_pad=0,
+                   stats_out=None, ln_stats=None, ln_s=None, ln_eps=1e-5):
     d = GemmDesc()
     d.a = a.data_ptr()
     d.a2 = 0 if a2 is None else a2.data_ptr()
@@ -205,7 +206,26 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
     d.out_bs = int(out_bs)
     d.out2 = 0 if out2 is None else out2.data_ptr()
     d.out2_ld, d.n_split, d.asym_pad = int(out2_ld), int(n_split), int(asym_pad)
+    # LayerNorm fold (include/mdx.h): producer statistics / consumer correction
+    d.stats_out = 0 if stats_out is None else stats_out.data_ptr()
+    d.ln_stats = 0 if ln_stats is None else ln_stats.data_ptr()
+    d.ln_s = 0 if ln_s is None else ln_s.data_ptr()
+    d.ln_nt = 0 if ln_stats is None else (int(c1) + int(c2)) // 64
+    d.ln_eps = float(ln_eps)
     return d
+
+
+def fold_layernorm(wt, gamma, beta, bias=None):
+    """Host side of the LayerNorm fold (include/mdx.h, mdx_gemm_desc.ln_stats): for y = LN(x; gamma, beta) W^T + b returns
+    (fp16 gamma (.) W [N, K], S fp32 [N], W beta + b fp32 [N]).  S is summed from the fp16-ROUNDED product, i.e. from
+    exactly the numbers the MFMA multiplies, so the mean term cancels to accumulation noise."""
+    w32 = wt.to(torch.float64)
+    wg = (w32 * gamma.to(torch.float64)[None, :]).to(f16)
+    s = wg.to(torch.float64).sum(1).to(f32).contiguous()
+    cb = w32 @ beta.to(torch.float64)
+    if bias is not None:
+        cb = cb + bias.to(torch.float64)
+    return wg.contiguous(), s, cb.to(f32).contiguous()
 
 
 def gemm_workspace_bytes(desc):

@@ -326,6 +326,79 @@ def test_gemm_split_rowmajor_transposed_output(ops, B, T, C, splitk):
     check(f"gemm_split_vt_B{B}_T{T}_C{C}_s{splitk}", vt, full[:, 2 * C:].reshape(B, T, C).permute(0, 2, 1), rel_l2=1e-3)
 
 
+@pytest.mark.parametrize("M,C,kind,sp,sc", [
+    (256, 320, "plain", 1, 1), (200, 64, "plain", 1, 1), (512, 640, "geglu", 1, 1), (256, 320, "qkv", 1, 1),
+    (128, 1280, "plain", 4, 4), (128, 640, "geglu", 2, 2), (128, 640, "qkv", 1, 3), (4096, 320, "geglu", 1, 1),
+    (64, 1280, "plain", 0, 0),
+])
+def test_gemm_layernorm_fold(ops, M, C, kind, sp, sc):
+    """nn.LayerNorm folded into the GEMMs around it (mdx_gemm_desc.stats_out / ln_stats; BasicTransformerBlock
+    attention.py:176-185): the producer GEMM (bias + residual) emits per-row {sum, sumsq}, the consumer multiplies the RAW
+    rows by gamma (.) W and corrects the accumulators.  Checked against explicit LN on the producer's fp16 output, for the
+    plain / GEGLU / merged q|k|v^T consumers, direct and split-K on either side.  The un-normalised rows carry a mean of
+    about the same size as their spread, so the cancellation is exercised."""
+    rng = np.random.RandomState(M + C + sp)
+    K0 = 256
+    a0 = h16(rng.standard_normal((M, K0)))
+    w0 = h16(rng.standard_normal((C, K0)) / math.sqrt(K0))
+    b0 = (rng.standard_normal(C) + 1.0).astype(np.float32)
+    r0 = h16(rng.standard_normal((M, C)) * 2)
+    g = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    be = (0.3 * rng.standard_normal(C)).astype(np.float32)
+    nout = {"plain": C, "geglu": 8 * C, "qkv": 3 * C}[kind]
+    w1 = h16(rng.standard_normal((nout, C)) / math.sqrt(C))
+    b1 = rng.standard_normal(nout).astype(np.float32)
+
+    def run(desc, keep):
+        need = ops.gemm_workspace_bytes(desc)
+        ws = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=DEV)
+        desc.workspace, desc.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        ops.gemm_run(desc)
+        torch.cuda.synchronize()
+
+    # producer
+    x = torch.empty((M, C), dtype=torch.float16, device=DEV)
+    stats = torch.full((M, C // 64, 2), float("nan"), dtype=torch.float32, device=DEV)
+    pa, pw, pb, pr = dev16(a0), pack_dense(w0), dev32(b0), dev16(r0)
+    run(ops.make_gemm_desc(pa, pw, C, 1, M, 1, K0, x, C, bias=pb, residual=pr, residual_ld=C, splitk=sp, stats_out=stats), None)
+    xr = x.float().cpu()
+    check(f"lnfold_producer_M{M}_C{C}_s{sp}", x, torch.tensor(a0) @ torch.tensor(w0).T + torch.tensor(b0) + torch.tensor(r0),
+          rel_l2=1e-3)
+    st_ref = torch.stack([xr.reshape(M, C // 64, 64).sum(-1), (xr ** 2).reshape(M, C // 64, 64).sum(-1)], -1)
+    check(f"lnfold_stats_M{M}_C{C}_s{sp}", stats, st_ref, rel_l2=1e-5)
+
+    # consumer
+    ln = O.layer_norm(xr, torch.tensor(g), torch.tensor(be), 1e-5)
+    full = ln @ torch.tensor(w1).T + torch.tensor(b1)
+    if kind == "geglu":
+        half = 4 * C
+        nt = half // 64
+        w1p = np.stack([w1[:half].reshape(nt, 64, C), w1[half:].reshape(nt, 64, C)], 1).reshape(8 * C, C)
+        b1p = np.stack([b1[:half].reshape(nt, 64), b1[half:].reshape(nt, 64)], 1).reshape(-1)
+    else:
+        w1p, b1p = w1, b1
+    wg, s, cb = ops.fold_layernorm(dev16(w1p), dev32(g), dev32(be), dev32(b1p))
+    wgp = ops.pack_gemm_weight(wg)
+    if kind == "plain":
+        out = torch.empty((M, C), dtype=torch.float16, device=DEV)
+        run(ops.make_gemm_desc(x, wgp, C, 1, M, 1, C, out, C, bias=cb, splitk=sc, ln_stats=stats, ln_s=s), None)
+        check(f"lnfold_plain_M{M}_C{C}_s{sc}", out, full, rel_l2=2e-3)
+    elif kind == "geglu":
+        out = torch.empty((M, 4 * C), dtype=torch.float16, device=DEV)
+        run(ops.make_gemm_desc(x, wgp, 8 * C, 1, M, 1, C, out, 4 * C, bias=cb, splitk=sc, epilogue=ops.EPI_GEGLU,
+                               ln_stats=stats, ln_s=s), None)
+        xa, gate = full.chunk(2, dim=-1)
+        check(f"lnfold_geglu_M{M}_C{C}_s{sc}", out, xa * O.gelu_tanh(gate), rel_l2=3e-3)
+    else:
+        B, T = 2, M // 2
+        qk = torch.empty((B, T, 2 * C), dtype=torch.float16, device=DEV)
+        vt = torch.zeros((B, C, T), dtype=torch.float16, device=DEV)
+        run(ops.make_gemm_desc(x, wgp, 3 * C, B, T, 1, C, qk, 2 * C, bias=cb, splitk=sc, out2=vt, out2_ld=T, n_split=2 * C,
+                               ln_stats=stats, ln_s=s), None)
+        check(f"lnfold_qk_M{M}_C{C}_s{sc}", qk.reshape(M, 2 * C), full[:, : 2 * C], rel_l2=2e-3)
+        check(f"lnfold_vt_M{M}_C{C}_s{sc}", vt, full[:, 2 * C:].reshape(B, T, C).permute(0, 2, 1), rel_l2=2e-3)
+
+
 # --------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, heads):
     b, n, c = q.shape
