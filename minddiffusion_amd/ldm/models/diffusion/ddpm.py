@@ -106,11 +106,16 @@ class LatentDiffusion:
         c_concat, c_crossattn = self._split_cond(cond, c_concat, c_crossattn)
         return self.model(x_noisy, t, c_concat=c_concat, c_crossattn=c_crossattn)
 
-    def apply_model_nhwc(self, x_noisy, t, cond):
+    def apply_model_nhwc(self, x_noisy, t, cond, temb=None):
         """Fast path used by the samplers: returns the UNet's static NHWC fp16 eps buffer [B, H*W, 8]
         (valid until the next call) so the fused sampler-step kernel can consume it without a layout pass.
-        `x_noisy` already carries the c_concat channels for hybrid conditioning (the sampler writes them once)."""
-        return self.unet.forward_nhwc(x_noisy, t, cond)
+        `x_noisy` already carries the c_concat channels for hybrid conditioning (the sampler writes them once).
+        temb: the row of time_embedding_table() that belongs to `t` (optional)."""
+        return self.unet.forward_nhwc(x_noisy, t, cond, temb=temb)
+
+    def time_embedding_table(self, t):
+        """UNetModel.time_embedding_table: the timestep-only part of the UNet for all steps of a run, batched."""
+        return self.unet.time_embedding_table(t)
 
     # ---- ddpm.py:197-200
     def q_sample(self, x_start, t, noise=None):

@@ -14,6 +14,8 @@ Differences from the reference, both on the fp32 side of its fp16 arithmetic: th
 are float64 on the host (the reference casts the grid to fp16, dpm_solver.py:415), and x stays fp32 (sampler.py:88
 casts the start noise to fp16).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -32,9 +34,9 @@ class DPMSolverSampler:
     def register_buffer(self, name, attr):
         setattr(self, name, attr)
 
-    def _eps_nhwc(self, x, t, cond):
+    def _eps_nhwc(self, x, t, cond, temb=None):
         if hasattr(self.model, "apply_model_nhwc"):
-            return self.model.apply_model_nhwc(x, t, cond)
+            return self.model.apply_model_nhwc(x, t, cond, **({} if temb is None else {"temb": temb}))
         e = self.model.apply_model(x, t, cond).to(torch.float32).contiguous()
         return ops.nchw_to_nhwc(e, 8)
 
@@ -71,17 +73,22 @@ class DPMSolverSampler:
 
         ns = NoiseScheduleVP("discrete", alphas_cumprod=self.alphas_cumprod)
         plan = multistep_2m_plan(ns, S, order=2, lower_order_final=True)
-        t_all = torch.tensor([p["t_input"] for p in plan], dtype=torch.float32, device=dev)[:, None].expand(S, nb).contiguous()
+        t_all = torch.tensor([p["t_input"] for p in plan], dtype=torch.float32, device=dev)
+        # timestep-only part of the UNet for all S (fractional) timesteps in one batched pass (see PLMSSampler)
+        temb_all = None
+        if hasattr(self.model, "time_embedding_table") and os.environ.get("MDX_SAMPLER_TEMB_TABLE", "1") != "0":
+            temb_all = self.model.time_embedding_table(t_all)
+        t_all = t_all[:, None].expand(S, nb).contiguous()
         x0_bufs = [torch.empty_like(img), torch.empty_like(img)]    # data predictions at the last two grid points
         x_next = torch.empty_like(img)
         for k, p in enumerate(plan):
             if use_cfg:
                 x_in[:b].copy_(img)
                 x_in[b:].copy_(img)
-                eps = self._eps_nhwc(x_in, t_all[k], c_in)
+                eps = self._eps_nhwc(x_in, t_all[k], c_in, None if temb_all is None else temb_all[k])
                 eps_u, eps_c = eps[:b], eps[b:]
             else:
-                eps_u, eps_c = None, self._eps_nhwc(img, t_all[k], c_in)
+                eps_u, eps_c = None, self._eps_nhwc(img, t_all[k], c_in, None if temb_all is None else temb_all[k])
             cur, prev = x0_bufs[k & 1], x0_bufs[(k & 1) ^ 1]
             f = np.float32
             ops.sampler_step(img, eps_u, eps_c, eps_c.shape[-1], scale, [], (1., 0., 0., 0.),

@@ -12,6 +12,8 @@ Same class name, constructor and ``sample(...)`` keyword surface.  What changes 
 Results are identical in structure to the reference (S+1 UNet calls for PLMS, intermediates dict,
 callbacks once per step).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -92,9 +94,9 @@ class _SamplerBase:
 
     # ---- model call: prefer the NHWC fast path of our LatentDiffusion; any object with the reference's
     #      apply_model(x, t, cond) -> NCHW eps still works (its output is re-laid-out by a HIP kernel).
-    def _eps_nhwc(self, x, t, cond):
+    def _eps_nhwc(self, x, t, cond, temb=None):
         if hasattr(self.model, "apply_model_nhwc"):
-            return self.model.apply_model_nhwc(x, t, cond), None
+            return self.model.apply_model_nhwc(x, t, cond, **({} if temb is None else {"temb": temb})), None
         e = self.model.apply_model(x, t, cond)
         e = e.to(torch.float32).contiguous()
         buf = ops.nchw_to_nhwc(e, 8)
@@ -153,6 +155,11 @@ class _SamplerBase:
             x0 = torch.as_tensor(x0).to(device=dev, dtype=torch.float32)
         # per-step timestep vectors, fp32 on the device (the UNet's sinusoid takes float timesteps, util.py:111-131)
         t_all = torch.as_tensor(np.ascontiguousarray(time_range), dtype=torch.float32, device=dev)
+        # the timestep-only part of the UNet (time_embed MLP + the ResBlock emb_layers, openaimodel.py:550-551,188) for
+        # ALL steps in one batched pass; step i then hands row i to the UNet instead of recomputing it
+        temb_all = None
+        if hasattr(self.model, "time_embedding_table") and os.environ.get("MDX_SAMPLER_TEMB_TABLE", "1") != "0":
+            temb_all = self.model.time_embedding_table(t_all)
         t_all = t_all[:, None].expand(total_steps, nb).contiguous()
 
         alphas, alphas_prev = self.ddim_alphas, self.ddim_alphas_prev
@@ -163,17 +170,18 @@ class _SamplerBase:
         pred_x0 = torch.empty_like(img)
         x_next = torch.empty_like(img)
 
-        def model_eps(x, t_row):
+        def model_eps(x, i):
+            t_row, temb = t_all[i], (None if temb_all is None else temb_all[i])
             if use_cfg:
                 x_in[:b, :cx].copy_(x)
                 x_in[b:, :cx].copy_(x)
-                eps, keep = self._eps_nhwc(x_in, t_row, c_in)
+                eps, keep = self._eps_nhwc(x_in, t_row, c_in, temb)
                 return eps[:b], eps[b:], keep           # batch = [uncond ; cond] (plms.py:192-195)
             if x_in is not None:
                 x_in[:, :cx].copy_(x)
-                eps, keep = self._eps_nhwc(x_in, t_row, c_in)
+                eps, keep = self._eps_nhwc(x_in, t_row, c_in, temb)
                 return None, eps, keep
-            eps, keep = self._eps_nhwc(x, t_row, c_in)
+            eps, keep = self._eps_nhwc(x, t_row, c_in, temb)
             return None, eps, keep
 
         def step(x, eps_u, eps_c, index, coef, olds, e_out, x_out, p_out):
@@ -196,7 +204,7 @@ class _SamplerBase:
                     noise = torch.randn(x0.shape, device=dev, dtype=torch.float32, generator=self.generator)
                 img_orig = self.model.q_sample(x0, ts, noise)
                 img = img_orig * mask + (1. - mask) * img
-            eps_u, eps_c, _keep = model_eps(img, t_all[i])
+            eps_u, eps_c, _keep = model_eps(img, i)
             if not self.multistep:
                 step(img, eps_u, eps_c, index, (1., 0., 0., 0.), [], None, x_next, pred_x0)
             else:
@@ -205,7 +213,7 @@ class _SamplerBase:
                 if n_old == 0:
                     # Pseudo Improved Euler (2nd order), plms.py:231-235: S+1 UNet calls in total
                     step(img, eps_u, eps_c, index, (1., 0., 0., 0.), [], e_buf, x_next, None)
-                    eps_u2, eps_c2, _keep2 = model_eps(x_next, t_all[min(i + 1, total_steps - 1)])
+                    eps_u2, eps_c2, _keep2 = model_eps(x_next, min(i + 1, total_steps - 1))
                     step(img, eps_u2, eps_c2, index, (.5, .5, 0., 0.), [e_buf], None, x_next, pred_x0)
                 elif n_old == 1:  # Adams-Bashforth 2, plms.py:236-238
                     step(img, eps_u, eps_c, index, (3. / 2, -1. / 2, 0., 0.), hist[:1], e_buf, x_next, pred_x0)

@@ -423,6 +423,7 @@ class UNetModel:
         emit(lambda: ops.dense_small(e1, w["te2.w"], w["te2.b"], out=emb), "small", 2 * B * ted * ted)
         emit(lambda: ops.dense_small(emb, w["emb.w"], w["emb.b"], act_in=True, out=P.emb_all), "small",
              2 * B * ted * self._emb_total)
+        P.temb_ops = len(main)   # main[:temb_ops] only fill P.emb_all: skipped when the caller hands the rows in
 
         xin = A.get((B, H * W, self.cin_pad))
         emit(lambda: ops.nchw_to_nhwc(P.x_static, self.cin_pad, out=xin), "small")
@@ -663,9 +664,24 @@ class UNetModel:
         if P.graph is not None and getattr(P, "graph_ctx_len", None) != T:
             P.graph = None
 
-    def forward_nhwc(self, x, timesteps, context):
+    def time_embedding_table(self, t):
+        """Everything the UNet derives from the timestep alone -- sinusoid, time_embed MLP and the 22 ResBlock
+        emb_layers (openaimodel.py:550-551, 150-157, 188) -- for ALL the steps of a sampling run in one batched pass:
+        t [S] -> [S, emb_total] fp32.  A sampler computes it once per sample() (the 51 MB of emb weights are then read
+        once per run instead of once per step) and passes row i to forward_nhwc(..., temb=row)."""
+        if self.w is None:
+            raise MdxError("UNetModel: load_state_dict() must be called before time_embedding_table()")
+        t = torch.as_tensor(t, dtype=f32).to(self.device).reshape(-1).contiguous()
+        w = self.w
+        e0 = ops.timestep_embedding(t, self.model_channels)
+        e1 = ops.dense_small(e0, w["te0.w"], w["te0.b"], act_out=True)
+        e2 = ops.dense_small(e1, w["te2.w"], w["te2.b"])
+        return ops.dense_small(e2, w["emb.w"], w["emb.b"], act_in=True)
+
+    def forward_nhwc(self, x, timesteps, context, temb=None):
         """Run the UNet; returns the plan's static NHWC fp16 eps buffer [B, H*W, 8] (first 4 channels valid).
-        The buffer is overwritten by the next call."""
+        The buffer is overwritten by the next call.  temb: optional row(s) of time_embedding_table() for `timesteps`
+        ([emb_total] or [B, emb_total]); the time-embedding launches are then skipped."""
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise MdxError("UNetModel: x must be a CUDA(HIP) tensor (no CPU fallback)")
         B, C, H, W = x.shape
@@ -674,15 +690,22 @@ class UNetModel:
         P = self._plan(B, H, W)
         self._ensure_context(P, context)
         P.x_static.copy_(x)
-        P.t_static.copy_(timesteps.to(device=self.device, dtype=f32) if isinstance(timesteps, torch.Tensor)
-                         else torch.as_tensor(timesteps, dtype=f32, device=self.device))
+        if temb is not None:
+            if temb.shape[-1] != self._emb_total or temb.dtype != f32:
+                raise MdxError(f"UNetModel: temb must be fp32 [.., {self._emb_total}] rows of time_embedding_table()")
+            P.emb_all.copy_(temb)          # [emb_total] broadcasts over the batch
+        else:
+            P.t_static.copy_(timesteps.to(device=self.device, dtype=f32) if isinstance(timesteps, torch.Tensor)
+                             else torch.as_tensor(timesteps, dtype=f32, device=self.device))
+            for op in P.main[:P.temb_ops]:
+                op()
         if self.use_graph and not P.graph_failed:
             if P.graph is None:
                 self._capture(P)
             if P.graph is not None:
                 P.graph.replay()
                 return P.eps_nhwc
-        for op in P.main:
+        for op in P.main[P.temb_ops:]:
             op()
         self.last_launch_count = len(P.main)
         return P.eps_nhwc
@@ -690,12 +713,13 @@ class UNetModel:
     def _capture(self, P):
         """Capture the whole forward as one hipGraph (kills ~450 launch gaps per call)."""
         try:
-            for op in P.main:  # warm-up outside capture
+            body = P.main[P.temb_ops:]   # the graph starts from P.emb_all (filled eagerly or from the sampler's table)
+            for op in body:  # warm-up outside capture
                 op()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for op in P.main:
+                for op in body:
                     op()
             P.graph = g
             P.graph_ctx_len = P.ctx_len

@@ -276,6 +276,32 @@ def test_context_cache_is_not_fooled_by_address_reuse():
     assert not torch.equal(out_a, out_b)
 
 
+@pytest.mark.parametrize("graph", [True, False])
+def test_time_embedding_table_rows_equal_per_call_embedding(graph):
+    """UNetModel.time_embedding_table batches the timestep-only part of the UNet (sinusoid, time_embed MLP, the ResBlock
+    emb_layers: openaimodel.py:550-551, 150-157, 188) over all steps of a run; a call that is handed row i must give
+    bit-identical eps to the call that recomputes it from t[i] (integer and DPM-Solver's fractional timesteps)."""
+    cfg = _tiny_cfg()
+    params = O.init_params(_oracle_cfg(cfg), seed=8)
+    net = _build(cfg, params, graph)
+    x, ctx = _inputs(2, 8, 8, 7, cfg["context_dim"], seed=9)
+    xd, cd = torch.tensor(x, device=DEV), torch.tensor(ctx, device=DEV)
+    ts = torch.tensor([981.0, 501.0, 500.25, 1.0, 0.0] + [float(v) for v in range(3, 40, 4)], device=DEV)
+    table = net.time_embedding_table(ts)
+    assert table.shape == (ts.numel(), net._emb_total) and table.dtype == torch.float32
+    for i in (0, 2, 4, 9):
+        ref = net.forward_nhwc(xd, ts[i].expand(2), cd).clone()
+        got = net.forward_nhwc(xd, None, cd, temb=table[i]).clone()
+        assert torch.equal(ref, got), f"row {i}"
+        got2 = net.forward_nhwc(xd, None, cd, temb=table[i][None].expand(2, -1)).clone()
+        assert torch.equal(ref, got2)
+    # different rows per batch element == different timesteps per batch element
+    mixed = net.forward_nhwc(xd, None, cd, temb=table[[1, 3]]).clone()
+    assert torch.equal(mixed, net.forward_nhwc(xd, ts[[1, 3]], cd))
+    with pytest.raises(Exception):
+        net.forward_nhwc(xd, None, cd, temb=table[0][:-1])
+
+
 def test_plan_buffers_survive_allocator_churn():
     """Regression: GEMM descriptors hold raw device pointers, so the plan must own its activation buffers
     (they used to be freed with the planning arena and recycled by the caching allocator)."""
