@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--split", type=int, default=0)
     ap.add_argument("--warm", action="store_true", help="do not flush the caches: operands and output stay resident")
+    ap.add_argument("--only", default="", help="comma list of shape-name substrings")
     args = ap.parse_args()
     from minddiffusion_amd import ops, _lib
     lib = _lib.load()
@@ -79,6 +80,8 @@ def main():
               ("conv32_640_640", 32, 32, 640, 640, 3), ("conv64_320_320", 64, 64, 320, 320, 3),
               ("ff2_16_5120_1280", 16, 16, 5120, 1280, 1), ("geglu32_640", 32, 32, 640, 5120, 1)]
     for name, H, W, cin, cout, ks in shapes:
+        if args.only and not any(o in name for o in args.only.split(",")):
+            continue
         trace_one(ops, lib, name, B, H, W, cin, cout, ks, args.split, flush_caches=not args.warm)
 
 

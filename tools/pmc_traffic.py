@@ -27,7 +27,7 @@ def family(name):
         return "splitk_reduce"
     if "attn_kernel" in name:
         return "attention"
-    if "gn_stats" in name or "gn_apply" in name:
+    if "gn_stats" in name or "gn_apply" in name or "gn_fused" in name:
         return "groupnorm"
     if "ln_kernel" in name:
         return "layernorm"
