@@ -380,15 +380,22 @@ void gn_geometry(GnParams& p) {
     int cw = (64 / L) * L;
     if (cw == 0) cw = L;                            // a single group wider than 64 chunks (cpg > 512): one group/block
     if (cw > p.CC) cw = p.CC;
-    p.cw = cw;
-    p.ncb = (p.CC + cw - 1) / cw;
-    int nblk = (GN_TARGET_BLOCKS + p.ncb * p.B - 1) / (p.ncb * p.B);
     // every gn_apply block re-folds all slab partials of its groups: keep the fold short for the UNet's small tensors
     // (measured: 256 slabs cost the 64x64-latent UNet +17 % GroupNorm time) and only widen for image-sized ones
     // (VAE decoder at 256^2 / 512^2, GLIDE super-resolution), which otherwise leave 3/4 of the CUs idle
     const int cap = p.HW >= 16384 ? GN_MAX_NBLK : 64;   // keep in step with mdx_groupnorm_ws_floats
-    if (nblk > cap) nblk = cap;
     const int max_by_pix = (p.HW + 3) / 4;          // at least ~4 pixels per slab
+    // Wide column blocks give the longest contiguous runs per pixel, but at UNet batch 2 the slab cap then leaves a
+    // 64x64x320 tensor with 128 blocks for 256 CUs: narrow the column blocks (whole groups at a time) until the grid
+    // has >= 512 blocks (measured -1.4 % on the whole UNet evaluation at batch 2; batch 16 already has 1024 and
+    // loses 1 % with narrow columns, so it keeps the wide ones)
+    static const int min_blocks = getenv("MDX_GN_MIN_BLOCKS") ? atoi(getenv("MDX_GN_MIN_BLOCKS")) : 512;
+    const int slabs = cap < max_by_pix ? cap : max_by_pix;
+    while (cw > L && ((p.CC + cw - 1) / cw) * p.B * slabs < min_blocks) cw -= L;
+    p.cw = cw;
+    p.ncb = (p.CC + cw - 1) / cw;
+    int nblk = (GN_TARGET_BLOCKS + p.ncb * p.B - 1) / (p.ncb * p.B);
+    if (nblk > cap) nblk = cap;
     if (nblk > max_by_pix) nblk = max_by_pix;
     if (nblk < 1) nblk = 1;
     p.pix = (p.HW + nblk - 1) / nblk;
