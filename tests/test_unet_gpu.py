@@ -219,6 +219,33 @@ def test_sd2_full_size_single_step():
     check("sd2_full_single_step_B1_64x64", got, ref, rel_l2=5e-3, max_abs=5e-2)
 
 
+def test_sd2_full_size_ddim_cfg_trajectory():
+    """BASELINE config 1 at full size, shortened to 4 DDIM steps (the step count must divide 1000, util.py:134-148): SDv2 UNet, 64x64 latent, CFG 9.0 (UNet batch 2), the
+    sampler's per-run time-embedding table and the captured hipGraph -- the exact code path bench.py times -- against the
+    fp32 CPU oracle's sampler on the same seeded weights (8 UNet row evaluations on the host, about a minute).
+    Tolerance: fp16 storage over four chained evaluations with guidance scale 9 amplifying eps differences."""
+    from minddiffusion_amd.configs import SD2_UNET
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from minddiffusion_amd.ldm.models.diffusion.ddim import DDIMSampler
+    import os
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    params = O.init_params(O.SD2_UNET, seed=4)
+    net = _build(dict(SD2_UNET), params, True)
+    model = LatentDiffusion(net, linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    omodel = O.ModelOracle(O.UNetOracle(O.SD2_UNET, params))
+    S, scale = 4, 9.0
+    x_T = np.random.RandomState(42).randn(1, 4, 64, 64).astype(np.float32)
+    c = np.random.RandomState(1).randn(1, 77, 1024).astype(np.float32)
+    uc = np.random.RandomState(2).randn(1, 77, 1024).astype(np.float32)
+    ref, ref_inter = O.sample(omodel, S, 1, (4, 64, 64), c, x_T, "ddim", unconditional_guidance_scale=scale,
+                              unconditional_conditioning=uc)
+    got, inter = DDIMSampler(model).sample(S, 1, (4, 64, 64), conditioning=torch.tensor(c, device=DEV),
+                                           x_T=torch.tensor(x_T, device=DEV), unconditional_guidance_scale=scale,
+                                           unconditional_conditioning=torch.tensor(uc, device=DEV), verbose=False)
+    check("sd2_full_ddim4_cfg9_latent", got, ref, rel_l2=1e-2, max_rel=2e-2)
+    check("sd2_full_ddim4_cfg9_pred_x0", inter["pred_x0"][-1], ref_inter["pred_x0"][-1], rel_l2=2e-2)
+
+
 def test_sd2_768_single_step():
     """BASELINE config 3 building block: the SDv2 UNet on a 96x96 latent (768x768 px): levels 96/48/24/12, so the
     24x24 and 12x12 convs fall off the 8x16-patch HALO kernel onto the generic implicit-GEMM path, and the
