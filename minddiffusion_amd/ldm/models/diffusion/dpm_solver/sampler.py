@@ -50,7 +50,8 @@ class DPMSolverSampler:
         if cond.shape[0] != batch_size:
             print(f"Warning: Got {cond.shape[0]} conditionings but batch-size is {batch_size}")
         if mask is not None or x0 is not None:
-            raise NotImplementedError("mask/x0 blending is the inpainting path: SURVEY 8(f) item 4")
+            raise NotImplementedError("mask/x0 blending is implemented by PLMSSampler / DDIMSampler (WK inpaint.py uses PLMS); "
+                                      "the reference never passes it to DPMSolverSampler")
         if not (isinstance(cond, torch.Tensor) and cond.is_cuda):
             raise MdxError("conditioning must be a CUDA(HIP) tensor [B, T, context_dim]")
         dev = cond.device
