@@ -49,6 +49,7 @@ struct GemmParams {
     const float* ln_stats;   // consumer: [M][ln_nt][2] written by the producer
     const float* ln_s;       // consumer: S[n] = sum_k (gamma (.) W)[n][k], fp32 [N]
     int ln_nt;
+    int spread;              // gemm_kernel: 1-D grid of (tile, split) items dealt round-robin to the XCDs
     float ln_eps;
     long out_bs;   // element stride between samples of a row-major output (0 = dense [M][out_ld])
     int B, H, W, Ho, Wo, HoWo, M, N, K;
@@ -437,8 +438,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
 
     // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (per-XCD L2s are private), so give every
     // XCD a CONTIGUOUS run of tile ids; ids run fastest along the dimension that shares the bigger operand.
-    const int tile_id = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
-    if (tile_id >= p.tiles_m * p.tiles_n) return;
+    // SPREAD order (one row of M tiles, i.e. no two blocks share a weight tile): consecutive block ids -- consecutive
+    // XCDs -- take consecutive (tile, split) items, so the weight stream is pulled through all 8 XCDs' fabric links
+    // even when there are only 10 N tiles (the contiguous order would park them on 5 XCDs and leave 3 idle).
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int tile_id = p.spread ? (int)(blockIdx.x % (unsigned)ntiles) : (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile_id >= ntiles) return;
     trace_mark(p, 0);
     int tile_m, tile_n;
     if (p.n_fastest) {
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
         tile_m = tile_id - tile_n * p.tiles_m;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int split = blockIdx.y;
+    const int split = p.spread ? (int)(blockIdx.x / (unsigned)ntiles) : (int)blockIdx.y;
     const int kt_begin = split * p.ktiles_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
 
@@ -1317,6 +1322,9 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     // share the bigger operand inside an XCD: unique activation bytes vs weight bytes
     p.n_fastest = ((size_t)p.M * p.cin >= (size_t)p.N * p.K) ? 1 : 0;
     dim3 grid(8 * p.tiles_per_xcd, ns);
+    static const int spread_env = getenv("MDX_GEMM_SPREAD") ? atoi(getenv("MDX_GEMM_SPREAD")) : 1;
+    p.spread = (!halo && p.tiles_m == 1 && spread_env) ? 1 : 0;
+    if (p.spread) grid = dim3(ntiles * ns, 1);
     p.trace = (g_gemm_trace && (size_t)grid.x * grid.y <= g_gemm_trace_slots) ? g_gemm_trace : nullptr;
     GemmCfg cc = c;
     if (!getenv("MDX_GEMM_CFG")) {
