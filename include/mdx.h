@@ -120,6 +120,8 @@ typedef struct mdx_gemm_desc {
     const float* ln_s;
     int ln_nt;
     float ln_eps;
+    int tile_m;           /* 0 = auto (tuned table, then the cost model); 64 | 128 forces the M tile.  For tools/tune_gemm.py,
+                             which measures the (tile_m, splitk) candidates of every UNet shape on the device. */
 } mdx_gemm_desc;
 
 #define MDX_EPI_NONE 0

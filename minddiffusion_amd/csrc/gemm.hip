@@ -1120,8 +1120,24 @@ struct Tiling {
     int bm, ns;
 };
 
-Tiling choose_tiling(const GemmParams& p, int bn, int forced_ns) {
+// Measured (tile_m, splitk) per UNet shape: tools/tune_gemm.py times every candidate on the device with cold weights
+// and writes gemm_tuned.inc.  Shapes that are not in the table fall through to the cost model below.
+struct TunedEntry {
+    int M, N, K, ksize, bm, ns;
+};
+static const TunedEntry g_tuned[] = {
+#include "gemm_tuned.inc"
+    {0, 0, 0, 0, 0, 0}};
+
+Tiling choose_tiling(const GemmParams& p, int bn, int forced_ns, int forced_bm) {
     static const char* envbm = getenv("MDX_GEMM_BM");
+    static const bool use_table = !(getenv("MDX_GEMM_TUNED") && atoi(getenv("MDX_GEMM_TUNED")) == 0);
+    if (use_table && forced_ns <= 0 && forced_bm <= 0 && !envbm && !getenv("MDX_GEMM_BN")) {
+        for (const TunedEntry* e = g_tuned; e->M; ++e)
+            if (e->M == p.M && e->N == p.N && e->K == p.K && e->ksize == p.ksize && p.stride == 1 && !p.upsample) {
+                if (e->bm >= 128 || !halo_eligible(p, 128)) return Tiling{e->bm, e->ns};
+            }
+    }
     const int kt = (p.K + 63) / 64;
     const int chunks = p.cin / 64;
     const double slab_mb = (double)p.M * p.N * 4.0 / 1048576.0;
@@ -1132,12 +1148,13 @@ Tiling choose_tiling(const GemmParams& p, int bn, int forced_ns) {
     for (int oi = 0; oi < 3; ++oi) {
         const int bm = order[oi];
         if (envbm && atoi(envbm) != bm) continue;
+        if (forced_bm > 0 && forced_bm != bm) continue;
         const bool halo = bm >= 128 && halo_eligible(p, bm);
         // 256-row tiles exist for the HALO kernel only and are opt-in (MDX_GEMM_BM=256): measured on MI355X they move
         // 45 % fewer DMA bytes per MAC yet run no faster than two co-resident 128-row blocks (profiles/
         // r01_halo256_ab.txt) -- the K-step's barrier/issue structure, not the DMA rate, is what bounds this kernel
         if (bm == 256 && (!halo || !envbm)) continue;
-        if (bm == 64 && halo_eligible(p, 128) && !envbm) continue;  // HALO beats the generic kernel on every conv
+        if (bm == 64 && halo_eligible(p, 128) && !envbm && forced_bm <= 0) continue;  // HALO beats the generic kernel on every conv
         const int tiles = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
         // us per K-tile step of one block running alone on its CU (tools/gemm_trace.py): fewer DMA instructions and
         // MFMAs per step for the smaller tiles and for the HALO kernel (one activation DMA per 9 taps)
@@ -1262,7 +1279,7 @@ extern "C" size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d) {
     GemmParams p{};
     if (fill_params(d, p) != MDX_OK) return 0;
     const GemmCfg c = pick_cfg(p);
-    const int ns = choose_tiling(p, c.bn, d->splitk).ns;
+    const int ns = choose_tiling(p, c.bn, d->splitk, d->tile_m).ns;
     return ns > 1 ? (size_t)ns * p.M * p.N * sizeof(float) : 0;
 }
 
@@ -1284,7 +1301,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     const int bn = c.bn;
     p.bk = c.bk;
     p.ktiles = (p.K + c.bk - 1) / c.bk;
-    const Tiling tl = choose_tiling(p, bn, d->splitk);
+    const Tiling tl = choose_tiling(p, bn, d->splitk, d->tile_m);
     c.bm = tl.bm;
     int ns = tl.ns;
     if (ns > p.ktiles) ns = p.ktiles;
