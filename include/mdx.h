@@ -122,6 +122,7 @@ typedef struct mdx_gemm_desc {
     float ln_eps;
     int tile_m;           /* 0 = auto (tuned table, then the cost model); 64 | 128 forces the M tile.  For tools/tune_gemm.py,
                              which measures the (tile_m, splitk) candidates of every UNet shape on the device. */
+    int tile_n;           /* 0 = auto; 64 | 128 forces the N tile (same purpose; GEGLU always uses 128) */
 } mdx_gemm_desc;
 
 #define MDX_EPI_NONE 0

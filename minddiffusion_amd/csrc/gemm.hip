@@ -49,6 +49,7 @@ struct GemmParams {
     const float* ln_stats;   // consumer: [M][ln_nt][2] written by the producer
     const float* ln_s;       // consumer: S[n] = sum_k (gamma (.) W)[n][k], fp32 [N]
     int ln_nt;
+    int bn_hint;             // mdx_gemm_desc.tile_n
     int spread;              // gemm_kernel: 1-D grid of (tile, split) items dealt round-robin to the XCDs
     float ln_eps;
     long out_bs;   // element stride between samples of a row-major output (0 = dense [M][out_ld])
@@ -1001,6 +1002,7 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     p.ln_s = d->ln_s;
     p.ln_nt = d->ln_nt;
     p.ln_eps = d->ln_eps;
+    p.bn_hint = d->tile_n;
     p.out2_ld = d->out2_ld;
     p.n_split = d->n_split;
     p.ws = (float*)d->workspace;
@@ -1074,8 +1076,32 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     return MDX_OK;
 }
 
+// Measured (tile_m, tile_n, splitk) per UNet shape: tools/tune_gemm.py times every candidate on the device with cold
+// weights and writes gemm_tuned.inc.  Shapes that are not in the table fall through to pick_bn / the cost model.
+struct TunedEntry {
+    int M, N, K, ksize, bm, bn, ns;   // bn 0 = pick_bn's default
+};
+static const TunedEntry g_tuned[] = {
+#include "gemm_tuned.inc"
+    {0, 0, 0, 0, 0, 0, 0}};
+
+bool halo_eligible(const GemmParams& p, int bm);
+
+const TunedEntry* lookup_tuned(const GemmParams& p) {
+    static const bool use_table = !(getenv("MDX_GEMM_TUNED") && atoi(getenv("MDX_GEMM_TUNED")) == 0) &&
+                                  !getenv("MDX_GEMM_BM") && !getenv("MDX_GEMM_BN");
+    if (!use_table || p.bn_hint || p.stride != 1 || p.upsample) return nullptr;
+    for (const TunedEntry* e = g_tuned; e->M; ++e)
+        if (e->M == p.M && e->N == p.N && e->K == p.K && e->ksize == p.ksize)
+            return (e->bm >= 128 || !halo_eligible(p, 128)) ? e : nullptr;
+    return nullptr;
+}
+
 int pick_bn(const GemmParams& p) {
     if (p.epilogue == MDX_EPI_GEGLU) return 128;
+    if (p.bn_hint == 64 || p.bn_hint == 128) return p.bn_hint;
+    if (const TunedEntry* e = lookup_tuned(p))
+        if (e->bn) return e->bn;
     static const char* envbn = getenv("MDX_GEMM_BN");
     if (envbn && (atoi(envbn) == 64 || atoi(envbn) == 128)) return atoi(envbn);
     if (p.N % 128 == 0) return 128;
@@ -1120,24 +1146,10 @@ struct Tiling {
     int bm, ns;
 };
 
-// Measured (tile_m, splitk) per UNet shape: tools/tune_gemm.py times every candidate on the device with cold weights
-// and writes gemm_tuned.inc.  Shapes that are not in the table fall through to the cost model below.
-struct TunedEntry {
-    int M, N, K, ksize, bm, ns;
-};
-static const TunedEntry g_tuned[] = {
-#include "gemm_tuned.inc"
-    {0, 0, 0, 0, 0, 0}};
-
 Tiling choose_tiling(const GemmParams& p, int bn, int forced_ns, int forced_bm) {
     static const char* envbm = getenv("MDX_GEMM_BM");
-    static const bool use_table = !(getenv("MDX_GEMM_TUNED") && atoi(getenv("MDX_GEMM_TUNED")) == 0);
-    if (use_table && forced_ns <= 0 && forced_bm <= 0 && !envbm && !getenv("MDX_GEMM_BN")) {
-        for (const TunedEntry* e = g_tuned; e->M; ++e)
-            if (e->M == p.M && e->N == p.N && e->K == p.K && e->ksize == p.ksize && p.stride == 1 && !p.upsample) {
-                if (e->bm >= 128 || !halo_eligible(p, 128)) return Tiling{e->bm, e->ns};
-            }
-    }
+    if (forced_ns <= 0 && forced_bm <= 0)
+        if (const TunedEntry* e = lookup_tuned(p)) return Tiling{e->bm, e->ns};
     const int kt = (p.K + 63) / 64;
     const int chunks = p.cin / 64;
     const double slab_mb = (double)p.M * p.N * 4.0 / 1048576.0;
