@@ -197,7 +197,7 @@ def cpu_baseline(n_evals=1):
     }
 
 
-PMC_FILE = "r01_p_pmc_traffic.json"
+PMC_FILE = "r01_q_pmc_traffic.json"
 
 
 def pmc_traffic():

@@ -15,6 +15,7 @@ python tools/pmc_traffic.py gpurun_out/pmc > $OUT/${TAG}_pmc_traffic.json 2>$OUT
 rm -rf gpurun_out/pmc
 
 timeout 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > $OUT/pytest_gpu.txt
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" > $OUT/smoke.txt 2>&1
 timeout 300 python bench.py > $OUT/${TAG}_bench.json 2>$OUT/bench.err
 timeout 100 python tools/op_profile.py --batch 2 > $OUT/${TAG}_op_profile_b2.txt 2>&1
 
