@@ -40,7 +40,7 @@ def time_desc(ops, d, flush, reps):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="sd2", choices=["sd2", "wukong"])
+    ap.add_argument("--model", default="sd2", choices=["sd2", "wukong", "glide", "vae"])
     ap.add_argument("--batch", type=int, default=2, help="UNet batch (2 x images under CFG)")
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--reps", type=int, default=7)
@@ -53,22 +53,41 @@ def main():
     from minddiffusion_amd import ops
     from minddiffusion_amd._lib import GemmDesc
     dev = torch.device("cuda:0")
-    net = bench.build_model(dev, args.model).unet
     B, h = args.batch, args.latent
-    ctx = torch.randn(B, 77, net.context_dim, device=dev, dtype=torch.float16)
-    x = torch.randn(B, 4, h, h, device=dev)
-    net.use_graph = False
-    net.forward_nhwc(x, torch.full((B,), 500.0, device=dev), ctx)      # sane values in every activation buffer
+    plans = []      # one forward each, so that every activation buffer holds sane values
+    if args.model in ("sd2", "wukong"):
+        net = bench.build_model(dev, args.model).unet
+        ctx = torch.randn(B, 77, net.context_dim, device=dev, dtype=torch.float16)
+        net.use_graph = False
+        net.forward_nhwc(torch.randn(B, 4, h, h, device=dev), torch.full((B,), 500.0, device=dev), ctx)
+        plans.append(net._plan(B, h, h))
+    elif args.model == "glide":     # bench.py glide_256: base at UNet batch 2P (64x64), super-res at P (256x256)
+        dm, sr = bench.build_glide(dev)
+        Pn = bench.CONFIGS["glide_256"]["batch"]
+        tok = torch.randint(1, 50000, (2 * Pn, 128), device=dev)
+        msk = torch.ones((2 * Pn, 128), dtype=torch.bool, device=dev)
+        for m in (dm.model, sr.model):
+            m.use_graph = False
+        dm.model.forward_nhwc(torch.randn(2 * Pn, 3, 64, 64, device=dev), torch.full((2 * Pn,), 500.0, device=dev), tok, msk)
+        plans.append(dm.model._plan(2 * Pn, 64, 64))
+        sr.model.forward_nhwc(torch.randn(Pn, 3, 256, 256, device=dev), torch.full((Pn,), 500.0, device=dev), tok[:Pn], msk[:Pn],
+                              low_res=torch.randn(Pn, 3, 64, 64, device=dev))
+        plans.append(sr.model._plan(Pn, 256, 256))
+        B, h = Pn, 256
+    else:                           # AutoencoderKL.decode of B latents (bench.py sd2_512_images / _e2e)
+        vae = bench.build_vae(dev)
+        vae.decode(torch.randn(B, 4, h, h, device=dev))
+        plans.append(vae.decoder._plan(B, h, h))
     torch.cuda.synchronize()
-    P = net._plan(B, h, h)
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
     shapes = {}
-    for d in P.descs:
-        if d.stride != 1 or d.upsample:
-            continue
-        M, N, K = d.B * d.H * d.W, d.N, d.ksize * d.ksize * (d.c1 + d.c2)
-        shapes.setdefault((M, N, K, d.ksize), d)
-    big_ws = torch.empty((96 << 20) // 4, dtype=torch.float32, device=dev)
+    for P in plans:
+        for d in P.descs:
+            if d.stride != 1 or d.upsample:
+                continue
+            M, N, K = d.B * d.H * d.W, d.N, d.ksize * d.ksize * (d.c1 + d.c2)
+            shapes.setdefault((M, N, K, d.ksize), d)
+    big_ws = torch.empty((256 << 20) // 4, dtype=torch.float32, device=dev)
     lines, log = [], []
     for (M, N, K, ks), d0 in sorted(shapes.items()):
         kt = (K + 63) // 64
