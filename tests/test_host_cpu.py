@@ -266,3 +266,44 @@ def test_mindspore_checkpoint_reader_roundtrip(tmp_path):
     value = bytes([0x0A, 1]) + b"b" + bytes([0x12, len(tensor)]) + tensor
     open(p2, "wb").write(bytes([0x0A, len(value)]) + value)
     np.testing.assert_array_equal(C.load_checkpoint(p2)["b"], np.array([1.0, -2.5, 3.0], np.float32))
+
+
+def test_layernorm_fold_host_algebra():
+    """ops.fold_layernorm (host side of mdx_gemm_desc.ln_stats): LN(x; gamma, beta) W^T + b must equal
+    rstd * (x (gamma (.) W)^T - mean * S) + (W beta + b) -- checked in float64 on rows whose mean is as large as
+    their spread, with the fp16 rounding of gamma (.) W taken into account on both sides (BasicTransformerBlock
+    attention.py:176-185)."""
+    from minddiffusion_amd import ops
+    rng = np.random.RandomState(0)
+    M, K, N = 16, 128, 64
+    x = torch.tensor(rng.standard_normal((M, K)) * 1.5 + 1.0).half().double()
+    w = torch.tensor(rng.standard_normal((N, K)) / np.sqrt(K)).half()
+    g = torch.tensor(1 + 0.3 * rng.standard_normal(K), dtype=torch.float32)
+    be = torch.tensor(0.3 * rng.standard_normal(K), dtype=torch.float32)
+    b = torch.tensor(rng.standard_normal(N), dtype=torch.float32)
+    wg, s, cb = ops.fold_layernorm(w, g, be, b)
+    assert wg.dtype == torch.float16 and s.shape == (N,) and cb.shape == (N,)
+    mean = x.mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(((x - mean) ** 2).mean(1, keepdim=True) + 1e-5)
+    folded = rstd * (x @ wg.double().T - mean * s.double()) + cb.double()
+    # reference with the SAME fp16-rounded gamma (.) W, i.e. the only approximation the fold introduces is that rounding
+    exact = ((x - mean) * rstd) @ wg.double().T + (w.double() @ be.double() + b.double())
+    assert float((folded - exact).abs().max()) < 1e-5      # S is summed in float64 and stored in fp32: ~1e-7 * |mean * S|
+    plain = ((x - mean) * rstd * g.double() + be.double()) @ w.double().T + b.double()
+    assert float((folded - plain).abs().max()) < 5e-3      # fp16 rounding of gamma (.) W (2^-11 relative per weight)
+
+
+def test_tuned_tile_table_is_well_formed():
+    """csrc/gemm_tuned.inc (tools/tune_gemm.py): one {M, N, K, ksize, tile_m, tile_n, splitk} row per shape."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "minddiffusion_amd", "csrc",
+                        "gemm_tuned.inc")
+    seen = set()
+    for ln in open(path):
+        if ln.lstrip().startswith("//") or not ln.strip():
+            continue
+        m = re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},", ln)
+        assert m, ln
+        M, N, K, ks, bm, bn, ns = map(int, m.groups())
+        assert M > 0 and N % 8 == 0 and K > 0 and ks in (1, 3) and bm in (64, 128) and bn in (0, 64, 128) and 1 <= ns <= 32
+        assert (M, N, K, ks) not in seen, f"duplicate shape {ln}"
+        seen.add((M, N, K, ks))
