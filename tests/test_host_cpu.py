@@ -307,3 +307,30 @@ def test_tuned_tile_table_is_well_formed():
         assert M > 0 and N % 8 == 0 and K > 0 and ks in (1, 3) and bm in (64, 128) and bn in (0, 64, 128) and 1 <= ns <= 32
         assert (M, N, K, ks) not in seen, f"duplicate shape {ln}"
         seen.add((M, N, K, ks))
+
+
+def test_unet_plan_folds_layernorm_into_its_gemms(monkeypatch):
+    """With the LayerNorm fold (default) a transformer block issues no layernorm launch: proj_in / to_out carry
+    stats_out, the q|k|v, cross-attention q and GEGLU GEMMs carry ln_stats + ln_s.  MDX_UNET_LN_FOLD=0 restores the three
+    explicit launches per block (attention.py:176-185)."""
+    from minddiffusion_amd.configs import TINY_UNET
+    from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from minddiffusion_amd.weights import synthetic_unet_params_numpy
+
+    def plan(fold):
+        monkeypatch.setenv("MDX_UNET_LN_FOLD", "1" if fold else "0")
+        net = UNetModel(device="cpu", **TINY_UNET)
+        net.load_state_dict(synthetic_unet_params_numpy(net.parameter_shapes(), 0))
+        return net, net._plan(2, 8, 8)
+    net, P = plan(True)
+    blocks = sum(1 for k in net.w if k.endswith("attn2.q.w"))
+    assert blocks >= 3
+    assert sum(m["kind"] == "layernorm" for m in P.meta) == 0
+    assert sum(1 for d in P.descs if d.ln_stats) == 3 * blocks and sum(1 for d in P.descs if d.stats_out) == 3 * blocks
+    for d in P.descs:
+        if d.ln_stats:
+            assert d.ln_s and d.ln_nt * 64 == d.c1 and abs(d.ln_eps - 1e-5) < 1e-12 and d.bias
+    _, P0 = plan(False)
+    assert sum(m["kind"] == "layernorm" for m in P0.meta) == 3 * blocks
+    assert not any(d.ln_stats or d.stats_out for d in P0.descs)
+    assert len(P0.main) == len(P.main) + 3 * blocks
