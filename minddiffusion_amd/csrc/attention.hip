@@ -162,16 +162,24 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         const float m_new = fmaxf(m_run, mx);           // finite: tile 0 always has a visible key (key 0), so m_run is
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);  // first tile: exp2(-inf) = 0
         const float mb = m_new * p.scale_log2;
-        float psum = 0.f;
+        // two scores per instruction where the ISA has packed fp32 (v_pk_fma_f32 for x * scale - m, v_pk_add_f32 for the
+        // row sum): the softmax VALU work, not the MFMAs, bounds this kernel at D = 64
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 sc2 = {p.scale_log2, p.scale_log2}, nmb2 = {-mb, -mb};
+        f32x2 psum2 = {0.f, 0.f};
         f16x8 pf[4];  // B fragments for the 4 16-key chunks
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(acc_s[kt][r], p.scale_log2, -mb));
-                psum += pv;
-                pf[kt * 2 + (r >> 3)][r & 7] = (f16)pv;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 x2 = {acc_s[kt][r], acc_s[kt][r + 1]};
+                const f32x2 a2 = __builtin_elementwise_fma(x2, sc2, nmb2);
+                const f32x2 pv2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+                psum2 += pv2;
+                pf[kt * 2 + (r >> 3)][r & 7] = (f16)pv2.x;
+                pf[kt * 2 + (r >> 3)][(r & 7) + 1] = (f16)pv2.y;
             }
+        const float psum = psum2.x + psum2.y;
         l_run = l_run * alpha + psum;
         // rescale O only when some query of this wave saw a new maximum (alpha == 1 everywhere otherwise)
         if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {
