@@ -8,10 +8,13 @@
 //   S^T[key][q] = K Q^T     : MFMA 32x32x16 f16, A = K rows (ds_read_b128), B = Q (registers)
 //   online softmax           : every lane owns ONE query (col = lane&31) and 32 of the 64 keys,
 //                              so row max / row sum need a single lane^32 exchange
-//   O^T[d][q] += V^T P^T    : A = V^T rows (2 x ds_read_b64), B = P straight from the S^T
-//                              accumulator registers (the C layout of S^T IS the B layout of PV
-//                              under the key permutation kappa(c,hi,j) = 16c + 4hi + (j&3) + 8(j>>2);
-//                              the same permutation is applied to the V^T reads) -- no cross-lane moves.
+//   O^T[d][q] += V^T P^T    : A = V^T rows (one ds_read_b128 per fragment), B = P straight from the S^T
+//                              accumulator registers: the C layout of S^T IS the B layout of PV up to a
+//                              permutation of the keys inside a 32-key tile, and that permutation is undone
+//                              for free on the other side -- lane l31 of the QK^T MFMA multiplies K row
+//                              pi(l31) (bits 2 and 3 swapped), so accumulator register r of lane (q, hi) holds
+//                              key 16(r>>3) + 8hi + (r&7) and k index 8hi + j of PV chunk c is key 16c + 8hi + j:
+//                              contiguous in V^T -- no cross-lane moves, no register shuffles.
 // Head dims 40 / 64 / 80 / 160 (SDv2: 64; Wukong-Huahua: 8 heads => 40 / 80 / 160; GLIDE: 64).
 // V must be supplied TRANSPOSED ([b][h*D+d][key]); the projection GEMM writes it that way
 // (MDX_OUT_TRANSPOSED), which keeps every LDS read of this kernel wide and conflict-light.
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     float l_run = 0.f;        // lane-partial running sum
 
     const int vswz = (lane >> 1) & 7;
+    const int krow_l = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // pi(l31): swap bits 2 and 3
     const int ntiles = (p.Nk + BKV - 1) / BKV;
 
     // One KV tile.  BUF and MASK are compile-time so that every LDS address is (loop-invariant register + immediate)
@@ -128,13 +132,15 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         const char* sk = smem + BUF * STAGE;
         const char* sv = sk + K_BYTES;
 
-        // ---- S^T = K Q^T : two 32-key tiles
+        // ---- S^T = K Q^T : two 32-key tiles.  Lane l31 multiplies K row pi(l31) (bits 2 and 3 of the row swapped): S^T's
+        // accumulator rows then hold the keys in the order in which the PV MFMA wants them as its B operand -- k index
+        // 8*hi + j of chunk c <-> key 16c + 8*hi + j -- so a V^T fragment is ONE contiguous 16-B LDS read.
         f32x16 acc_s[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_s[kt][r] = 0.f;
-            const int krow = kt * 32 + l31;
+            const int krow = kt * 32 + krow_l;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + krow * K_ROWB + (((2 * s + hi) ^ kkey(krow)) << 4));
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int key = key0 + kt * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);   // pi(row)
                     if (key > kmax) acc_s[kt][r] = -INFINITY;
                 }
         }
@@ -195,12 +201,8 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                const char* vr = sv + (d * 32 + l31) * V_ROWB + 8 * hi;
-                const f16x4 lo = *reinterpret_cast<const f16x4*>(vr + (((2 * c) ^ vswz) << 4));
-                const f16x4 hi4 = *reinterpret_cast<const f16x4*>(vr + (((2 * c + 1) ^ vswz) << 4));
-                f16x8 vf;
-                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
+                const char* vr = sv + (d * 32 + l31) * V_ROWB;
+                const f16x8 vf = *reinterpret_cast<const f16x8*>(vr + (((2 * c + hi) ^ vswz) << 4));   // keys 16c + 8hi .. +7
                 acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c], acc_o[d], 0, 0, 0);
             }
         }
