@@ -164,7 +164,12 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc_s[kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        {   // lane <-> lane^32 exchange as ONE VALU instruction (gfx950 v_permlane32_swap) instead of an LDS round trip
+            // (ds_bpermute + lgkmcnt(0) sat on the critical path of every tile): after the swap the two results hold
+            // {own, partner} in some order in every lane, and max is symmetric
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         const float m_new = fmaxf(m_run, mx);           // finite: tile 0 always has a visible key (key 0), so m_run is
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);  // first tile: exp2(-inf) = 0
         const float mb = m_new * p.scale_log2;
