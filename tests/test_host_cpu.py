@@ -334,3 +334,26 @@ def test_unet_plan_folds_layernorm_into_its_gemms(monkeypatch):
     assert sum(m["kind"] == "layernorm" for m in P0.meta) == 3 * blocks
     assert not any(d.ln_stats or d.stats_out for d in P0.descs)
     assert len(P0.main) == len(P.main) + 3 * blocks
+
+
+def test_tuned_table_drives_the_split_choice():
+    """mdx_gemm_workspace_bytes (host only, no launch) must follow csrc/gemm_tuned.inc for the shapes it lists:
+    split-K slabs = splitk x M x N x 4 bytes (0 when the entry says one split)."""
+    from minddiffusion_amd import _lib, ops
+    lib = _lib.load()
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "minddiffusion_amd", "csrc",
+                        "gemm_tuned.inc")
+    rows = [tuple(map(int, m.groups())) for m in
+            (re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},", ln) for ln in open(path)) if m]
+    checked = 0
+    for M, N, K, ks, bm, bn, ns in rows:
+        if ks != 1 or M % 64 or K % 64:      # dense rows are enough to pin the hook-up (B=1, H=M tokens, W=1)
+            continue
+        a = torch.zeros((1,), dtype=torch.float16)      # pointers are never dereferenced on this path
+        d = ops.make_gemm_desc(a, a, N, 1, M, 1, K, a, N)
+        need = lib.mdx_gemm_workspace_bytes(ctypes.byref(d))
+        assert need == (ns * M * N * 4 if ns > 1 else 0), (M, N, K, ns, need)
+        checked += 1
+        if checked >= 12:
+            break
+    assert checked >= 6
