@@ -38,7 +38,7 @@ class DPMSolverSampler:
         if hasattr(self.model, "apply_model_nhwc"):
             return self.model.apply_model_nhwc(x, t, cond, **({} if temb is None else {"temb": temb}))
         e = self.model.apply_model(x, t, cond).to(torch.float32).contiguous()
-        return ops.nchw_to_nhwc(e, 8)
+        return ops.nchw_to_nhwc(e, (e.shape[1] + 7) // 8 * 8)
 
     def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
                quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0., score_corrector=None,

@@ -83,8 +83,13 @@ class _SamplerBase:
         size = (batch_size, C, H, W)
         if verbose:
             print(f'Data shape for {type(self).__name__} sampling is {size}')
+        # the reference's sample() always runs the S-step DDIM grid (plms.py:107-121); `timesteps` /
+        # `ddim_use_original_steps` are plms_sampling() options (plms.py:134-142) and are forwarded when given
         return self.plms_sampling(conditioning, size, callback=callback, img_callback=img_callback,
-                                  quantize_denoised=quantize_x0, mask=mask, x0=x0, ddim_use_original_steps=False,
+                                  quantize_denoised=quantize_x0, mask=mask, x0=x0,
+                                  ddim_use_original_steps=bool(kwargs.get("ddim_use_original_steps", False)),
+                                  timesteps=kwargs.get("timesteps"), dropout_masks=kwargs.get("dropout_masks"),
+                                  step_noises=kwargs.get("step_noises"),
                                   noise_dropout=noise_dropout, temperature=temperature,
                                   score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, x_T=x_T,
                                   log_every_t=log_every_t,
@@ -99,20 +104,22 @@ class _SamplerBase:
             return self.model.apply_model_nhwc(x, t, cond, **({} if temb is None else {"temb": temb})), None
         e = self.model.apply_model(x, t, cond)
         e = e.to(torch.float32).contiguous()
-        buf = ops.nchw_to_nhwc(e, 8)
+        buf = ops.nchw_to_nhwc(e, (e.shape[1] + 7) // 8 * 8)
         return buf, buf
 
     # ---- plms.py:124-179 + 182-247
     def plms_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None, timesteps=None,
                       quantize_denoised=False, mask=None, x0=None, img_callback=None, log_every_t=100,
                       temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
-                      unconditional_guidance_scale=1., unconditional_conditioning=None, verbose=True, blend_noises=None):
-        if ddim_use_original_steps or timesteps is not None:
-            raise NotImplementedError("ddim_use_original_steps / timesteps subsets are not used by the reference's CLIs")
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, verbose=True, blend_noises=None,
+                      dropout_masks=None, step_noises=None):
         if mask is not None and x0 is None:
             raise ValueError("mask blending needs x0 (plms.py:154)")
-        if quantize_denoised or score_corrector is not None or noise_dropout > 0.:
-            raise NotImplementedError("quantize_x0 / score_corrector / noise_dropout are never set by the reference's CLIs")
+        if quantize_denoised or score_corrector is not None:
+            # both need objects the reference's CLIs never construct (a VQ first stage with .quantize, a score corrector)
+            raise NotImplementedError("quantize_x0 / score_corrector are never set by the reference's CLIs")
+        if not 0. <= float(noise_dropout) < 1.:
+            raise ValueError("noise_dropout must be in [0, 1)")
         # hybrid (inpainting) conditioning: {"c_concat": mask + masked-image latent, "c_crossattn": text} (inpaint.py:84-88,
         # WK plms.py:188-205); the concat part is the same for the cond and uncond halves
         c_cat = None
@@ -131,9 +138,30 @@ class _SamplerBase:
             img = torch.randn(shape, device=dev, dtype=torch.float32, generator=self.generator)
         else:
             img = torch.as_tensor(x_T).to(device=dev, dtype=torch.float32).contiguous().clone()
-        ts = self.ddim_timesteps
-        time_range = np.flip(ts)
-        total_steps = ts.shape[0]
+        # ---- which timesteps, and which tables `index` selects from (plms.py:134-142, 205-208)
+        if ddim_use_original_steps:
+            # every DDPM step (or the first `timesteps` of them): tables are the model's alphas_cumprod themselves.  The
+            # reference reads `self.model.ddim_sigmas_for_original_num_steps` (plms.py:208), an attribute make_schedule
+            # creates on the SAMPLER (plms.py:64-67): we use the sampler's.
+            n_orig = int(self.ddpm_num_timesteps if timesteps is None else timesteps)
+            if not 0 < n_orig <= self.ddpm_num_timesteps:
+                raise ValueError(f"timesteps must be in (0, {self.ddpm_num_timesteps}] with ddim_use_original_steps")
+            time_range = np.arange(n_orig - 1, -1, -1, dtype=np.int64)
+            alphas, alphas_prev = self.alphas_cumprod, self.alphas_cumprod_prev
+            sqrt_one_minus_alphas = self.sqrt_one_minus_alphas_cumprod
+            sigmas = np.asarray(self.ddim_sigmas_for_original_num_steps, dtype=np.float32)
+        else:
+            ts = self.ddim_timesteps
+            if timesteps is not None:                                # plms.py:137-139: a prefix of the DDIM grid
+                n_ddim = ts.shape[0]
+                subset_end = int(min(timesteps / n_ddim, 1) * n_ddim) - 1
+                ts = ts[:subset_end]
+                if ts.shape[0] == 0:
+                    raise ValueError(f"timesteps={timesteps} selects an empty subset of the {n_ddim}-step DDIM grid")
+            time_range = np.flip(ts)
+            alphas, alphas_prev = self.ddim_alphas, self.ddim_alphas_prev
+            sqrt_one_minus_alphas, sigmas = self.ddim_sqrt_one_minus_alphas, self.ddim_sigmas
+        total_steps = int(time_range.shape[0])
         if verbose:
             print(f"Running {type(self).__name__} Sampling with {total_steps} timesteps")
         scale = float(unconditional_guidance_scale)
@@ -162,8 +190,6 @@ class _SamplerBase:
             temb_all = self.model.time_embedding_table(t_all)
         t_all = t_all[:, None].expand(total_steps, nb).contiguous()
 
-        alphas, alphas_prev = self.ddim_alphas, self.ddim_alphas_prev
-        sqrt_one_minus_alphas, sigmas = self.ddim_sqrt_one_minus_alphas, self.ddim_sigmas
         intermediates = {'x_inter': [img.clone()], 'pred_x0': [img.clone()]}
         pool = [torch.empty_like(img) for _ in range(4)]  # eps history buffers (3 live + 1 being written)
         hist = []                                         # newest first; at most 3 (plms.py:169-171)
@@ -184,12 +210,28 @@ class _SamplerBase:
             eps, keep = self._eps_nhwc(x, t_row, c_in, temb)
             return None, eps, keep
 
+        drop_count, noise_count = [0], [0]
+
         def step(x, eps_u, eps_c, index, coef, olds, e_out, x_out, p_out):
             a_t, a_prev = np.float32(alphas[index]), np.float32(alphas_prev[index])
             sigma_t = np.float32(sigmas[index])
             noise = None
             if float(sigma_t) != 0.0:
-                noise = torch.randn(x.shape, device=dev, dtype=torch.float32, generator=self.generator) * temperature
+                if step_noises is not None:   # tests inject the k-th N(0,1) draw to compare with the oracle (eta != 0)
+                    noise = torch.as_tensor(step_noises[noise_count[0]]).to(device=dev, dtype=torch.float32) * temperature
+                else:
+                    noise = torch.randn(x.shape, device=dev, dtype=torch.float32, generator=self.generator) * temperature
+                noise_count[0] += 1
+                if noise_dropout > 0.:
+                    # plms.py:224-225 `ops.dropout(noise, p=noise_dropout)`: zero with probability p, scale the rest by
+                    # 1 / (1 - p).  dropout_masks[k] (1 = keep) injects the k-th draw so that tests can feed the oracle
+                    # the same mask; otherwise it comes from the sampler's generator.
+                    if dropout_masks is not None:
+                        keep = torch.as_tensor(dropout_masks[drop_count[0]]).to(device=dev, dtype=torch.float32)
+                    else:
+                        keep = (torch.rand(x.shape, device=dev, generator=self.generator) >= noise_dropout).to(torch.float32)
+                    drop_count[0] += 1
+                    noise = noise * keep / (1. - float(noise_dropout))
             ops.sampler_step(x, eps_u, eps_c, eps_c.shape[-1], scale, olds, coef,
                              np.sqrt(a_t), np.float32(sqrt_one_minus_alphas[index]), np.sqrt(a_prev),
                              np.sqrt(np.float32(1.) - a_prev - sigma_t ** 2), sigma_t, noise, e_out, x_out, p_out)

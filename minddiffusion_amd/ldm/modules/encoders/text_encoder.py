@@ -23,7 +23,7 @@ f16, f32 = torch.float16, torch.float32
 
 class TextEncoder:
     def __init__(self, context_length, vocab_size, output_dim, width, layers, heads, dtype=None, act="gelu_tanh",
-                 device=None, use_graph=True):
+                 device=None, use_graph=True, ln_eps=1e-5):
         if width % heads or (width // heads) not in (40, 64, 80, 160):
             raise MdxError(f"TextEncoder: head dim {width / heads} is not supported by mdx_attention_f16 (40/64/80/160)")
         if act not in ("gelu_tanh", "quick_gelu"):
@@ -34,6 +34,9 @@ class TextEncoder:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()
                                                                                    if torch.cuda.is_available() else 0)
         self.use_graph = use_graph
+        # ln_1 / ln_2 epsilon: SDv2 passes epsilon=1e-5 (text_encoder.py:84,93); Wukong builds nn.LayerNorm([d_model]) with
+        # MindSpore's default 1e-7 (WK text_encoder.py:91,100).  ln_final is the default 1e-7 in both.
+        self.ln_eps = float(ln_eps)
         self.w = None
         self._plans = {}
 
@@ -121,7 +124,7 @@ class TextEncoder:
         scale = float(dh) ** -0.5
         for i in range(self.layers):
             L = f"l{i}."
-            main.append(lambda x=x, L=L: ops.layernorm(x.view(B * T, wd), w[L + "ln_1.g"], w[L + "ln_1.b"], 1e-5,
+            main.append(lambda x=x, L=L: ops.layernorm(x.view(B * T, wd), w[L + "ln_1.g"], w[L + "ln_1.b"], self.ln_eps,
                                                        out=a.view(B * T, wd)))
             gemm(a=a, w=w[L + "qk.w"], N=2 * wd, B=B, H=T, W=1, c1=wd, out=qk, out_ld=2 * wd, bias=w[L + "qk.b"])
             gemm(a=a, w=w[L + "v.w"], N=wd, B=B, H=T, W=1, c1=wd, out=vt, out_ld=T, bias=w[L + "v.b"],
@@ -131,7 +134,7 @@ class TextEncoder:
                                               causal=True))                                     # mask :136-139, :57-60
             gemm(a=o, w=w[L + "out.w"], N=wd, B=B, H=T, W=1, c1=wd, out=x2, out_ld=wd, bias=w[L + "out.b"],
                  residual=x, residual_ld=wd)                                                     # x + attn(ln_1(x)) :94
-            main.append(lambda x2=x2, L=L: ops.layernorm(x2.view(B * T, wd), w[L + "ln_2.g"], w[L + "ln_2.b"], 1e-5,
+            main.append(lambda x2=x2, L=L: ops.layernorm(x2.view(B * T, wd), w[L + "ln_2.g"], w[L + "ln_2.b"], self.ln_eps,
                                                          out=a.view(B * T, wd)))
             gemm(a=a, w=w[L + "fc.w"], N=4 * wd, B=B, H=T, W=1, c1=wd, out=h, out_ld=4 * wd, bias=w[L + "fc.b"],
                  epilogue=epi)

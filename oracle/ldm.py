@@ -455,11 +455,15 @@ class ModelOracle:
 
 def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0.0,
            unconditional_guidance_scale=1.0, unconditional_conditioning=None, noise_fn=None,
-           temperature=1.0, log_every_t=100, mask=None, x0=None, blend_noises=None):
+           temperature=1.0, log_every_t=100, mask=None, x0=None, blend_noises=None, timesteps=None,
+           ddim_use_original_steps=False, noise_dropout=0.0, dropout_masks=None):
     """PLMSSampler.sample/plms_sampling/p_sample_plms (plms.py:69-247).
 
     sampler='ddim' applies get_x_prev_and_pred_x0 (plms.py:210-228) with e'=e_t each step
     (SURVEY 0.4): S model calls instead of S+1, eta may be != 0 (noise from noise_fn(shape)).
+    timesteps / ddim_use_original_steps: plms.py:134-142, 205-208 (a prefix of the DDIM grid, or every DDPM step with the
+    model's own alphas_cumprod tables).  noise_dropout: plms.py:224-225 `ops.dropout(noise, p)` = zero with probability p,
+    survivors scaled by 1/(1-p); dropout_masks[k] (1 = keep) is the k-th draw.
     Returns (samples, intermediates).
     """
     if sampler == "plms" and eta != 0:
@@ -467,6 +471,16 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
     ts = make_ddim_timesteps(S, model.num_timesteps)
     sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(model.alphas_cumprod, ts, eta)
     sqrt_one_minus_alphas = np.sqrt(1.0 - alphas).astype(np.float32)
+    if ddim_use_original_steps:   # plms.py:134-135, 141-142, 205-208; sigmas: plms.py:64-67
+        n_orig = model.num_timesteps if timesteps is None else int(timesteps)
+        ts = np.arange(n_orig, dtype=np.int64)
+        ac, acp = model.alphas_cumprod, model.alphas_cumprod_prev
+        alphas, alphas_prev = ac, acp
+        sqrt_one_minus_alphas = np.sqrt(1.0 - ac).astype(np.float32)
+        sigmas = (np.float32(eta) * np.sqrt((1 - acp) / (1 - ac) * (1 - ac / acp))).astype(np.float32)
+    elif timesteps is not None:   # plms.py:137-139
+        subset_end = int(min(timesteps / ts.shape[0], 1) * ts.shape[0]) - 1
+        ts = ts[:subset_end]
     b = batch_size
     img = torch.as_tensor(x_T, dtype=torch.float32)
     assert tuple(img.shape) == (b,) + tuple(shape)
@@ -501,6 +515,8 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
         e_u, e_c = model.apply_model(x_in, t_in, c_in).chunk(2, dim=0)
         return e_u + scale * (e_c - e_u)
 
+    drops = [0]
+
     def x_prev_and_pred_x0(x, e_t, index):  # plms.py:210-228
         a_t = torch.tensor(alphas[index])
         a_prev = torch.tensor(alphas_prev[index])
@@ -510,6 +526,10 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
         dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t
         if float(sigma_t) != 0.0:
             noise = sigma_t * torch.as_tensor(noise_fn(tuple(x.shape)), dtype=torch.float32) * temperature
+            if noise_dropout > 0.0:   # plms.py:224-225
+                keep = torch.as_tensor(dropout_masks[drops[0]], dtype=torch.float32)
+                drops[0] += 1
+                noise = noise * keep / (1.0 - noise_dropout)
         else:
             noise = 0.0
         return a_prev.sqrt() * pred_x0 + dir_xt + noise, pred_x0

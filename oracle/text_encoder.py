@@ -17,9 +17,10 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-SD2_TEXT = dict(context_length=77, vocab_size=49408, width=1024, layers=23, heads=16, act="gelu_tanh")
+SD2_TEXT = dict(context_length=77, vocab_size=49408, width=1024, layers=23, heads=16, act="gelu_tanh", ln_eps=1e-5)
 # wukong-huahua/ldm/modules/encoders/modules.py:30: width 768, 12 layers, 12 heads; real QuickGELU (text_encoder.py:67-74)
-WK_TEXT = dict(context_length=77, vocab_size=49408, width=768, layers=12, heads=12, act="quick_gelu")
+# ln_1 / ln_2 = nn.LayerNorm([d_model]) without an epsilon argument: MindSpore's default 1e-7 (WK text_encoder.py:91,100)
+WK_TEXT = dict(context_length=77, vocab_size=49408, width=768, layers=12, heads=12, act="quick_gelu", ln_eps=1e-7)
 
 
 def param_shapes(cfg=SD2_TEXT, prefix="transformer."):
@@ -76,7 +77,7 @@ def encode_tokens(p, tokens, cfg=SD2_TEXT, prefix="transformer."):
     mask = torch.triu(torch.full((T, T), float("-inf")), 1)                                          # :136-139
     for i in range(cfg["layers"]):
         b = f"{prefix}transformer_layer.resblocks.{i}."
-        a = F.layer_norm(x, (w,), _t(p, b + "ln_1.gamma"), _t(p, b + "ln_1.beta"), eps=1e-5)        # :89, :100
+        a = F.layer_norm(x, (w,), _t(p, b + "ln_1.gamma"), _t(p, b + "ln_1.beta"), eps=cfg.get("ln_eps", 1e-5))   # SD2 :84,93 (1e-5); WK :91,100 (default 1e-7)
         qkv = a @ _t(p, b + "attn.attn.in_proj.weight").T + _t(p, b + "attn.attn.in_proj.bias")      # :47
         q, k, v = qkv.split(w, dim=-1)
         q = (q * d ** -0.5).reshape(B, T, H, d).permute(0, 2, 1, 3)                                  # :54-55
@@ -85,7 +86,7 @@ def encode_tokens(p, tokens, cfg=SD2_TEXT, prefix="transformer."):
         wts = torch.softmax(q @ k.transpose(-1, -2) + mask, dim=-1)                                  # :58-60
         o = (wts @ v).permute(0, 2, 1, 3).reshape(B, T, w)
         x = x + (o @ _t(p, b + "attn.attn.out_proj.weight").T + _t(p, b + "attn.attn.out_proj.bias"))
-        a = F.layer_norm(x, (w,), _t(p, b + "ln_2.gamma"), _t(p, b + "ln_2.beta"), eps=1e-5)
+        a = F.layer_norm(x, (w,), _t(p, b + "ln_2.gamma"), _t(p, b + "ln_2.beta"), eps=cfg.get("ln_eps", 1e-5))
         h = _act(a @ _t(p, b + "c_fc.weight").T + _t(p, b + "c_fc.bias"), cfg["act"])
         x = x + (h @ _t(p, b + "c_proj.weight").T + _t(p, b + "c_proj.bias"))
     # ln_final = nn.LayerNorm([width]) with MindSpore's default epsilon 1e-7 (text_encoder.py:132)

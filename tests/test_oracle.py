@@ -162,3 +162,60 @@ def test_ddim_single_step_formula():
     pred = (torch.tensor(x_T) - np.sqrt(1 - a_t) * e) / np.sqrt(a_t)
     ref = np.sqrt(a_prev) * pred + np.sqrt(1 - a_prev) * e
     np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=1e-5)
+
+
+class _RecordingModel:
+    """apply_model = 0.1 * x, recording the timesteps it is called with (sampler-option tests)."""
+    parameterization = "eps"
+
+    def __init__(self):
+        s = ldm.register_schedule()
+        self.num_timesteps = s["num_timesteps"]
+        self.alphas_cumprod = s["alphas_cumprod"]
+        self.alphas_cumprod_prev = s["alphas_cumprod_prev"]
+        self.ts = []
+
+    def apply_model(self, x, t, cond):
+        self.ts.append(int(t[0]))
+        return 0.1 * x
+
+
+def test_sampler_options_timesteps_subset_and_original_steps():
+    """plms.py:134-142, 205-208: `timesteps` keeps a prefix of the DDIM grid; `ddim_use_original_steps` walks every DDPM
+    step with the model-level alpha tables; one step of the latter has the closed form of plms.py:218-226."""
+    x_T = np.random.RandomState(0).randn(1, 4, 4, 4).astype(np.float32)
+    c = np.zeros((1, 2, 8), np.float32)
+    m = _RecordingModel()
+    ldm.sample(m, 10, 1, (4, 4, 4), c, x_T, "ddim", timesteps=6)
+    assert m.ts == [401, 301, 201, 101, 1]              # int(min(6/10, 1) * 10) - 1 = 5 entries of [1, 101, ..., 901]
+    m = _RecordingModel()
+    ldm.sample(m, 10, 1, (4, 4, 4), c, x_T, "ddim", timesteps=25)   # ratio clamps to 1 -> 9 of the 10
+    assert m.ts == [801, 701, 601, 501, 401, 301, 201, 101, 1]
+    m = _RecordingModel()
+    ldm.sample(m, 10, 1, (4, 4, 4), c, x_T, "plms", timesteps=3, ddim_use_original_steps=True)
+    assert m.ts == [2, 1, 1, 0]                         # PLMS: the extra call of the first step uses t_next
+    m = _RecordingModel()
+    out, _ = ldm.sample(m, 10, 1, (4, 4, 4), c, x_T, "ddim", timesteps=1, ddim_use_original_steps=True)
+    a_t, a_prev = m.alphas_cumprod[0], m.alphas_cumprod_prev[0]
+    assert a_prev == 1.0
+    x = torch.tensor(x_T)
+    pred = (x - np.sqrt(1 - a_t) * 0.1 * x) / np.sqrt(a_t)
+    np.testing.assert_allclose(out.numpy(), pred.numpy(), atol=1e-6)   # dir term vanishes at a_prev = 1
+
+
+def test_sampler_option_noise_dropout():
+    """plms.py:224-225: dropped entries receive no noise, kept entries noise / (1 - p)."""
+    x_T = np.random.RandomState(0).randn(1, 4, 4, 4).astype(np.float32)
+    c = np.zeros((1, 2, 8), np.float32)
+    noise = np.random.RandomState(1).randn(1, 4, 4, 4).astype(np.float32)
+    keep = (np.random.RandomState(2).rand(1, 4, 4, 4) >= 0.5).astype(np.float32)
+    run = lambda **kw: ldm.sample(_RecordingModel(), 1, 1, (4, 4, 4), c, x_T, "ddim", eta=1.0,
+                                  noise_fn=lambda shp: noise, **kw)[0].numpy()
+    base = ldm.sample(_RecordingModel(), 1, 1, (4, 4, 4), c, x_T, "ddim", eta=0.0)[0].numpy()
+    full = run()
+    drop = run(noise_dropout=0.5, dropout_masks=[keep])
+    sig = ldm.make_ddim_sampling_parameters(ldm.register_schedule()["alphas_cumprod"], ldm.make_ddim_timesteps(1), 1.0)[0][0]
+    assert sig > 0
+    # eta changes the dir coefficient too, so compare the two eta = 1 runs with each other
+    np.testing.assert_allclose(drop - (full - sig * noise), sig * noise * keep / 0.5, atol=1e-5)
+    assert np.abs(full - base).max() > 0

@@ -20,7 +20,7 @@ def _build(cfg, params, graph=True):
     from minddiffusion_amd.ldm.modules.encoders.text_encoder import TextEncoder
     enc = TextEncoder(context_length=cfg["context_length"], vocab_size=cfg["vocab_size"], output_dim=cfg["width"],
                       width=cfg["width"], layers=cfg["layers"], heads=cfg["heads"], act=cfg["act"], device=DEV,
-                      use_graph=graph)
+                      use_graph=graph, ln_eps=cfg.get("ln_eps", 1e-5))
     enc.load_state_dict(params, prefix="transformer.")
     return enc
 
@@ -94,3 +94,23 @@ def test_full_wukong_text_encoder():
     ref = OT.encode_tokens(params, tok, cfg)
     got = emb(tok)
     check("wukong_text_encoder_B2", got, ref, rel_l2=5e-3, max_abs=1e-1)
+
+
+@pytest.mark.parametrize("ln_eps", [1e-5, 1e-7])
+def test_text_encoder_layernorm_epsilon_is_honoured(ln_eps):
+    """SDv2 builds ln_1 / ln_2 with epsilon=1e-5 (text_encoder.py:84,93), Wukong with MindSpore's default 1e-7
+    (WK text_encoder.py:91,100).  With O(1) activations the two are indistinguishable, so this case shrinks the
+    embedding tables until the first layer's row variance (~1e-6) is comparable to the epsilon."""
+    cfg = dict(OT.SD2_TEXT, vocab_size=100, width=128, layers=1, heads=2, act="quick_gelu", ln_eps=ln_eps)
+    params = OT.init_params(cfg, seed=3)
+    for k in ("transformer.embedding_table", "transformer.positional_embedding"):
+        params[k] = (params[k] * 0.002).astype(np.float32)
+    tok = np.random.RandomState(4).randint(0, 100, (2, 77))
+    ref = OT.encode_tokens(params, tok, cfg)
+    other = OT.encode_tokens(params, tok, dict(cfg, ln_eps=1e-5 if ln_eps == 1e-7 else 1e-7))
+    assert float((ref - other).norm() / ref.norm()) > 5e-2      # the case does separate the two epsilons
+    # 1e-2: the 1e-3-sized token rows lose a little to fp16 subnormals before the first LayerNorm (vs 0.78 between epsilons)
+    check(f"text_encoder_ln_eps_{ln_eps:g}", _build(cfg, params)(tok), ref, rel_l2=1e-2, max_abs=1e-1)
+    from minddiffusion_amd.ldm.modules.encoders.modules import FrozenCLIPEmbedder_ZH
+    assert FrozenCLIPEmbedder_ZH.wukong(device=DEV).transformer.ln_eps == 1e-7
+    assert FrozenCLIPEmbedder_ZH(device=DEV).transformer.ln_eps == 1e-5

@@ -381,3 +381,53 @@ def test_wukong_style_unet_and_plms():
     e = model.apply_model(torch.tensor(x, device=DEV), torch.tensor(ts, device=DEV),
                           c_crossattn=torch.tensor(ctx, device=DEV))
     assert torch.equal(e, got)
+
+
+@pytest.mark.parametrize("mode", ["subset", "original", "dropout"])
+def test_sampler_options_vs_oracle(mode):
+    """plms_sampling options of the reference that its CLIs never set (plms.py:134-142, 205-208, 224-225):
+    `timesteps` prefix of the DDIM grid, `ddim_use_original_steps` (every DDPM step, model-level alpha tables) and
+    `noise_dropout` (eta != 0; the N(0,1) draws and the keep masks are injected on both sides)."""
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from minddiffusion_amd.ldm.models.diffusion.plms import PLMSSampler
+    from minddiffusion_amd.ldm.models.diffusion.ddim import DDIMSampler
+    cfg = _tiny_cfg()
+    params = O.init_params(_oracle_cfg(cfg), seed=12)
+    net = _build(cfg, params, True)
+    model = LatentDiffusion(net, linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    omodel = O.ModelOracle(O.UNetOracle(_oracle_cfg(cfg), params))
+    B, H, W, T = 2, 8, 8, 6
+    rng = np.random.RandomState(13)
+    x_T = rng.randn(B, 4, H, W).astype(np.float32)
+    c = rng.randn(B, T, cfg["context_dim"]).astype(np.float32)
+    uc = np.repeat(rng.randn(1, T, cfg["context_dim"]).astype(np.float32), B, 0)
+    dev = lambda a: torch.tensor(a, device=DEV)
+    common = dict(unconditional_guidance_scale=5.0)
+    if mode == "subset":       # S = 10 grid, timesteps = 6 -> the first int(0.6 * 10) - 1 = 5 DDIM timesteps, PLMS (6 UNet calls)
+        ref, ri = O.sample(omodel, 10, B, (4, H, W), c, x_T, "plms", unconditional_conditioning=uc, timesteps=6, **common)
+        got, gi = PLMSSampler(model).sample(10, B, (4, H, W), conditioning=dev(c), x_T=dev(x_T), verbose=False,
+                                            unconditional_conditioning=dev(uc), timesteps=6, **common)
+        assert len(gi["x_inter"]) == len(ri["x_inter"])
+    elif mode == "original":   # the 7 lowest DDPM steps t = 6..0 with alphas_cumprod[t] / alphas_cumprod_prev[t]
+        ref, _ = O.sample(omodel, 10, B, (4, H, W), c, x_T, "ddim", unconditional_conditioning=uc, timesteps=7,
+                          ddim_use_original_steps=True, **common)
+        got, _ = DDIMSampler(model).sample(10, B, (4, H, W), conditioning=dev(c), x_T=dev(x_T), verbose=False,
+                                           unconditional_conditioning=dev(uc), timesteps=7, ddim_use_original_steps=True,
+                                           **common)
+    else:                      # DDIM eta = 0.6 with 30 % noise dropout
+        S = 5
+        noises = [rng.randn(B, 4, H, W).astype(np.float32) for _ in range(S)]
+        masks = [(rng.rand(B, 4, H, W) >= 0.3).astype(np.float32) for _ in range(S)]
+        it = iter(noises)
+        ref, _ = O.sample(omodel, S, B, (4, H, W), c, x_T, "ddim", eta=0.6, unconditional_conditioning=uc,
+                          noise_fn=lambda shp: next(it), noise_dropout=0.3, dropout_masks=masks, **common)
+        got, _ = DDIMSampler(model).sample(S, B, (4, H, W), conditioning=dev(c), x_T=dev(x_T), verbose=False, eta=0.6,
+                                           unconditional_conditioning=dev(uc), noise_dropout=0.3, dropout_masks=masks,
+                                           step_noises=noises, **common)
+        # without injected masks the draw comes from the generator: finite, and different from the no-dropout run
+        free, _ = DDIMSampler(model).sample(S, B, (4, H, W), conditioning=dev(c), x_T=dev(x_T), verbose=False, eta=0.6,
+                                            unconditional_conditioning=dev(uc), noise_dropout=0.3, step_noises=noises, **common)
+        assert torch.isfinite(free).all() and not torch.equal(free, got)
+    check(f"tiny_sampler_option_{mode}", got, ref, rel_l2=1e-2, max_rel=1e-2)
+    with pytest.raises(NotImplementedError):
+        PLMSSampler(model).sample(4, B, (4, H, W), conditioning=dev(c), x_T=dev(x_T), verbose=False, quantize_x0=True)
