@@ -131,17 +131,80 @@ class DDimSampleDiffusionModel:
         return sample, pred
 
 
+# ---- checkpoint ingestion (src/txt2img.py:34-57)
+BASE_NET_PREFIX = "p_mean_variance.guider_net.model."   # GenerativePSampleDiffusionModel.p_mean_variance (PMeanVariance)
+#                                                          .guider_net (SamplingWithGuidance).model (Text2ImUNet)
+SUPRES_NET_PREFIX = "p_mean_variance.guider_net."       # DDimSampleDiffusionModel.p_mean_variance.guider_net = the UNet
+
+
+def rewrite_checkpoint_keys(param_dict, model_type="base"):
+    """The key rewrite of src/txt2img.py:41-53, applied to {name: array}: drop every `diffusion_with_p_sample` path
+    component (the training wrapper's attribute) and, for the base model, insert `model` after `guider_net` (at sampling
+    time the UNet sits inside SamplingWithGuidance, diffusion_creator.py:33-44)."""
+    out = {}
+    for key, val in param_dict.items():
+        parts = []
+        for comp in key.split("."):
+            if comp == "diffusion_with_p_sample":
+                continue
+            parts.append(comp)
+            if comp == "guider_net" and model_type == "base":
+                parts.append("model")
+        out[".".join(parts)] = val
+    return out
+
+
+def load_ckpt(net, ckpt_file, model_type="base", strict=True):
+    """src/txt2img.py:34-57 `load_ckpt(net, ckpt_file, model_type)`: read the MindSpore .ckpt, rewrite its keys, load
+    them into `net` (what init_diffusion_model / init_super_res_model returned).  Returns the reference's
+    `param_not_load` list (names of `net` parameters the file did not supply).  strict=True (default) raises if that
+    list is not empty or if the file holds UNet keys the model does not own; strict=False loads what matches, as
+    ms.load_param_into_net does -- but a model with missing weights cannot run here, so missing keys always raise."""
+    if not ckpt_file:
+        return []
+    from ..ms_checkpoint import load_checkpoint
+    sd = rewrite_checkpoint_keys(load_checkpoint(ckpt_file), model_type)
+    prefix = BASE_NET_PREFIX if model_type == "base" else SUPRES_NET_PREFIX
+    unet = net.model if hasattr(net, "model") else net
+    own = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    if not own and model_type != "base":
+        # diffusion_creator.py:49-50 loads a bare up-sampler checkpoint straight into the UNet (no wrapper prefix)
+        own = dict(sd)
+    shapes = unet.parameter_shapes()
+    not_loaded = [prefix + k for k in shapes if k not in own]
+    if not_loaded:
+        raise KeyError(f"load_ckpt({ckpt_file!r}, model_type={model_type!r}): {len(not_loaded)} parameters of the model "
+                       f"are not in the checkpoint, e.g. {not_loaded[:3]} (file keys look like {list(sd)[:2]})")
+    unet.load_state_dict(own, strict=strict)
+    return not_loaded
+
+
 def init_diffusion_model(options, guidance_scale, shape, ckpt_path=None, params=None):
+    """diffusion_creator.py:27-44.  Weights: `params` ({reference parameter name: array}) or `ckpt_path` (a MindSpore .ckpt
+    in the layout src/txt2img.py:100 loads with load_ckpt(..., "base")); the reference accepts ckpt_path here and loads in
+    the caller -- we load here so that the argument is never silently ignored."""
     model = create_model(**options)
+    if params is not None and ckpt_path:
+        raise ValueError("pass either params or ckpt_path")
     if params is not None:
         model.load_state_dict(params)
     sch = _Schedule(options["noise_schedule"], options["diffusion_steps"], options["timestep_respacing"])
-    return GenerativePSampleDiffusionModel(model, sch, guidance_scale, shape)
+    net = GenerativePSampleDiffusionModel(model, sch, guidance_scale, shape)
+    if ckpt_path:
+        load_ckpt(net, ckpt_path, "base")
+    return net
 
 
 def init_super_res_model(options, shape, ckpt_path=None, params=None):
+    """diffusion_creator.py:46-61 (`load_checkpoint(ckpt_path, up_sample_model)` at :49-50: bare UNet names; the wrapped
+    layout of src/txt2img.py:104 is accepted too)."""
     model = create_upsample_model(**options)
+    if params is not None and ckpt_path:
+        raise ValueError("pass either params or ckpt_path")
     if params is not None:
         model.load_state_dict(params)
     sch = _Schedule(options["noise_schedule"], options["diffusion_steps"], options["timestep_respacing"])
-    return DDimSampleDiffusionModel(model, sch, shape)
+    net = DDimSampleDiffusionModel(model, sch, shape)
+    if ckpt_path:
+        load_ckpt(net, ckpt_path, "supres")
+    return net

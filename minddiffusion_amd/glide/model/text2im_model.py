@@ -25,6 +25,7 @@ import torch
 
 from ... import ops
 from ..._lib import MdxError
+from ...weights import check_state_dict
 from ...ldm.modules.diffusionmodules.openaimodel import _Arena, _round_up
 
 f16, f32 = torch.float16, torch.float32
@@ -171,12 +172,8 @@ class Text2ImUNet:
 
     def load_state_dict(self, params, strict=True):
         shapes = self.parameter_shapes()
-        missing = [k for k in shapes if k not in params]
-        if strict and missing:
-            raise KeyError(f"missing parameters: {missing[:5]} ... ({len(missing)} total)")
-        for k, shp in shapes.items():
-            if tuple(params[k].shape) != tuple(shp):
-                raise ValueError(f"{k}: expected shape {shp}, got {tuple(params[k].shape)}")
+        check_state_dict(shapes, {k: v for k, v in params.items() if strict or k in shapes}, True,
+                         f"{type(self).__name__}.load_state_dict")
         P, w = params, {}
         ted = self.time_embed_dim
         w["te0.w"] = self._dev(P["time_embed.0.weight"], f16)

@@ -18,13 +18,24 @@ class AutoencoderKL:
     def __init__(self, ddconfig, embed_dim, ckpt_path=None, ignore_keys=(), image_key="image", colorize_nlabels=None,
                  monitor=None, use_fp16=False, device=None, use_graph=True):
         assert ddconfig["double_z"]
-        if ckpt_path is not None:
-            raise NotImplementedError("MindSpore .ckpt ingestion is SURVEY 8(f) item 4; pass arrays to load_state_dict")
         self.embed_dim = embed_dim
         self.ddconfig = dict(ddconfig)
         self.decoder = Decoder(device=device, use_graph=use_graph, **ddconfig)
         self.encoder = Encoder(device=device, use_graph=use_graph, **ddconfig)
         self.generator = None          # torch.Generator for encode()'s noise (None: the default generator)
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
+
+    def init_from_ckpt(self, path, ignore_keys=()):
+        """autoencoder.py:44-54: read a MindSpore .ckpt (minddiffusion_amd/ms_checkpoint.py), drop keys that start with
+        one of `ignore_keys`, load.  Accepts a bare VAE checkpoint or a whole LatentDiffusion one (first_stage_model.*)."""
+        from ...ms_checkpoint import VAE_PREFIX, load_checkpoint
+        sd = load_checkpoint(path)
+        if any(k.startswith(VAE_PREFIX) for k in sd):
+            sd = {k[len(VAE_PREFIX):]: v for k, v in sd.items() if k.startswith(VAE_PREFIX)}
+        sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
+        self.load_state_dict(sd, strict="encoder.conv_in.weight" in sd)
+        return self
 
     def parameter_shapes(self):
         zc = self.ddconfig["z_channels"]
@@ -37,7 +48,10 @@ class AutoencoderKL:
 
     def load_state_dict(self, params, strict=True):
         """Reference names: post_quant_conv.*, decoder.*, quant_conv.*, encoder.*.  A decode-only checkpoint (no encoder.*)
-        loads with strict=False; encode() then raises."""
+        loads with strict=False; encode() then raises.  strict also rejects keys this model does not own."""
+        from ...weights import check_state_dict
+        if strict:
+            check_state_dict(self.parameter_shapes(), params, True, "AutoencoderKL.load_state_dict")
         self.decoder.load_state_dict(params, prefix="decoder.",
                                      post_quant=(params["post_quant_conv.weight"], params["post_quant_conv.bias"]),
                                      strict=strict)

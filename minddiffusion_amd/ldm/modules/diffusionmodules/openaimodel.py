@@ -28,6 +28,7 @@ import torch
 
 from .... import ops
 from ...._lib import MdxError
+from ....weights import check_state_dict
 
 f16, f32 = torch.float16, torch.float32
 
@@ -253,13 +254,8 @@ class UNetModel:
         """params: name -> array/tensor keyed by the reference's parameter names.  Packs everything into
         the kernels' layouts on the device (fp16 weights, fp32 biases / norm affine)."""
         shapes = self.parameter_shapes()
-        if strict:
-            missing = [k for k in shapes if k not in params]
-            if missing:
-                raise KeyError(f"missing parameters: {missing[:5]} ... ({len(missing)} total)")
-        for k, shp in shapes.items():
-            if tuple(params[k].shape) != tuple(shp):
-                raise ValueError(f"{k}: expected shape {shp}, got {tuple(params[k].shape)}")
+        # every owned parameter is needed to run: missing keys always raise; strict additionally rejects unexpected ones
+        check_state_dict(shapes, {k: v for k, v in params.items() if strict or k in shapes}, True, "UNetModel.load_state_dict")
         P = params
         w = {}
         w["te0.w"] = self._dev(P["time_embed.0.weight"], f16)

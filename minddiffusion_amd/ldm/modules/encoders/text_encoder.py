@@ -60,12 +60,9 @@ class TextEncoder:
 
     def load_state_dict(self, params, prefix="", strict=True):
         shapes = self.parameter_shapes(prefix)
-        missing = [k for k in shapes if k not in params]
-        if missing and strict:
-            raise MdxError(f"TextEncoder.load_state_dict: missing {len(missing)} parameters, e.g. {missing[:3]}")
-        for k, shp in shapes.items():
-            if k in params and tuple(np.shape(params[k])) != tuple(shp):
-                raise MdxError(f"TextEncoder.load_state_dict: {k} has shape {tuple(np.shape(params[k]))}, expected {shp}")
+        from ....weights import check_state_dict
+        check_state_dict(shapes, {k: v for k, v in params.items() if strict or k in shapes}, True,
+                         "TextEncoder.load_state_dict")
         wd = self.width
         g = lambda k: params[prefix + k]
         w = {"emb": self._dev(g("embedding_table"), f16)}

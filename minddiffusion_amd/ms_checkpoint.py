@@ -87,6 +87,8 @@ def load_checkpoint(path, strip_prefix=None):
                         ttype = bytes(v3).decode("utf-8")
                     elif n3 == 3 and w3 == 2:
                         content = v3
+        if tag is not None and strip_prefix is not None and not tag.startswith(strip_prefix):
+            continue                                     # not asked for: neither decoded nor validated
         if tag is None or ttype is None or content is None:
             raise ValueError(f"{path}: checkpoint entry without tag / tensor_type / tensor_content")
         if tag not in chunks:
@@ -106,11 +108,7 @@ def load_checkpoint(path, strip_prefix=None):
         n = int(np.prod(dims)) if dims else 1
         if arr.size != n:
             raise ValueError(f"{path}: parameter {tag!r}: {arr.size} elements for dims {dims}")
-        name = tag
-        if strip_prefix is not None:
-            if not tag.startswith(strip_prefix):
-                continue
-            name = tag[len(strip_prefix):]
+        name = tag if strip_prefix is None else tag[len(strip_prefix):]
         out[name] = arr.reshape(dims).copy()
     return out
 

@@ -57,3 +57,24 @@ def synthetic_unet_params_device(shapes, seed=0, device="cuda:0", zero_init=Fals
             v = r / math.sqrt(int(np.prod(shape[1:])))
         out[name] = v
     return out
+
+
+def check_state_dict(shapes, params, strict=True, who="load_state_dict", ignore_prefixes=()):
+    """Shared key / shape validation of every ``load_state_dict`` here: `shapes` = the names and shapes this object owns
+    (reference parameter names), `params` = what the caller passed.  Returns (missing, unexpected).
+    strict=True raises on EITHER list -- a renamed key in a real checkpoint must not be dropped silently
+    (``ms.load_param_into_net`` returns the not-loaded list; the reference's CLIs print it) -- and always on a shape
+    mismatch.  Keys under `ignore_prefixes` belong to a sibling object sharing the same dict."""
+    missing = [k for k in shapes if k not in params]
+    unexpected = [k for k in params if k not in shapes and not any(k.startswith(p) for p in ignore_prefixes)]
+    if strict and (missing or unexpected):
+        parts = []
+        if missing:
+            parts.append(f"{len(missing)} missing, e.g. {missing[:3]}")
+        if unexpected:
+            parts.append(f"{len(unexpected)} unexpected, e.g. {unexpected[:3]}")
+        raise KeyError(f"{who}: " + "; ".join(parts))
+    for k, shp in shapes.items():
+        if k in params and tuple(np.shape(params[k])) != tuple(shp):
+            raise ValueError(f"{who}: {k} has shape {tuple(np.shape(params[k]))}, expected {tuple(shp)}")
+    return missing, unexpected

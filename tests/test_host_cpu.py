@@ -357,3 +357,82 @@ def test_tuned_table_drives_the_split_choice():
         if checked >= 12:
             break
     assert checked >= 6
+
+
+def test_checkpoints_with_reference_prefixes_load_all_models(tmp_path):
+    """MindSpore .ckpt files keyed the way the reference's CLIs find them load into the mirrors --
+    `model.diffusion_model.` / `first_stage_model.` / `cond_stage_model.` for LatentDiffusion (ddpm.py:75,350), and the
+    Taichu-GLIDE training-wrapper names that src/txt2img.py:34-57 rewrites (drop `diffusion_with_p_sample`, insert
+    `model` after `guider_net` for the base model).  Renamed / surplus keys must be reported, not dropped."""
+    from oracle import glide as OG
+    from oracle import ldm as OL
+    from minddiffusion_amd import ms_checkpoint as C
+    from minddiffusion_amd.configs import TINY_UNET
+    from minddiffusion_amd.glide import diffusion_creator as DC
+    from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    # ---- LatentDiffusion checkpoint -> UNetModel
+    ocfg = dict(TINY_UNET, num_heads=TINY_UNET.get("num_heads", -1), num_head_channels=TINY_UNET.get("num_head_channels", -1))
+    up = OL.init_params(ocfg, seed=0)
+    ck = {C.UNET_PREFIX + k: v for k, v in up.items()}
+    ck["first_stage_model.decoder.conv_in.bias"] = np.zeros(3, np.float32)
+    path = str(tmp_path / "ldm.ckpt")
+    C.save_checkpoint(ck, path, slice_bytes=1 << 16)
+    unet_sd, vae_sd, _ = C.load_latent_diffusion(path)
+    net = UNetModel(device="cpu", **TINY_UNET)
+    net.load_state_dict(unet_sd)
+    assert sorted(unet_sd) == sorted(net.parameter_shapes()) and list(vae_sd) == ["decoder.conv_in.bias"]
+    renamed = dict(unet_sd)
+    renamed["out.2.conv.biass"] = renamed.pop("out.2.conv.bias")
+    with pytest.raises(KeyError, match="missing"):
+        net.load_state_dict(renamed)
+    with pytest.raises(KeyError, match="unexpected"):
+        net.load_state_dict(dict(unet_sd, extra_key=np.zeros(1, np.float32)))
+    net.load_state_dict(dict(unet_sd, extra_key=np.zeros(1, np.float32)), strict=False)   # surplus keys tolerated on request
+    # ---- GLIDE: key rewrite (pure function), then both models through ckpt_path
+    assert DC.rewrite_checkpoint_keys({"diffusion_with_p_sample.p_mean_variance.guider_net.out2.conv.weight": 1}, "base") \
+        == {"p_mean_variance.guider_net.model.out2.conv.weight": 1}
+    assert DC.rewrite_checkpoint_keys({"diffusion_with_p_sample.p_mean_variance.guider_net.out2.conv.weight": 1}, "supres") \
+        == {"p_mean_variance.guider_net.out2.conv.weight": 1}
+    otiny = dict(OG.BASE_OPTIONS, image_size=16, model_channels=64, num_res_blocks=1, channel_mult=(1, 2),
+                 attention_resolutions=(1, 2), text_ctx=16, xf_width=64, xf_layers=2, xf_heads=1, n_vocab=100)
+    bp = OG.init_params(otiny, seed=0)
+    wrapped = {"diffusion_with_p_sample.p_mean_variance.guider_net." + k: v for k, v in bp.items()}
+    wrapped["global_step"] = np.array([7], np.int64)                     # optimizer / bookkeeping entries are ignored
+    bpath = str(tmp_path / "glide_base.ckpt")
+    C.save_checkpoint(wrapped, bpath)
+    opts = dict(TINY_GLIDE, device="cpu", noise_schedule="squaredcos_cap_v2", diffusion_steps=1000, timestep_respacing="10")
+    m = DC.init_diffusion_model(opts, 3.0, (4, 3, 16, 16), ckpt_path=bpath)
+    ref = DC.create_model(**opts)
+    ref.load_state_dict(bp)
+    for k in ref.w:
+        assert torch.equal(m.model.w[k], ref.w[k]), k
+    oup = dict(otiny, in_channels=6, image_size=32, channel_mult=(1, 1, 2))
+    sp = OG.init_params(oup, seed=1)
+    uopts = dict(opts, image_size=32, channel_mult=(1, 1, 2), low_size=8, noise_schedule="linear", timestep_respacing="fast27")
+    for name, sd in (("wrapped", {"diffusion_with_p_sample.p_mean_variance.guider_net." + k: v for k, v in sp.items()}),
+                     ("bare", sp)):                                     # src/txt2img.py:104 and diffusion_creator.py:49-50
+        spath = str(tmp_path / f"glide_up_{name}.ckpt")
+        C.save_checkpoint(sd, spath)
+        s = DC.init_super_res_model(uopts, (2, 3, 32, 32), ckpt_path=spath)
+        refu = DC.create_upsample_model(**uopts)
+        refu.load_state_dict(sp)
+        for k in refu.w:
+            assert torch.equal(s.model.w[k], refu.w[k]), (name, k)
+    # a base checkpoint offered as the up-sampler (or a truncated file) must raise, never load silently
+    with pytest.raises((KeyError, ValueError)):
+        DC.init_super_res_model(uopts, (2, 3, 32, 32), ckpt_path=bpath)
+    short = dict(list(wrapped.items())[:-5])
+    C.save_checkpoint(short, bpath)
+    with pytest.raises(KeyError):
+        DC.init_diffusion_model(opts, 3.0, (4, 3, 16, 16), ckpt_path=bpath)
+    # strip_prefix filters BEFORE validation: a malformed entry outside the prefix does not abort the load
+    good = {C.UNET_PREFIX + "a": np.ones(2, np.float32)}
+    p3 = str(tmp_path / "mixed.ckpt")
+    C.save_checkpoint(good, p3)
+    bad_tensor = bytes([0x08, 5]) + bytes([0x12, 7]) + b"Float32" + bytes([0x1A, 4]) + bytes(4)   # dims [5], 1 element
+    value = bytes([0x0A, 5]) + b"other" + bytes([0x12, len(bad_tensor)]) + bad_tensor
+    with open(p3, "ab") as f:
+        f.write(bytes([0x0A, len(value)]) + value)
+    assert list(C.load_checkpoint(p3, strip_prefix=C.UNET_PREFIX)) == ["a"]
+    with pytest.raises(ValueError):
+        C.load_checkpoint(p3)
