@@ -261,28 +261,23 @@ def main():
                 return pipe(prompts=prompts, x_T=x_T, H=8 * h, W=8 * w, steps=cfg["steps"], scale=cfg["scale"], eta=0.0,
                             decode=True)
             return pipe(c=c, uc=uc, x_T=x_T, H=8 * h, W=8 * w, steps=cfg["steps"], scale=cfg["scale"], eta=0.0,
-                        decode=bool(cfg.get("vae")))
+                        decode=bool(cfg.get("vae")), batch_size=Bg)
     else:
-        from minddiffusion_amd.glide.main_funcs import ddim_sample_loop, gaussian_p_sample_loop
+        # Taichu-GLIDE/src/txt2img.py:113-126 through the library's sharded pipeline: rank 0 holds the prompts of the
+        # global batch; ONE packed broadcast carries them, the per-step unconditional token ids (identical on every rank,
+        # SURVEY 8(e)) and the noise seed; each rank then runs base (60 steps, CFG) + up-sampler (27 steps) on its shard
+        from minddiffusion_amd.glide.pipeline import GlidePipeline
         dm, sr = build_glide(device)
         if args.no_graph:
             dm.model.use_graph = sr.model.use_graph = False
-        P = batch
-        tok = torch.from_numpy(np.random.RandomState(1).randint(1, 50000, (2 * P, 128)).astype(np.int32)).to(device)
-        if world > 1:   # rank 0's synthetic prompts go to every rank (RCCL broadcast, 8 KB)
-            torch.distributed.broadcast(tok, src=0)
-        msk = torch.ones((2 * P, 128), dtype=torch.int32, device=device)
-        rng = np.random.RandomState(7 + rank)
-        g = torch.Generator(device=device)
-        g.manual_seed(42 + rank)
-        dm.generator = g
+        gp = GlidePipeline(dm, sr, text_ctx=128, vocab_len=50001)
+        tok = msk = None
+        if rank == 0:
+            tok = np.random.RandomState(1).randint(1, 50000, (Bg, 128)).astype(np.int32)
+            msk = np.ones((Bg, 128), np.int32)
 
         def one_step():
-            x0 = torch.randn((2 * P, 3, 64, 64), device=device, generator=g)
-            base = gaussian_p_sample_loop(dm, tok, msk, (2 * P, 3, 64, 64), dm.num_timesteps, text_ctx=128, noise=x0,
-                                          vocab_len=50001, rng=rng)[:P]
-            up0 = torch.randn((P, 3, 256, 256), device=device, generator=g) * 0.997
-            return ddim_sample_loop(sr, (P, 3, 256, 256), base, tok[:P], msk[:P], sr.num_timesteps, noise=up0)
+            return gp(tokens=tok, mask=msk, seed=42)
 
     def barrier():
         if world > 1:

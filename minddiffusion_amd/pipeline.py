@@ -40,23 +40,28 @@ class DiffusionPipeline:
         return torch.from_numpy(np.random.RandomState(seed).randn(batch, *shape).astype(np.float32))
 
     def __call__(self, prompts=None, c=None, uc=None, H=512, W=512, steps=50, scale=9.0, eta=0.0, x_T=None, seed=42,
-                 decode=False, gather=False, callback=None, img_callback=None):
+                 decode=False, gather=False, callback=None, img_callback=None, batch_size=None, per_sample_uc=False):
+        """Multi-rank runs: every rank calls with the same `prompts` list (or the same `batch_size` when rank 0 passes
+        precomputed (c, uc) tensors); only rank 0's c / uc / x_T are used, the other ranks may pass None."""
         rank, n = D.world()
         shape = [4, H // 8, W // 8]                                   # txt2img.py:253
         if prompts is not None and rank == 0:
             uc = self.model.get_learned_conditioning(len(prompts) * [""])   # txt2img.py:246-248
             c = self.model.get_learned_conditioning(list(prompts))            # txt2img.py:251
         if n > 1:
-            meta = [None]
-            if rank == 0:
-                meta = [(int(c.shape[0]), int(c.shape[1]), int(c.shape[2]))]
-            torch.distributed.broadcast_object_list(meta, src=0)
-            B, T, Dc = meta[0]
+            B = len(prompts) if prompts is not None else (int(c.shape[0]) if c is not None else batch_size)
+            if B is None:
+                raise MdxError("DiffusionPipeline: ranks without the conditioning tensor need prompts= or batch_size= "
+                               "(the global batch) to size the broadcast")
+            unet = self.model.unet
             if rank == 0 and x_T is None:
                 x_T = self.start_noise(B, shape, seed)
+            to_dev = lambda t: None if t is None else t.to(self.device)
+            # exactly ONE collective: T, the uc form and the noise flag ride in the payload header (distributed.py)
             c, uc, x_T = D.broadcast_conditioning(
-                c.to(self.device) if rank == 0 else None, uc.to(self.device) if rank == 0 else None,
-                x_T.to(self.device) if rank == 0 else None, B, (T, Dc), shape, self.device)
+                to_dev(c) if rank == 0 else None, to_dev(uc) if rank == 0 else None, to_dev(x_T) if rank == 0 else None,
+                B, (int(getattr(unet, "max_context_len", 80)), int(unet.context_dim)), shape, self.device,
+                per_sample_uc=per_sample_uc)
         else:
             if c is None:
                 raise MdxError("DiffusionPipeline: pass prompts (with a text encoder attached) or (c, uc) tensors")

@@ -1,0 +1,144 @@
+"""Two ranks sharing ONE MI355X ("runnable with N ranks on 1 GPU"): the batch-sharded pipelines with the REAL
+DDIM / PLMS samplers and the real (tiny) Taichu-GLIDE models -- every kernel through libmdx.so -- against single-process
+runs of the same shards: bit for bit.  The process group is gloo (RCCL refuses two ranks on one device); the payload of
+the one broadcast is staged through the host by distributed._broadcast, everything else is the production path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from _util import check
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+STEPS, SCALE, B = 5, 5.0, 4
+
+GL_TINY = dict(image_size=16, num_channels=64, num_res_blocks=1, channel_mult=(1, 2), num_heads=1, num_head_channels=64,
+               num_heads_upsample=-1, attention_resolutions=(1, 2), dropout=0.0, text_ctx=16, xf_width=64, xf_layers=2,
+               xf_heads=1, xf_final_ln=True, n_vocab=100, xf_padding=True, diffusion_steps=1000,
+               noise_schedule="squaredcos_cap_v2", timestep_respacing="10", use_scale_shift_norm=True,
+               resblock_updown=True, use_fp16=True, cache_text_emb=False)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ldm_model():
+    from oracle import ldm as O
+    from minddiffusion_amd.configs import TINY_UNET
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    cfg = dict(TINY_UNET)
+    ocfg = dict(cfg)
+    ocfg.setdefault("num_heads", -1)
+    ocfg.setdefault("num_head_channels", -1)
+    net = UNetModel(**cfg)
+    net.load_state_dict(O.init_params(ocfg, seed=21))     # the oracle is only the seeded weight source here
+    return LatentDiffusion(net, linear_start=0.00085, linear_end=0.0120, timesteps=1000), cfg["context_dim"]
+
+
+def _ldm_inputs(ctx_dim):
+    rng = np.random.RandomState(31)
+    c = torch.from_numpy(rng.randn(B, 7, ctx_dim).astype(np.float16))
+    uc = torch.from_numpy(rng.randn(1, 7, ctx_dim).astype(np.float16))
+    x_T = torch.from_numpy(rng.randn(B, 4, 8, 8).astype(np.float32))
+    return c, uc, x_T
+
+
+def _glide_models(P):
+    from oracle import glide as OG
+    from minddiffusion_amd.glide.diffusion_creator import init_diffusion_model, init_super_res_model
+    otiny = dict(OG.BASE_OPTIONS, image_size=16, model_channels=64, num_res_blocks=1, channel_mult=(1, 2),
+                 attention_resolutions=(1, 2), text_ctx=16, xf_width=64, xf_layers=2, xf_heads=1, n_vocab=100,
+                 timestep_respacing="10")
+    dm = init_diffusion_model(options=GL_TINY, guidance_scale=3.0, shape=(2 * P, 3, 16, 16),
+                              params=OG.init_params(otiny, seed=2))
+    uopts = dict(GL_TINY, image_size=32, channel_mult=(1, 1, 2), noise_schedule="linear", timestep_respacing="fast27",
+                 low_size=16)
+    oup = dict(otiny, in_channels=6, image_size=32, channel_mult=(1, 1, 2), noise_schedule="linear",
+               timestep_respacing="fast27")
+    sr = init_super_res_model(options=uopts, shape=(P, 3, 32, 32), params=OG.init_params(oup, seed=4))
+    return dm, sr
+
+
+def _glide_prompts():
+    rng = np.random.RandomState(41)
+    return rng.randint(1, 99, (B, 16)).astype(np.int32), np.ones((B, 16), np.int32)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from minddiffusion_amd import distributed as D
+    from minddiffusion_amd.pipeline import DiffusionPipeline
+    from minddiffusion_amd.glide.pipeline import GlidePipeline
+    torch.cuda.set_device(0)
+    D.init_from_env(backend="gloo")
+    r0 = lambda t: t if rank == 0 else None
+    model, ctx_dim = _ldm_model()
+    c, uc, x_T = _ldm_inputs(ctx_dim)
+    for sampler in ("ddim", "plms"):
+        pipe = DiffusionPipeline(model, sampler=sampler, device=DEV)
+        out = pipe(c=r0(c), uc=r0(uc), x_T=r0(x_T), H=64, W=64, steps=STEPS, scale=SCALE, batch_size=B)
+        torch.save(out.cpu(), os.path.join(out_dir, f"{sampler}_{rank}.pt"))
+    dm, sr = _glide_models(B // world)
+    tok, msk = _glide_prompts()
+    gp = GlidePipeline(dm, sr, text_ctx=16, vocab_len=100)
+    img = gp(tokens=r0(tok), mask=r0(msk), seed=5)
+    torch.save(img.cpu(), os.path.join(out_dir, f"glide_{rank}.pt"))
+    torch.save(torch.from_numpy(gp.last_uncond_tokens), os.path.join(out_dir, f"uncond_{rank}.pt"))
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_real_samplers_equal_single_process(tmp_path):
+    from minddiffusion_amd.pipeline import DiffusionPipeline
+    from minddiffusion_amd.glide.pipeline import GlidePipeline
+    out_dir = str(tmp_path)
+    mp.spawn(_worker, args=(2, _free_port(), out_dir), nprocs=2, join=True)
+    model, ctx_dim = _ldm_model()
+    c, uc, x_T = _ldm_inputs(ctx_dim)
+    per = B // 2
+    for sampler in ("ddim", "plms"):
+        pipe = DiffusionPipeline(model, sampler=sampler, device=DEV)
+        for rank in range(2):
+            lo, hi = rank * per, (rank + 1) * per
+            ref = pipe(c=c[lo:hi], uc=uc, x_T=x_T[lo:hi], H=64, W=64, steps=STEPS, scale=SCALE).cpu()
+            got = torch.load(os.path.join(out_dir, f"{sampler}_{rank}.pt"))
+            assert torch.isfinite(got).all() and float(got.abs().max()) > 0
+            assert torch.equal(got, ref), f"{sampler} rank {rank}: sharded run differs from the single-process shard"
+        # and the un-sharded batch agrees to fp16 noise (a different batch size may pick other tiles / split-K factors)
+        full = pipe(c=c, uc=uc, x_T=x_T, H=64, W=64, steps=STEPS, scale=SCALE).cpu()
+        both = torch.cat([torch.load(os.path.join(out_dir, f"{sampler}_{r}.pt")) for r in range(2)], 0)
+        check(f"two_rank_{sampler}_vs_full_batch", both, full, rel_l2=5e-3, max_rel=1e-2)
+    u0, u1 = (torch.load(os.path.join(out_dir, f"uncond_{r}.pt")) for r in range(2))
+    assert torch.equal(u0, u1) and tuple(u0.shape) == (10, 16)
+    dm, sr = _glide_models(per)
+    tok, msk = _glide_prompts()
+    gp = GlidePipeline(dm, sr, text_ctx=16, vocab_len=100)
+    for rank in range(2):
+        lo, hi = rank * per, (rank + 1) * per
+        x0, noises, up0 = gp.image_noise(5, lo, hi, 10)
+        # single process, same shard: feed the broadcast's products by hand through the reference-shaped loops
+        from minddiffusion_amd.glide.main_funcs import ddim_sample_loop, gaussian_p_sample_loop
+        t2 = torch.from_numpy(np.concatenate([tok[lo:hi], tok[lo:hi]], 0))
+        m2 = torch.from_numpy(np.concatenate([msk[lo:hi], msk[lo:hi]], 0))
+        base = gaussian_p_sample_loop(dm, t2, m2, (2 * per, 3, 16, 16), 10, text_ctx=16, noise=torch.cat([x0, x0], 0),
+                                      vocab_len=100, uncond_tokens=u0.numpy(), step_noises=noises)[:per]
+        ref = ddim_sample_loop(sr, (per, 3, 32, 32), base, torch.from_numpy(tok[lo:hi]), torch.from_numpy(msk[lo:hi]), 27,
+                               noise=up0).cpu()
+        got = torch.load(os.path.join(out_dir, f"glide_{rank}.pt"))
+        assert torch.isfinite(got).all() and tuple(got.shape) == (per, 3, 32, 32)
+        assert torch.equal(got, ref), f"GLIDE rank {rank}: sharded run differs from the single-process shard"
