@@ -133,47 +133,86 @@ def build_model(device, cfg_name="sd2"):
     return model
 
 
-def dominant_kernel_roofline(model, B, h, w, ctx, passes=3):
-    """Per-launch HIP-event timing of the dominant kernel class (gemm_kernel: every implicit-GEMM conv / dense
-    launch of one UNet evaluation, in their real sequence so weights stream from HBM, not from a warm cache)."""
-    net = model.unet
-    P = net._plan(B, h, w)
-    x = torch.randn(B, 4, h, w, device=net.device)
-    t = torch.full((B,), 981.0, device=net.device)
-    net._ensure_context(P, ctx)
-    P.x_static.copy_(x)
-    P.t_static.copy_(t)
-    idx = [i for i, m in enumerate(P.meta) if m["kind"] == "gemm"]
-    flops = sum(P.meta[i]["flops"] for i in idx)
-    times = []
+HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def family_profile(P, ops_list=None, passes=3):
+    """Per-op HIP-event timing of one evaluation of a planned network (UNetModel / Text2ImUNet plan `P`): the ops run in
+    their real sequence on the launch stream (so weights stream from HBM, activations sit where the previous op left them),
+    each bracketed by an event pair recorded on that stream.  Returns {kind: {ms, ops, launches, flops, bytes}} with the
+    minimum over `passes` of each family's summed time.  kinds: gemm (implicit-GEMM conv / dense incl. their split-K
+    reduce), attention, groupnorm, layernorm, small."""
+    ops_list = P.main if ops_list is None else ops_list
+    meta = P.meta[len(P.meta) - len(ops_list):]
+    best = None
     for _ in range(passes):
-        evs = {}
-        for i, op in enumerate(P.main):
-            if i in evs or P.meta[i]["kind"] != "gemm":
-                op()
-                continue
+        evs = []
+        for op in ops_list:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()          # recorded on torch's current stream == the stream the kernels are launched on
+            e0.record()          # torch's current stream == the stream libmdx launches on (ops._stream)
             op()
             e1.record()
-            evs[i] = (e0, e1)
+            evs.append((e0, e1))
         torch.cuda.synchronize()
-        times.append(sum(a.elapsed_time(b) for a, b in evs.values()))  # ms
-    t_ms = min(times)
-    launches = sum(P.meta[i]["launches"] for i in idx)
-    achieved = flops / (t_ms * 1e-3) / 1e12
+        fam = {}
+        for (e0, e1), m in zip(evs, meta):
+            f = fam.setdefault(m["kind"], {"ms": 0.0, "ops": 0, "launches": 0, "flops": 0, "bytes": 0})
+            f["ms"] += e0.elapsed_time(e1)
+            f["ops"] += 1
+            f["launches"] += m["launches"]
+            f["flops"] += m["flops"]
+            if m["kind"] in ("groupnorm", "layernorm"):
+                mm = dict(kv.split("=") for kv in m["info"].split() if "=" in kv)
+                if {"B", "HW", "C"} <= set(mm):      # algorithmic traffic: read the fp16 tensor once, write it once
+                    f["bytes"] += 2 * 2 * int(mm["B"]) * int(mm["HW"]) * int(mm["C"])
+        if best is None:
+            best = fam
+        else:
+            for k in fam:
+                if fam[k]["ms"] < best[k]["ms"]:
+                    best[k]["ms"] = fam[k]["ms"]
+    return best
+
+
+def family_fractions(fams, weight=1.0, acc=None):
+    """Accumulate (weighted by evaluations per unit) family totals across plans."""
+    acc = {} if acc is None else acc
+    for k, f in fams.items():
+        a = acc.setdefault(k, {"ms": 0.0, "launches": 0.0, "flops": 0.0, "bytes": 0.0})
+        for key in a:
+            a[key] += weight * f[key]
+    return acc
+
+
+def roofline_from_families(acc, evals_label):
+    """The `roofline` object: dominant kernel family = gemm (MFMA-bound), plus per-family fractions: attention vs the
+    MFMA peak, GroupNorm / LayerNorm vs the HBM peak (algorithmic bytes = one read + one write of the fp16 tensor)."""
+    g = acc["gemm"]
+    achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    fam_out = {}
+    for k, f in sorted(acc.items()):
+        ent = {"ms": round(f["ms"], 4), "launches": round(f["launches"], 1)}
+        if f["flops"] and k in ("gemm", "attention"):
+            tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
+            ent.update(bound="mfma", tflops=round(tf, 1), frac=round(tf / MFMA_PEAK_TFLOPS, 4))
+        elif f["bytes"]:
+            gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9
+            ent.update(bound="hbm", gbs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+        fam_out[k] = ent
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-        "kernel": "gemm_kernel (implicit-GEMM conv3x3/conv1x1/dense; all launches of one UNet eval, in sequence)",
-        "launches_per_unet_eval": launches,
-        "avg_launch_us": round(t_ms * 1e3 / max(launches, 1), 2),
-        "algorithmic_gflop_per_launch": round(flops / max(launches, 1) / 1e9, 3),
-        "algorithmic_tflop_per_unet_eval_gemm_only": round(flops / 1e12, 4),
+        "kernel": "gemm_kernel / conv3x3_halo_kernel (+ splitk_reduce): every implicit-GEMM conv3x3 / conv1x1 / dense launch of "
+                  + evals_label + ", HIP events per op on the launch stream, ops in their real sequence",
+        "launches_per_unit_of_profile": round(g["launches"], 1),
+        "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
+        "algorithmic_gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
+        "algorithmic_tflop_gemm_only": round(g["flops"] / 1e12, 4),
+        "families": fam_out,
     }
 
 
-def cpu_baseline(n_evals=1):
+def cpu_baseline(n_evals=3):
     """The oracle (fp32 PyTorch-CPU restatement -- the MindSpore reference cannot run here) timed on this host:
     one SDv2 UNet evaluation, B=1, 64x64 (BASELINE config 0 = 0.804 TFLOP).  One DDIM-50 + CFG latent = 100 such
     evaluations, so latents/s = 1 / (100 * t_eval)."""
@@ -188,30 +227,43 @@ def cpu_baseline(n_evals=1):
         t0 = time.time()
         net(x, torch.tensor([981.0]), ctx)
         ts.append(time.time() - t0)
-    t_eval = min(ts[1:]) if len(ts) > 1 else ts[0]
+    t_eval = float(np.median(ts[1:])) if len(ts) > 1 else ts[0]
     return {
         "value": round(1.0 / (100.0 * t_eval), 6), "unit": "latents/s", "cores": threads, "kind": "port",
-        "sample": f"{n_evals} timed SDv2 UNet eval(s) (B=1, 64x64 latent, fp32, oracle/ldm.py) after 1 warm-up: "
-                  f"{t_eval:.2f} s/eval; one 50-step DDIM+CFG latent = 100 evals (extrapolated)",
+        "sample": f"median of {n_evals} timed SDv2 UNet evals (B=1, 64x64 latent, fp32, oracle/ldm.py) after 1 warm-up: "
+                  f"{t_eval:.2f} s/eval (all: {', '.join(f'{t:.2f}' for t in ts[1:])}); one 50-step DDIM+CFG latent = "
+                  f"100 evals (extrapolated)",
         "host_cpu_count": os.cpu_count(),
     }
 
 
-PMC_FILE = "r01_q_pmc_traffic.json"
+PMC_FILE = "r02_pmc_traffic.json"
 
 
-def pmc_traffic():
-    """HBM-side bytes per GEMM-family launch (implicit-GEMM kernels + their split-K reduces) from the committed
-    rocprofv3 PMC passes (tools/pmc_traffic.py: FETCH_SIZE x2-corrected + WRITE_SIZE; PMC counters cannot be read
-    live from inside this process).  Returns (bytes per launch, algorithmic-bytes note) or (None, None)."""
+def pmc_traffic(gemm_launches_now):
+    """L2<->fabric bytes per GEMM-family launch (implicit-GEMM kernels + their split-K reduces) from the rocprofv3 PMC passes
+    committed under profiles/ (tools/pmc_traffic.py: FETCH_SIZE x2-corrected + WRITE_SIZE; PMC counters cannot be read from
+    inside this process, and `--pmc` may not be combined with the timing run).  The passes are taken on THIS bench command;
+    the file is only used when its GEMM-family launch count per evaluation equals the plan's launch count in this process --
+    otherwise it describes another launch mix and `traffic` is null.  Returns (bytes per launch | None, note)."""
     try:
         with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
-            fam = json.load(f)["families"]
+            doc = json.load(f)
+        fam = doc["families"]
         g, r = fam["gemm"], fam.get("splitk_reduce", {"launches_per_eval": 0, "read_MB_per_eval": 0, "write_MB_per_eval": 0})
+        n = g["launches_per_eval"] + r["launches_per_eval"]
+        if abs(n - gemm_launches_now) > 0.5:
+            return None, (f"profiles/{PMC_FILE} holds {n:.0f} GEMM-family launches per evaluation, this build issues "
+                          f"{gemm_launches_now}: stale PMC passes, not reported")
         total = (g["read_MB_per_eval"] + g["write_MB_per_eval"] + r["read_MB_per_eval"] + r["write_MB_per_eval"]) * 1e6
-        return int(total / (g["launches_per_eval"] + r["launches_per_eval"])), None
-    except Exception:
-        return None, None
+        note = (f"L2<->fabric bytes per GEMM-family launch (MALL hits included): rocprofv3 --pmc FETCH_SIZE (x2, gfx950 "
+                f"correction) and WRITE_SIZE, separate passes of `{doc.get('command', '?')}` ({n:.0f} launches per evaluation "
+                f"= this run's); whole evaluation {doc.get('total_read_MB_per_eval')} MB read + "
+                f"{doc.get('total_write_MB_per_eval')} MB written vs 4.45 GB algorithmic (1.73 GB weights + 2 x 1.36 GB "
+                f"activations); profiles/{PMC_FILE}")
+        return int(total / n), note
+    except Exception as e:      # no committed passes for this build
+        return None, f"no PMC passes for this build ({type(e).__name__})"
 
 
 def main():
@@ -307,7 +359,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": cfg["workload"] + "; synthetic seeded weights + synthetic text conditioning",
                        "name": args.config, "global_batch": Bg, "parallelism": f"batch-shard x{world}",
-                       "hip_graph": not args.no_graph},
+                       "hip_graph": None},
         }
         if cfg["family"] == "ldm":
             # per-UNet-step ms: HIP events around apply_model (CFG batch = 2 x per-GPU batch), median of 20 warm calls
@@ -330,7 +382,12 @@ def main():
                                     sampler=cfg["sampler"])
             n_evals = cfg["steps"] + (1 if cfg["sampler"] == "plms" else 0)
             tflop_per_unit = cfg["tflop_per_row"] * 2 * n_evals + cfg.get("vae_tflop", 0.0)   # CFG doubles the rows
-            roof = dominant_kernel_roofline(model, nb, h, w, ctx)
+            Pl = model.unet._plan(nb, h, w)
+            # what actually ran in the timed region: a captured hipGraph replay, or (capture failed / --no-graph) eager launches
+            result["config"]["hip_graph"] = Pl.graph is not None
+            fams = family_profile(Pl, Pl.main[Pl.temb_ops:])
+            roof = roofline_from_families(family_fractions(fams), f"one UNet evaluation at batch {nb}")
+            gemm_launches = fams["gemm"]["launches"]
             if cfg.get("vae"):   # VAE decode alone: HIP events around AutoencoderKL.decode, median of 10 warm calls
                 zz = torch.randn(batch, 4, h, w, device=device)
                 for _ in range(2):
@@ -357,15 +414,17 @@ def main():
                 result["vae_decode_ms"] = round(vms, 3)
                 result["vae_decode_tflops"] = round(cfg["vae_tflop"] * batch / vms * 1e3, 1)
             if args.config == "sd2_512":
-                roof["traffic"] = pmc_traffic()[0]
-                roof["traffic_note"] = ("L2<->fabric bytes per GEMM-family launch (MALL hits included), rocprofv3 PMC: "
-                                        "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, from profiles/" + PMC_FILE +
-                                        " (same workload, eager); algorithmic bytes per launch = (1.73 GB weights + "
-                                        "2 x 1.36 GB activations) / launches")
+                roof["traffic"], roof["traffic_note"] = pmc_traffic(gemm_launches)
         else:
+            # Taichu-GLIDE: one image = 60 guided base evaluations (UNet batch 2P) + 27 super-resolution evaluations (batch P);
+            # profile both plans and weight them by their evaluation counts
             tflop_per_unit = cfg["tflop_per_image"]
-            roof = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                    "traffic": None, "kernel": "gemm_kernel (not broken out for this config)"}
+            Pb, Ps = dm.model._plan(2 * batch, 64, 64), sr.model._plan(batch, 256, 256)
+            result["config"]["hip_graph"] = Pb.graph is not None and Ps.graph is not None
+            acc = family_fractions(family_profile(Pb), float(dm.num_timesteps))
+            acc = family_fractions(family_profile(Ps), float(sr.num_timesteps), acc)
+            roof = roofline_from_families(acc, f"{dm.num_timesteps} base evaluations at batch {2 * batch} + "
+                                               f"{sr.num_timesteps} super-resolution evaluations at batch {batch}")
         whole = units_per_s / world * tflop_per_unit
         roof["whole_path"] = {"achieved": round(whole, 2), "frac": round(whole / MFMA_PEAK_TFLOPS, 4),
                               "algorithmic_tflop_per_unit": tflop_per_unit,

@@ -138,6 +138,11 @@ int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s);
 size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d);
 /* Host-only validation of a descriptor (no launch): MDX_OK or MDX_E_INVALID with mdx_last_error() set. */
 int mdx_gemm_check(const mdx_gemm_desc* d);
+/* What mdx_gemm_f16 WOULD launch for this descriptor (host only, nothing is launched):
+ * out5 = {tile_m, tile_n, splitk, kernel (0 = generic implicit GEMM, 1 = HALO 3x3 conv), 1 if the choice came from the
+ * measured tile table csrc/gemm_tuned.inc}.  The parity tests assert with it that the table rows are hit at the
+ * benchmarked shapes. */
+int mdx_gemm_query(const mdx_gemm_desc* d, int* out5);
 
 /* ---- CrossAttention core: softmax(q k^T * scale) v, flash-style (attention.py:138-152);
  *      the [b*h, N, N] score tensor of the reference is never materialised.

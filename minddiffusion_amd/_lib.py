@@ -54,6 +54,7 @@ SIGNATURES = {
     "mdx_gemm_f16": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
     "mdx_gemm_workspace_bytes": (c_size_t, [ctypes.POINTER(GemmDesc)]),
     "mdx_gemm_check": (c_int, [ctypes.POINTER(GemmDesc)]),
+    "mdx_gemm_query": (c_int, [ctypes.POINTER(GemmDesc), ctypes.POINTER(c_int)]),
     "mdx_attention_f16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,
                                   c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "mdx_attention_causal_f16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,

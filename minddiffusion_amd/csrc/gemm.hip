@@ -1304,17 +1304,21 @@ extern "C" int mdx_gemm_check(const mdx_gemm_desc* d) {
     return MDX_OK;
 }
 
-extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
-    GemmParams p{};
-    int rc = fill_params(d, p);
-    if (rc != MDX_OK) return rc;
-    hipStream_t st = (hipStream_t)s;
-    GemmCfg c = pick_cfg(p);
-    const int bn = c.bn;
-    p.bk = c.bk;
-    p.ktiles = (p.K + c.bk - 1) / c.bk;
+// Everything mdx_gemm_f16 decides before it launches: tile shape, split-K factor (clamped to the caller's workspace), kernel.
+struct Resolved {
+    GemmCfg c;
+    int bn, ns;
+    bool halo, tuned;
+};
+
+static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
+    r.c = pick_cfg(p);
+    const int bn = r.bn = r.c.bn;
+    p.bk = r.c.bk;
+    p.ktiles = (p.K + r.c.bk - 1) / r.c.bk;
+    r.tuned = d->splitk <= 0 && d->tile_m <= 0 && lookup_tuned(p) != nullptr;
     const Tiling tl = choose_tiling(p, bn, d->splitk, d->tile_m);
-    c.bm = tl.bm;
+    r.c.bm = tl.bm;
     int ns = tl.ns;
     if (ns > p.ktiles) ns = p.ktiles;
     if (ns > 1) {
@@ -1329,9 +1333,9 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
             return MDX_E_WORKSPACE;
         }
     }
-    const bool halo = c.bm >= 128 && halo_eligible(p, c.bm);
+    r.halo = r.c.bm >= 128 && halo_eligible(p, r.c.bm);
     p.nsplit = ns;
-    if (halo) {
+    if (r.halo) {
         // chunk-aligned splits: a split owns whole 64-channel chunks (9 K tiles each)
         const int chunks = p.cin / 64;
         if (ns > chunks) ns = chunks;
@@ -1341,7 +1345,41 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         p.ktiles_per_split = (p.ktiles + ns - 1) / ns;
     }
     p.nsplit = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;  // no empty splits
-    ns = p.nsplit;
+    r.ns = p.nsplit;
+    return MDX_OK;
+}
+
+// What mdx_gemm_f16 would launch for this descriptor (no launch): out5 = {tile_m, tile_n, splitk, kernel (0 generic implicit
+// GEMM, 1 HALO conv), from_tuned_table}.  Parity tests use it to assert that the measured tile table (gemm_tuned.inc) is
+// actually hit at the benchmarked shapes.
+extern "C" int mdx_gemm_query(const mdx_gemm_desc* d, int* out5) {
+    GemmParams p{};
+    int rc = fill_params(d, p);
+    if (rc != MDX_OK) return rc;
+    MDX_REQUIRE(out5, "mdx_gemm_query: null output");
+    Resolved r;
+    rc = resolve_launch(d, p, r);
+    if (rc != MDX_OK) return rc;
+    out5[0] = r.c.bm;
+    out5[1] = r.bn;
+    out5[2] = r.ns;
+    out5[3] = r.halo ? 1 : 0;
+    out5[4] = r.tuned ? 1 : 0;
+    return MDX_OK;
+}
+
+extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
+    GemmParams p{};
+    int rc = fill_params(d, p);
+    if (rc != MDX_OK) return rc;
+    hipStream_t st = (hipStream_t)s;
+    Resolved rs;
+    rc = resolve_launch(d, p, rs);
+    if (rc != MDX_OK) return rc;
+    GemmCfg c = rs.c;
+    const int bn = rs.bn;
+    int ns = rs.ns;
+    const bool halo = rs.halo;
     p.tiles_m = (p.M + c.bm - 1) / c.bm;
     p.tiles_n = (p.N + bn - 1) / bn;
     const bool fastk = (p.cin % 64 == 0) && (p.c2 == 0 || p.c1 % 64 == 0);

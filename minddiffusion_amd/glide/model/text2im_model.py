@@ -307,10 +307,11 @@ class Text2ImUNet:
             C = C1 + (0 if x2 is None else x2.shape[2])
             gn_need[0] = max(gn_need[0], ops.groupnorm_ws_floats(Bq, HW, C))
             if scale is None:
-                emit(lambda: ops.groupnorm(x1, x2, g, b, 1e-5, silu, ws=P.gn_ws, out=out), "groupnorm", 0, 2)
+                emit(lambda: ops.groupnorm(x1, x2, g, b, 1e-5, silu, ws=P.gn_ws, out=out), "groupnorm", 0, 2,
+                     f"B={Bq} HW={HW} C={C}")
             else:
                 emit(lambda: ops.groupnorm_scaleshift(x1, x2, g, b, scale, shift, self._emb_total, 1e-5, silu,
-                                                      ws=P.gn_ws, out=out), "groupnorm", 0, 2)
+                                                      ws=P.gn_ws, out=out), "groupnorm", 0, 2, f"B={Bq} HW={HW} C={C}")
 
         def dense(src, rows_b, tokens, cin, nout, wt, bias=None, residual=None, epilogue=ops.EPI_NONE, out=None,
                   out_ld=None, out_mode=ops.OUT_ROWMAJOR, out_bs=0, src2=None, c2=0):

@@ -233,6 +233,13 @@ def gemm_workspace_bytes(desc):
     return int(_lib.load().mdx_gemm_workspace_bytes(ctypes.byref(desc)))
 
 
+def gemm_query(desc):
+    """(tile_m, tile_n, splitk, halo, from_tuned_table) mdx_gemm_f16 would use for this descriptor (no launch)."""
+    out = (ctypes.c_int * 5)()
+    _lib.check(_lib.load().mdx_gemm_query(ctypes.byref(desc), out), "mdx_gemm_query")
+    return tuple(int(v) for v in out)
+
+
 def gemm_run(desc):
     _lib.check(_lib.load().mdx_gemm_f16(ctypes.byref(desc), _stream()), "mdx_gemm_f16")
 

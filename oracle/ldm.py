@@ -15,11 +15,46 @@ MindSpore operator semantics restated here:
   * ops.ResizeNearestNeighbor (align_corners=False): exact 2x pixel duplication.
   * nn.Dropout(keep_prob=1.0): identity.
 """
+import contextlib
 import math
 
 import numpy as np
 import torch
 import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- precision mode
+# Default: all-fp32 (the reference's `use_fp16: False` path).  `with emulate_fp16():` switches every primitive below to an
+# emulation of the reference's SHIPPED mode `use_fp16: True` (configs/v2-inference.yaml:19,38; SURVEY App. A.1): each
+# MindSpore op that runs `.to_float(float16)` sees fp16-rounded inputs and parameters and returns an fp16-rounded result;
+# the arithmetic INSIDE an op is kept in fp32 (what Ascend's cube / vector units do internally is not in the reference
+# tree, so op-boundary rounding is a LOWER bound on the reference's fp16 noise).  Where the reference stays in fp32 on
+# purpose -- GroupNorm (util.py:87-108 `.to_float(ms.float32)`), the sinusoid (util.py:122-126), the sampler's x -- so does
+# the emulation.  Used to measure how far the fp16 reference itself is from this fp32 oracle (DESIGN.md section 3).
+class _Mode:
+    fp16 = False
+
+
+@contextlib.contextmanager
+def emulate_fp16(flag=True):
+    old = _Mode.fp16
+    _Mode.fp16 = bool(flag)
+    try:
+        yield
+    finally:
+        _Mode.fp16 = old
+
+
+def r16(t):
+    """Round to fp16 and back in emulation mode (identity otherwise).  Tensors, numpy arrays and Python floats."""
+    if not _Mode.fp16:
+        return t
+    if isinstance(t, torch.Tensor):
+        return t.to(torch.float16).to(torch.float32)
+    if isinstance(t, np.ndarray):
+        return t.astype(np.float16).astype(np.float32)
+    return float(np.float32(np.float16(t)))
+
 
 
 # ----------------------------------------------------------------------------- schedule
@@ -85,11 +120,14 @@ def timestep_embedding(timesteps, dim, max_period=10000):
 # ----------------------------------------------------------------------------- primitives
 def gelu_tanh(x):
     """ops.GeLU == tanh approximation."""
-    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+    x = r16(x)
+    return r16(0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3))))
 
 
 def silu(x):
-    return x * torch.sigmoid(x)
+    """nn.SiLU().to_float(dtype) (openaimodel.py:137): casts the fp32 GroupNorm output to fp16 first in fp16 mode."""
+    x = r16(x)
+    return r16(x * torch.sigmoid(x))
 
 
 def group_norm(x, gamma, beta, eps, groups=32):
@@ -104,20 +142,22 @@ def group_norm(x, gamma, beta, eps, groups=32):
 
 
 def layer_norm(x, gamma, beta, eps):
+    """nn.LayerNorm([C], epsilon).to_float(dtype): an fp16 op in the reference's fp16 mode (attention.py:176-178)."""
+    x = r16(x)
     mean = x.mean(dim=-1, keepdim=True)
     var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)
-    return (x - mean) / torch.sqrt(var + eps) * gamma + beta
+    return r16((x - mean) / torch.sqrt(var + eps) * r16(gamma) + r16(beta))
 
 
 def dense(x, w, b=None):
     """nn.Dense: y = x W^T + b, W [out,in]."""
-    y = x @ w.t()
-    return y if b is None else y + b
+    y = r16(x) @ r16(w).t()
+    return r16(y if b is None else y + r16(b))
 
 
 def conv2d(x, w, b, stride=1, padding=1):
     """nn.Conv2d(pad_mode='pad'): NCHW cross-correlation with symmetric zero pad."""
-    return F.conv2d(x, w, b, stride=stride, padding=padding)
+    return r16(F.conv2d(r16(x), r16(w), None if b is None else r16(b), stride=stride, padding=padding))
 
 
 def upsample_nearest2x(x):
@@ -215,13 +255,13 @@ class UNetOracle:
         h = silu(h)
         h = conv2d(h, p[pre + "in_layers_conv.conv.weight"], p[pre + "in_layers_conv.conv.bias"])
         emb_out = dense(silu(emb), p[pre + "emb_layers.1.weight"], p[pre + "emb_layers.1.bias"])
-        h = h + emb_out[:, :, None, None]
+        h = r16(h + emb_out[:, :, None, None])
         h = group_norm(h, p[pre + "out_layers_norm.gamma"], p[pre + "out_layers_norm.beta"], 1e-5)
         h = silu(h)
         h = conv2d(h, p[pre + "out_layers_conv.conv.weight"], p[pre + "out_layers_conv.conv.bias"])
         if (pre + "skip_connection.conv.weight") in p:
             x = conv2d(x, p[pre + "skip_connection.conv.weight"], p[pre + "skip_connection.conv.bias"], padding=0)
-        return x + h
+        return r16(x + h)
 
     def _attn(self, pre, x, context, heads):
         """CrossAttention.construct attention.py:117-166 (mask branch has no effect)."""
@@ -238,9 +278,10 @@ class UNetOracle:
             return t.reshape(bb, nn_, heads, d).permute(0, 2, 1, 3).reshape(bb * heads, nn_, d)
 
         q, k, v = rin(q), rin(k), rin(v)
-        sim = torch.matmul(q, k.transpose(1, 2)) * (d ** -0.5)
-        attn = torch.softmax(sim, dim=-1)
-        out = torch.matmul(attn, v)
+        # fp16 mode: the [b*h, N, N] scores, their scaling, the softmax and P.V are four fp16 ops (attention.py:138-152)
+        sim = r16(r16(torch.matmul(q, k.transpose(1, 2))) * r16(d ** -0.5))
+        attn = r16(torch.softmax(sim, dim=-1))
+        out = r16(torch.matmul(attn, v))
         out = out.reshape(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, heads * d)
         return dense(out, p[pre + "to_out.0.weight"], p[pre + "to_out.0.bias"])
 
@@ -257,20 +298,20 @@ class UNetOracle:
         if use_linear:
             x = dense(x, p[pre + "proj_in.weight"], p[pre + "proj_in.bias"])
         t = pre + "transformer_blocks.0."
-        x = self._attn(t + "attn1.", layer_norm(x, p[t + "norm1.gamma"], p[t + "norm1.beta"], 1e-5), None, heads) + x
-        x = self._attn(t + "attn2.", layer_norm(x, p[t + "norm2.gamma"], p[t + "norm2.beta"], 1e-5), context, heads) + x
+        x = r16(self._attn(t + "attn1.", layer_norm(x, p[t + "norm1.gamma"], p[t + "norm1.beta"], 1e-5), None, heads) + x)
+        x = r16(self._attn(t + "attn2.", layer_norm(x, p[t + "norm2.gamma"], p[t + "norm2.beta"], 1e-5), context, heads) + x)
         y = layer_norm(x, p[t + "norm3.gamma"], p[t + "norm3.beta"], 1e-5)
         y = dense(y, p[t + "ff.net.0.proj.weight"], p[t + "ff.net.0.proj.bias"])  # GEGLU attention.py:41-51
         a, gate = y.chunk(2, dim=-1)
-        y = a * gelu_tanh(gate)
+        y = r16(a * gelu_tanh(gate))
         y = dense(y, p[t + "ff.net.2.weight"], p[t + "ff.net.2.bias"])
-        x = y + x
+        x = r16(y + x)
         if use_linear:
             x = dense(x, p[pre + "proj_out.weight"], p[pre + "proj_out.bias"])
         x = x.reshape(b, h, w, c).permute(0, 3, 1, 2)
         if not use_linear:
             x = conv2d(x, p[pre + "proj_out.weight"], p[pre + "proj_out.bias"], padding=0)
-        return x + x_in
+        return r16(x + x_in)
 
     def _layer(self, pre, layer, h, emb, context):
         p = self.p
@@ -291,8 +332,8 @@ class UNetOracle:
     @torch.no_grad()
     def forward(self, x, timesteps, context):
         p = self.p
-        x = torch.as_tensor(x, dtype=torch.float32)
-        context = torch.as_tensor(context, dtype=torch.float32)
+        x = r16(torch.as_tensor(x, dtype=torch.float32))              # apply_model casts x_noisy / cond (ddpm.py:291-292)
+        context = r16(torch.as_tensor(context, dtype=torch.float32))
         timesteps = torch.as_tensor(timesteps)
         t_emb = timestep_embedding(timesteps, self.cfg["model_channels"])
         emb = dense(t_emb, p["time_embed.0.weight"], p["time_embed.0.bias"])
@@ -448,8 +489,8 @@ class ModelOracle:
 
     def q_sample(self, x0, t, noise):
         """ddpm.py:197-200."""
-        a = torch.as_tensor(self.sqrt_alphas_cumprod)[t].reshape(-1, 1, 1, 1)
-        b = torch.as_tensor(self.sqrt_one_minus_alphas_cumprod)[t].reshape(-1, 1, 1, 1)
+        a = r16(torch.as_tensor(self.sqrt_alphas_cumprod))[t].reshape(-1, 1, 1, 1)
+        b = r16(torch.as_tensor(self.sqrt_one_minus_alphas_cumprod))[t].reshape(-1, 1, 1, 1)
         return a * x0 + b * noise
 
 
@@ -469,15 +510,19 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
     if sampler == "plms" and eta != 0:
         raise ValueError("ddim_eta must be 0 for PLMS")  # plms.py:35-36
     ts = make_ddim_timesteps(S, model.num_timesteps)
-    sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(model.alphas_cumprod, ts, eta)
-    sqrt_one_minus_alphas = np.sqrt(1.0 - alphas).astype(np.float32)
+    # fp16 mode: the schedule tables are tensors of the MODEL dtype (ddpm.py:129-139 `to_mindspore = partial(ms.Tensor,
+    # dtype=self.dtype)`), so everything the sampler derives from them starts from fp16-rounded alphas_cumprod and is itself
+    # an fp16 op result (plms.py:47-67); `ms.numpy.full` then widens the selected scalars to fp32 (plms.py:212-215)
+    ac, acp = r16(np.asarray(model.alphas_cumprod, np.float32)), r16(np.asarray(model.alphas_cumprod_prev, np.float32))
+    sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(ac, ts, eta)
+    sigmas = r16(sigmas)
+    sqrt_one_minus_alphas = r16(np.sqrt(r16(1.0 - alphas)).astype(np.float32))
     if ddim_use_original_steps:   # plms.py:134-135, 141-142, 205-208; sigmas: plms.py:64-67
         n_orig = model.num_timesteps if timesteps is None else int(timesteps)
         ts = np.arange(n_orig, dtype=np.int64)
-        ac, acp = model.alphas_cumprod, model.alphas_cumprod_prev
         alphas, alphas_prev = ac, acp
-        sqrt_one_minus_alphas = np.sqrt(1.0 - ac).astype(np.float32)
-        sigmas = (np.float32(eta) * np.sqrt((1 - acp) / (1 - ac) * (1 - ac / acp))).astype(np.float32)
+        sqrt_one_minus_alphas = r16(np.sqrt(r16(1.0 - ac)).astype(np.float32))
+        sigmas = r16((np.float32(eta) * np.sqrt((1 - acp) / (1 - ac) * (1 - ac / acp))).astype(np.float32))
     elif timesteps is not None:   # plms.py:137-139
         subset_end = int(min(timesteps / ts.shape[0], 1) * ts.shape[0]) - 1
         ts = ts[:subset_end]
@@ -513,7 +558,7 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
         t_in = torch.cat([t, t], 0)
         c_in = wrap(torch.cat([uc, cond], 0), 2)
         e_u, e_c = model.apply_model(x_in, t_in, c_in).chunk(2, dim=0)
-        return e_u + scale * (e_c - e_u)
+        return r16(e_u + r16(scale * r16(e_c - e_u)))     # fp16 mode: eps is an fp16 tensor, each op rounds (plms.py:197)
 
     drops = [0]
 
@@ -547,13 +592,14 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
         elif len(old_eps) == 0:
             x_prev, _ = x_prev_and_pred_x0(img, e_t, index)
             e_next = get_model_output(x_prev, t_next)
-            e_prime = (e_t + e_next) / 2
+            e_prime = r16(r16(e_t + e_next) / 2)
         elif len(old_eps) == 1:
-            e_prime = (3 * e_t - old_eps[-1]) / 2
+            e_prime = r16(r16(r16(3 * e_t) - old_eps[-1]) / 2)
         elif len(old_eps) == 2:
-            e_prime = (23 * e_t - 16 * old_eps[-1] + 5 * old_eps[-2]) / 12
+            e_prime = r16(r16(r16(r16(23 * e_t) - r16(16 * old_eps[-1])) + r16(5 * old_eps[-2])) / 12)
         else:
-            e_prime = (55 * e_t - 59 * old_eps[-1] + 37 * old_eps[-2] - 9 * old_eps[-3]) / 24
+            e_prime = r16(r16(r16(r16(r16(55 * e_t) - r16(59 * old_eps[-1])) + r16(37 * old_eps[-2]))
+                              - r16(9 * old_eps[-3])) / 24)
         img, pred_x0 = x_prev_and_pred_x0(img, e_prime, index)
         old_eps.append(e_t)
         if len(old_eps) >= 4:

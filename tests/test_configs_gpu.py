@@ -1,0 +1,234 @@
+"""One parity test per BASELINE.json config AT ITS BENCHMARKED SHAPE (bench.py CONFIGS): the UNet batch, latent size and
+sampler that `bench.py --config ...` times, through the same plan / hipGraph / tile-table dispatch -- so every row of
+csrc/gemm_tuned.inc that a benchmark exercises is also exercised (and asserted to be hit) under a parity check.
+
+How a full batch is checked without running the fp32 CPU oracle on every row (0.8-2.1 TFLOP per row on the host):
+  * ORACLE rows: one or two rows of the full-batch HIP output are compared with oracle rows computed on the CPU
+    (same tolerance as the B = 1 tests: rel-L2 <= 5e-3);
+  * CONSISTENCY rows: further rows of the full-batch output are compared with B = 1 HIP evaluations of the same inputs
+    (which test_unet_gpu.py pins against the oracle): equal up to fp16 rounding of the different tile / split-K choices,
+    rel-L2 <= 2e-3;
+  * trajectories run at the benchmarked batch, the oracle follows image 0 (trajectories of different images are
+    independent).
+Measured values go to gpurun_out/parity_log.jsonl (copied to profiles/parity_r02.jsonl).
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from _util import ROOT, check
+from oracle import glide as OG
+from oracle import ldm as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _threads():
+    torch.set_num_threads(min(96, os.cpu_count() or 8))
+
+
+def _tuned_table():
+    rows = {}
+    for ln in open(os.path.join(ROOT, "minddiffusion_amd", "csrc", "gemm_tuned.inc")):
+        m = re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", ln)
+        if m:
+            v = [int(g) for g in m.groups()]
+            rows[tuple(v[:4])] = tuple(v[4:])
+    return rows
+
+
+def _assert_tuned_rows_hit(plan, name, min_hits):
+    """Every descriptor of the plan whose (M, N, K, ksize) is in the measured tile table must resolve to that row's
+    tile_m / tile_n / split (mdx_gemm_query = the decision path of mdx_gemm_f16 without the launch)."""
+    from minddiffusion_amd import ops
+    table = _tuned_table()
+    hits, kinds = 0, set()
+    for d in plan.descs:
+        M = d.B * d.H * d.W
+        key = (M, d.N, d.ksize * d.ksize * (d.c1 + d.c2), d.ksize)
+        tm, tn, ns, halo, tuned = ops.gemm_query(d)
+        kinds.add((tm, tn, halo))
+        if key in table and d.stride == 1 and not d.upsample and tuned:
+            bm, bn, tns = table[key]
+            assert tm == bm and (bn == 0 or tn == bn) and 1 <= ns <= max(tns, 1), (name, key, (tm, tn, ns), table[key])
+            assert (ns > 1) == (tns > 1), (name, key, ns, tns)
+            hits += 1
+        else:
+            assert not tuned or key in table
+    print("PARITY", {"name": f"{name}_tuned_rows_hit", "hits": hits, "descs": len(plan.descs), "tile_kinds": sorted(kinds)})
+    assert hits >= min_hits, f"{name}: only {hits} descriptors hit the tuned table (expected >= {min_hits})"
+    return hits
+
+
+def _unet(cfg, ocfg, seed):
+    from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    params = O.init_params(ocfg, seed=seed)
+    net = UNetModel(**dict(cfg))
+    net.use_graph = True
+    net.load_state_dict(params)
+    return net, O.UNetOracle(ocfg, params)
+
+
+def _ldm_full_batch_case(name, cfg, ocfg, B, hw, ctx_dim, t, oracle_rows, consistency_rows, seed, min_hits):
+    _threads()
+    net, oracle = _unet(cfg, ocfg, seed)
+    rng = np.random.RandomState(100 + seed)
+    x = rng.randn(B, 4, hw, hw).astype(np.float32)
+    ctx = rng.randn(B, 77, ctx_dim).astype(np.float32)
+    ts = np.full((B,), t, np.float32)
+    dev = lambda a: torch.tensor(a, device=DEV)
+    got = net(dev(x), dev(ts), dev(ctx)).cpu()
+    assert net._plans[(B, hw, hw)].graph is not None, "the benchmarked path replays a hipGraph"
+    _assert_tuned_rows_hit(net._plans[(B, hw, hw)], name, min_hits)
+    for r in oracle_rows:
+        ref = oracle(x[r:r + 1], torch.tensor(ts[r:r + 1]), ctx[r:r + 1])
+        check(f"{name}_B{B}_row{r}_vs_oracle", got[r:r + 1], ref, rel_l2=5e-3, max_abs=5e-2)
+    for r in consistency_rows:
+        one = net(dev(x[r:r + 1]), dev(ts[r:r + 1]), dev(ctx[r:r + 1])).cpu()
+        check(f"{name}_B{B}_row{r}_vs_B1_hip", got[r:r + 1], one, rel_l2=2e-3, max_abs=2e-2)
+    return net, oracle
+
+
+# --------------------------------------------------------------------------------------------- config 1: SDv2 512, DDIM-50, B=1
+def test_config1_sd2_512_ddim10_cfg9_full_size_trajectory():
+    """BASELINE configs[1] (the headline): SDv2 UNet, 64x64 latent, CFG 9.0, batch 1 (UNet batch 2), per-run time-embedding
+    table + hipGraph = the path bench.py times -- ten DDIM steps against the oracle's sampler (20 oracle row evaluations),
+    plus the tile-table assertion at UNet batch 2."""
+    from minddiffusion_amd.configs import SD2_UNET
+    from minddiffusion_amd.ldm.models.diffusion.ddim import DDIMSampler
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    _threads()
+    net, oracle = _unet(SD2_UNET, O.SD2_UNET, 4)
+    model = LatentDiffusion(net, linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    S, scale = 10, 9.0
+    x_T = np.random.RandomState(42).randn(1, 4, 64, 64).astype(np.float32)
+    c = np.random.RandomState(1).randn(1, 77, 1024).astype(np.float32)
+    uc = np.random.RandomState(2).randn(1, 77, 1024).astype(np.float32)
+    ref, ref_inter = O.sample(O.ModelOracle(oracle), S, 1, (4, 64, 64), c, x_T, "ddim", unconditional_guidance_scale=scale,
+                              unconditional_conditioning=uc)
+    got, inter = DDIMSampler(model).sample(S, 1, (4, 64, 64), conditioning=torch.tensor(c, device=DEV),
+                                           x_T=torch.tensor(x_T, device=DEV), unconditional_guidance_scale=scale,
+                                           unconditional_conditioning=torch.tensor(uc, device=DEV), verbose=False)
+    P = net._plans[(2, 64, 64)]
+    assert P.graph is not None
+    _assert_tuned_rows_hit(P, "config1_sd2_512_unet_b2", 8)
+    check("config1_sd2_512_ddim10_cfg9_latent", got, ref, rel_l2=1e-2, max_rel=2e-2)
+    check("config1_sd2_512_ddim10_cfg9_pred_x0", inter["pred_x0"][-1], ref_inter["pred_x0"][-1], rel_l2=2e-2)
+
+
+@pytest.mark.parametrize("sampler", ["ddim", "plms"])
+def test_config1_length_50_step_trajectory_tiny_unet(sampler):
+    """The benchmarked LENGTH: 50 sampler steps (DDIM: 50 UNet calls, PLMS: 51) with CFG on the tiny UNet, at the stated
+    trajectory bar (rel-L2 <= 1e-2 'after 50 steps')."""
+    from minddiffusion_amd.configs import TINY_UNET
+    from minddiffusion_amd.ldm.models.diffusion.ddim import DDIMSampler
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from minddiffusion_amd.ldm.models.diffusion.plms import PLMSSampler
+    cfg = dict(TINY_UNET)
+    ocfg = dict(cfg)
+    ocfg.setdefault("num_heads", -1)
+    ocfg.setdefault("num_head_channels", -1)
+    net, oracle = _unet(cfg, ocfg, 3)
+    model = LatentDiffusion(net, linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    omodel = O.ModelOracle(oracle)
+    B, H, W, T, S, scale = 2, 8, 8, 6, 50, 7.5
+    x_T = np.random.RandomState(42).randn(B, 4, H, W).astype(np.float32)
+    c = np.random.RandomState(1).randn(B, T, cfg["context_dim"]).astype(np.float32)
+    uc = np.repeat(np.random.RandomState(2).randn(1, T, cfg["context_dim"]).astype(np.float32), B, 0)
+    omodel.calls = 0
+    ref, _ = O.sample(omodel, S, B, (4, H, W), c, x_T, sampler, unconditional_guidance_scale=scale,
+                      unconditional_conditioning=uc)
+    assert omodel.calls == (S + 1 if sampler == "plms" else S)
+    cls = PLMSSampler if sampler == "plms" else DDIMSampler
+    got, _ = cls(model).sample(S, B, (4, H, W), conditioning=torch.tensor(c, device=DEV), x_T=torch.tensor(x_T, device=DEV),
+                               unconditional_guidance_scale=scale, unconditional_conditioning=torch.tensor(uc, device=DEV),
+                               verbose=False)
+    check(f"config1_length_tiny_{sampler}_S50_cfg7.5", got, ref, rel_l2=1e-2, max_rel=1e-2)
+
+
+# --------------------------------------------------------------------------------------------- config 2: Wukong 512, PLMS, B=8
+def test_config2_wukong_512_unet_batch16_and_plms():
+    """BASELINE configs[2]: Wukong-Huahua UNet (8 heads -> d = 40 / 80 / 160, 1x1-conv proj, ctx 768) at UNet batch 16
+    (8 images x CFG), 64x64 latent; then PLMS (pseudo improved Euler + AB-2: 3 UNet calls at batch 16) with the oracle
+    following image 0."""
+    from minddiffusion_amd.configs import WUKONG_UNET
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from minddiffusion_amd.ldm.models.diffusion.plms import PLMSSampler
+    net, oracle = _ldm_full_batch_case("config2_wukong_512", WUKONG_UNET, O.WUKONG_UNET, 16, 64, 768, 301.0,
+                                       oracle_rows=[3], consistency_rows=[0, 15], seed=2, min_hits=5)
+    model = LatentDiffusion(net, linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    S, scale, Bi = 2, 7.5, 8
+    rng = np.random.RandomState(7)
+    x_T = rng.randn(Bi, 4, 64, 64).astype(np.float32)
+    c = rng.randn(Bi, 77, 768).astype(np.float32)
+    uc = np.repeat(rng.randn(1, 77, 768).astype(np.float32), Bi, 0)
+    got, _ = PLMSSampler(model).sample(S, Bi, (4, 64, 64), conditioning={"c_crossattn": [torch.tensor(c, device=DEV)]},
+                                       x_T=torch.tensor(x_T, device=DEV), unconditional_guidance_scale=scale,
+                                       unconditional_conditioning={"c_crossattn": [torch.tensor(uc, device=DEV)]}, verbose=False)
+    ref, _ = O.sample(O.ModelOracle(oracle), S, 1, (4, 64, 64), c[:1], x_T[:1], "plms", unconditional_guidance_scale=scale,
+                      unconditional_conditioning=uc[:1])
+    check("config2_wukong_512_plms2_B8_image0", got[:1], ref, rel_l2=1e-2, max_rel=2e-2)
+
+
+# --------------------------------------------------------------------------------------------- config 3: SDv2 768, 4 images / GPU
+def test_config3_sd2_768_unet_batch8_latent96():
+    """BASELINE configs[3] per-GPU share: SDv2 UNet on a 96x96 latent at UNet batch 8 (4 images x CFG): M = 73 728-row
+    launches, N = 9216-token self-attention, the 24x24 / 12x12 convs on the generic kernel."""
+    from minddiffusion_amd.configs import SD2_UNET
+    _ldm_full_batch_case("config3_sd2_768", SD2_UNET, O.SD2_UNET, 8, 96, 1024, 661.0, oracle_rows=[5],
+                         consistency_rows=[0], seed=1, min_hits=4)
+
+
+# --------------------------------------------------------------------------------------------- config 4: Taichu-GLIDE, 8 images / GPU
+def test_config4_glide_base_batch16_and_superres_batch8_full_size():
+    """BASELINE configs[4] per-GPU share: the base model at 2P = 16 rows (64x64, 16-layer text transformer in the step) and
+    the FULL-SIZE super-resolution UNet (6 levels, 192..768 channels) at P = 8 on 256x256: the only place the HALO conv sees
+    W = 256 and the VAE-scale GroupNorm slabs inside a UNet."""
+    from minddiffusion_amd.glide.default_options import model_and_diffusion_defaults, model_and_diffusion_upsample
+    from minddiffusion_amd.glide.diffusion_creator import create_model, create_upsample_model
+    _threads()
+    rng = np.random.RandomState(5)
+    dev = lambda a: torch.tensor(a, device=DEV)
+    # ---- base, 2P = 16: rows 0..7 prompts, rows 8..15 the (shared) random unconditional prompt
+    P = 8
+    bp = OG.init_params(OG.BASE_OPTIONS, seed=0)
+    net = create_model(**model_and_diffusion_defaults())
+    net.load_state_dict(bp)
+    xs = rng.randn(P, 3, 64, 64).astype(np.float32)
+    x = np.concatenate([xs, xs], 0)
+    tok = rng.randint(1, 50000, (2 * P, 128)).astype(np.int32)
+    tok[P:] = tok[P]
+    mask = np.ones((2 * P, 128), np.int32)
+    mask[2, 40:] = 0
+    t = np.full((2 * P,), 982.0, np.float32)
+    got = net(dev(x), dev(t), dev(tok), dev(mask)).cpu()
+    assert net._plans[(2 * P, 64, 64)].graph is not None
+    _assert_tuned_rows_hit(net._plans[(2 * P, 64, 64)], "config4_glide_base_b16", 3)
+    rows = [2, P + 2]                                      # a padded prompt row and its unconditional partner
+    oracle = OG.GlideUNetOracle(OG.BASE_OPTIONS, bp)
+    ref = oracle(x[rows], torch.tensor(t[rows]), tok[rows], mask[rows])
+    check("config4_glide_base_B16_rows_vs_oracle", got[rows], ref, rel_l2=5e-3, max_abs=5e-2)
+    two = net(dev(x[rows]), dev(t[rows]), dev(tok[rows]), dev(mask[rows])).cpu()
+    check("config4_glide_base_B16_rows_vs_B2_hip", got[rows], two, rel_l2=2e-3, max_abs=2e-2)
+    del net, oracle, bp
+    torch.cuda.empty_cache()
+    # ---- super-resolution UNet, P = 8 at 256x256 (1.28 TFLOP per row on the oracle: one row)
+    up = OG.init_params(OG.UPSAMPLE_OPTIONS, seed=1)
+    sr = create_upsample_model(**model_and_diffusion_upsample())
+    sr.load_state_dict(up)
+    xu = rng.randn(P, 3, 256, 256).astype(np.float32)
+    low = np.clip(rng.randn(P, 3, 64, 64) * 0.5, -1, 1).astype(np.float32)
+    tu = np.full((P,), 500.0, np.float32)
+    gotu = sr(dev(xu), dev(tu), dev(low), dev(tok[:P]), dev(mask[:P])).cpu()
+    assert sr._plans[(P, 256, 256)].graph is not None
+    _assert_tuned_rows_hit(sr._plans[(P, 256, 256)], "config4_glide_superres_b8", 3)
+    oracle = OG.GlideUNetOracle(OG.UPSAMPLE_OPTIONS, up)
+    lowq = torch.round((torch.tensor(low[2:3]) + 1) * 127.5) / 127.5 - 1
+    refu = oracle(xu[2:3], torch.tensor(tu[2:3]), tok[2:3], mask[2:3], low_res=lowq)
+    check("config4_glide_superres_B8_row2_vs_oracle", gotu[2:3], refu, rel_l2=5e-3, max_abs=5e-2)
+    oneu = sr(dev(xu[2:3]), dev(tu[2:3]), dev(low[2:3]), dev(tok[2:3]), dev(mask[2:3])).cpu()
+    check("config4_glide_superres_B8_row2_vs_B1_hip", gotu[2:3], oneu, rel_l2=2e-3, max_abs=2e-2)
