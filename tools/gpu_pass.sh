@@ -1,0 +1,45 @@
+#!/bin/bash
+# One GPU-box pass (run from the repo root through gpurun): stages selected by name, outputs under gpurun_out/<tag>/.
+#   tools/gpu_pass.sh <tag> tests bench configs prof pmc opprof
+set -u
+export TMPDIR=/tmp
+TAG=${1:-r02}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+for stage in "$@"; do
+  case $stage in
+    tests)
+      rm -f gpurun_out/parity_log.jsonl
+      timeout 1500 python -m pytest tests -m gpu -q -rf --durations=15 > $OUT/pytest_gpu.log 2>&1
+      tail -25 $OUT/pytest_gpu.log
+      cp gpurun_out/parity_log.jsonl $OUT/parity.jsonl 2>/dev/null
+      timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -2 $OUT/smoke.txt ;;
+    bench)
+      timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json; tail -3 $OUT/bench.err ;;
+    configs)
+      for cfg in wukong_512_plms sd2_768 glide_256 sd2_512_e2e; do
+        timeout 400 python bench.py --config $cfg --no-cpu-baseline --steps 2 > $OUT/bench_$cfg.json 2>> $OUT/bench.err
+        python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/bench_$cfg.json"))
+    print("$cfg", d["value"], d["unit"], "gemm", d["roofline"]["achieved"], "whole", d["roofline"]["whole_path"]["achieved"])
+except Exception as e:
+    print("$cfg FAILED", e)
+PY
+      done ;;
+    prof)
+      timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o $TAG -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_prof.log 2>&1
+      DB=$(find gpurun_out/prof_bench -name "*_results.db" | head -1)
+      [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/bench_kernel_stats.md
+      rm -rf gpurun_out/prof_bench; head -30 $OUT/bench_kernel_stats.md ;;
+    pmc)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        timeout 300 rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc/$c -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $OUT/pmc_$c.log 2>&1
+      done
+      python tools/pmc_traffic.py gpurun_out/pmc > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err; rm -rf gpurun_out/pmc; cat $OUT/pmc_traffic.json | head -40 ;;
+    opprof)
+      timeout 200 python tools/op_profile.py --batch 2 --top 400 > $OUT/op_profile_b2.txt 2>&1; head -8 $OUT/op_profile_b2.txt ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
