@@ -677,14 +677,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
 // BM = 128: 8 x 16 patch, 4 waves (2 blocks per CU).  BM = 256: 16 x 16 patch, 8 waves (one block per CU): the halo grows
 // 180 -> 324 rows for twice the pixels and every weight tile is shared by twice as many rows, so the DMA bytes per MAC --
 // what bounds this kernel (about 60 GB/s per CU, 6 TB/s chip-wide through buffer_load..lds) -- drop by another 45 %.
-template <int BM, int BN, int NSB, bool SWAP>
+//
+// PW = 8 (BM = 128 only): the 8 x 8-pixel images of the deepest UNet level (64 x 64 latents: 16 of the 49 stride-1 convs,
+// K = 11520 / 23040, M = 64 per sample).  An M tile is TWO WHOLE SAMPLES (2 x 64 pixels); each sample's 10 x 10 halo
+// (zero padding from the buffer bounds check) sits in LDS once per 64-channel chunk: 200 halo rows instead of nine
+// 128-row im2col tiles -- the activation share of the per-CU DMA stream (what bounds a lone block per CU,
+// profiles/r01_dma_probe.txt) drops from 144 to 25 KiB per chunk, 288 -> 169 KiB in all at BN = 128.
+template <int BM, int BN, int NSB, bool SWAP, int PW>
 __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel(const GemmParams p) {
+    static_assert(PW == 16 || (PW == 8 && BM == 128), "patch width 16, or 8 with two-sample tiles");
     constexpr int NW = BM / 32;              // waves: (NW/2) x 2, each 64 patch pixels x BN/2 channels
-    constexpr int PH = BM / 16;              // patch rows (8 | 16); patch columns are always 16
+    constexpr int PH = BM / 16;              // PW = 16: patch rows (8 | 16)
+    constexpr int HWD = PW + 2;              // halo width in pixels (18 | 10)
     constexpr int WROWS = BM / (NW / 2);     // patch pixels per wave row (64)
     constexpr int TM = WROWS / 32;
     constexpr int TN = BN / 64;
-    constexpr int HROWS = (PH + 2) * 18;     // halo pixels (180 | 324)
+    constexpr int HROWS = PW == 16 ? (PH + 2) * 18 : (BM / 64) * 100;   // halo pixels (180 | 324 | 200)
     constexpr int HINST = (HROWS + 7) / 8;   // halo DMA instructions per chunk (23 | 41)
     constexpr int HALO_BYTES = HINST * 1024;
     constexpr int HJ = (HINST + NW - 1) / NW;   // ... per wave (6 | 6)
@@ -700,8 +708,10 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     const int hi = lane >> 5;
     const int l31 = lane & 31;
 
-    const int tile_id = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
-    if (tile_id >= p.tiles_m * p.tiles_n) return;
+    // SPREAD order (see gemm_kernel): a single row of M tiles deals its (tile, split) items round-robin to the XCDs
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int tile_id = p.spread ? (int)(blockIdx.x % (unsigned)ntiles) : (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile_id >= ntiles) return;
     int tile_m, tile_n;
     if (p.n_fastest) {
         tile_m = tile_id / p.tiles_n;
@@ -712,11 +722,12 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     }
     trace_mark(p, 0);
     const int n0 = tile_n * BN;
-    const int pw = p.W >> 4, ph = p.H / PH;
-    const int pb = tile_m / (ph * pw);
-    const int prem = tile_m - pb * (ph * pw);
+    // PW = 16: tile = one PH x 16 patch of sample pb.  PW = 8: tile = samples 2 * tile_m and 2 * tile_m + 1 (8 x 8 pixels each).
+    const int pw = PW == 16 ? p.W >> 4 : 1, ph = PW == 16 ? p.H / PH : 1;
+    const int pb = PW == 16 ? tile_m / (ph * pw) : tile_m * (BM / 64);
+    const int prem = PW == 16 ? tile_m - pb * (ph * pw) : 0;
     const int py0 = (prem / pw) * PH, px0 = (prem % pw) * 16;
-    const int split = blockIdx.y;
+    const int split = p.spread ? (int)(blockIdx.x / (unsigned)ntiles) : (int)blockIdx.y;
     const int kt_begin = split * p.ktiles_per_split;            // multiples of 9 (host guarantees chunk-aligned splits)
     const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
     const int nt = kt_end - kt_begin;
@@ -735,11 +746,23 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
 #pragma unroll
     for (int q = 0; q < HJ; ++q) {
         const int hp = (wave * HJ + q) * 8 + lrow;
-        const int hr = hp / 18, hc = hp - hr * 18;
-        const int y = py0 - 1 + hr, x = px0 - 1 + hc;
-        const bool ok = hp < HROWS && y >= 0 && y < p.H && x >= 0 && x < p.W;
-        hal_off[q] = ok ? (unsigned)((pb * p.H + y) * p.W + x) * row_bytes + (unsigned)((lchk ^ ((hc >> 1) & 7)) * 16)
-                        : MDX_OOB;
+        if constexpr (PW == 16) {
+            const int hr = hp / 18, hc = hp - hr * 18;
+            const int y = py0 - 1 + hr, x = px0 - 1 + hc;
+            const bool ok = hp < HROWS && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            hal_off[q] = ok ? (unsigned)((pb * p.H + y) * p.W + x) * row_bytes + (unsigned)((lchk ^ ((hc >> 1) & 7)) * 16)
+                            : MDX_OOB;
+        } else {
+            // two 10 x 10 halos back to back.  Swizzle key = (halo column / 2) % 4 | (halo row % 2) << 2: a ds_read_b128
+            // lane group covers four 4-pixel runs on four consecutive patch rows (8-wide rows), and this key sends its
+            // eight even and eight odd halo pixels to eight distinct 16-B slots each (conflict-free, as for PW = 16)
+            const int sm = hp / 100, r = hp - sm * 100;
+            const int hr = r / 10, hc = r - hr * 10;
+            const int y = hr - 1, x = hc - 1;
+            const bool ok = hp < HROWS && pb + sm < p.B && y >= 0 && y < 8 && x >= 0 && x < 8;
+            const int key = ((hc >> 1) & 3) | ((hr & 1) << 2);
+            hal_off[q] = ok ? (unsigned)(((pb + sm) * 8 + y) * 8 + x) * row_bytes + (unsigned)((lchk ^ key) * 16) : MDX_OOB;
+        }
     }
     unsigned b_off[BJ];
 #pragma unroll
@@ -772,7 +795,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int q = wm * WROWS + i * 32 + l31;
-        hp0[i] = (q >> 4) * 18 + (q & 15);
+        hp0[i] = PW == 16 ? (q >> 4) * 18 + (q & 15) : (q >> 6) * 100 + ((q >> 3) & 7) * 10 + (q & 7);
     }
     const int swz_b = (l31 >> 1) & 7;
     const int b_row_off = 2 * HALO_BYTES + (wn * (BN / 2) + l31) * 128;
@@ -805,13 +828,16 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
             if (t + NSB - 1 < nt) dma_b(kt_begin + t + NSB - 1, wr);
 
             const int ky = tap / 3, kx = tap - ky * 3;
-            const int dq = ky * 18 + kx;
+            const int dq = ky * HWD + kx;
             int a_row[TM], a_key[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int hp = hp0[i] + dq;
                 a_row[i] = hb * HALO_BYTES + hp * 128;
-                a_key[i] = ((((l31 & 15) + kx) >> 1) & 7) << 4;   // swizzle key = halo COLUMN / 2 (see the loader)
+                if constexpr (PW == 16)
+                    a_key[i] = ((((l31 & 15) + kx) >> 1) & 7) << 4;   // swizzle key = halo COLUMN / 2 (see the loader)
+                else   // halo column (l31 & 7) + kx, halo row parity ((l31 >> 3) + ky) & 1 (i * 4 rows keep the parity)
+                    a_key[i] = (((((l31 & 7) + kx) >> 1) & 3) | ((((l31 >> 3) + ky) & 1) << 2)) << 4;
             }
             const char* sb = smem + rd * B_BYTES;
             f16x8 af[2][TM], bf[2][TN];
@@ -846,7 +872,10 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     }
     __syncthreads();
     trace_mark(p, 3);
-    gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split, bpre);
+    if constexpr (PW == 16)
+        gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split, bpre);
+    else   // two whole 64-pixel samples: tile rows are consecutive output rows
+        gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{tile_m * BM}, n0, split, bpre);
     trace_mark(p, 4);
 }
 
@@ -1241,36 +1270,46 @@ bool launch_bn(const GemmCfg& c, const GemmParams& p, bool swap, bool fastk, dim
     return true;
 }
 
-template <int BM, int BN, int NSB, bool SWAP>
+template <int BM, int BN, int NSB, bool SWAP, int PW = 16>
 void launch_halo(const GemmParams& p, dim3 grid, hipStream_t st) {
-    constexpr size_t hinst = ((BM / 16 + 2) * 18 + 7) / 8;
+    constexpr size_t hinst = ((PW == 16 ? (BM / 16 + 2) * 18 : (BM / 64) * 100) + 7) / 8;
     constexpr size_t ring = 2 * hinst * 1024 + (size_t)NSB * BN * 128;
     constexpr size_t epi = (size_t)BM * (BN + 8) * 2 + 4096;
     constexpr size_t lds = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, NSB, SWAP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, NSB, SWAP>), grid, dim3(BM * 2), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW>), grid, dim3(BM * 2), lds, st, p);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int PW = 16>
 void launch_halo_cfg(const GemmParams& p, int nsb, bool swap, dim3 grid, hipStream_t st) {
     if (nsb == 3) {
-        if (swap) launch_halo<BM, BN, 3, true>(p, grid, st); else launch_halo<BM, BN, 3, false>(p, grid, st);
+        if (swap) launch_halo<BM, BN, 3, true, PW>(p, grid, st); else launch_halo<BM, BN, 3, false, PW>(p, grid, st);
     } else {
-        if (swap) launch_halo<BM, BN, 2, true>(p, grid, st); else launch_halo<BM, BN, 2, false>(p, grid, st);
+        if (swap) launch_halo<BM, BN, 2, true, PW>(p, grid, st); else launch_halo<BM, BN, 2, false, PW>(p, grid, st);
     }
 }
 
-// The HALO kernel applies to 3x3 / stride 1 / single-source convs whose image tiles into 8 x 16 patches.
+// 8 x 8-pixel images (the deepest UNet level at a 64 x 64 latent): two whole samples per 128-row tile (PW = 8).
+bool halo8_eligible(const GemmParams& p) {
+    static const char* env8 = getenv("MDX_GEMM_HALO8");
+    if (env8 && atoi(env8) == 0) return false;
+    return p.H == 8 && p.W == 8;
+}
+
+// The HALO kernel applies to 3x3 / stride 1 / single-source convs whose image tiles into 8 x 16 (16 x 16) patches, or
+// whose images are 8 x 8 (bm = 128 only).
 bool halo_eligible(const GemmParams& p, int bm) {
     static const char* env = getenv("MDX_GEMM_HALO");
     if (env && atoi(env) == 0) return false;
-    return p.ksize == 3 && p.stride == 1 && !p.upsample && p.c2 == 0 && p.cin % 64 == 0 && p.H % (bm / 16) == 0 &&
-           p.W % 16 == 0 && p.out_mode == MDX_OUT_ROWMAJOR;
+    if (!(p.ksize == 3 && p.stride == 1 && !p.upsample && p.c2 == 0 && p.cin % 64 == 0 && p.out_mode == MDX_OUT_ROWMAJOR))
+        return false;
+    if (bm == 128 && halo8_eligible(p)) return true;
+    return p.H % (bm / 16) == 0 && p.W % 16 == 0;
 }
 
 }  // namespace
@@ -1390,7 +1429,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     p.n_fastest = ((size_t)p.M * p.cin >= (size_t)p.N * p.K) ? 1 : 0;
     dim3 grid(8 * p.tiles_per_xcd, ns);
     static const int spread_env = getenv("MDX_GEMM_SPREAD") ? atoi(getenv("MDX_GEMM_SPREAD")) : 1;
-    p.spread = (!halo && p.tiles_m == 1 && spread_env) ? 1 : 0;
+    p.spread = (p.tiles_m == 1 && spread_env) ? 1 : 0;
     if (p.spread) grid = dim3(ntiles * ns, 1);
     p.trace = (g_gemm_trace && (size_t)grid.x * grid.y <= g_gemm_trace_slots) ? g_gemm_trace : nullptr;
     GemmCfg cc = c;
@@ -1409,6 +1448,8 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         if (envn && atoi(envn) >= 2 && atoi(envn) <= 3) nsb = atoi(envn);
         if (c.bm == 256) {
             if (bn == 128) launch_halo_cfg<256, 128>(p, nsb, swap, grid, st); else launch_halo_cfg<256, 64>(p, nsb, swap, grid, st);
+        } else if (halo8_eligible(p)) {
+            if (bn == 128) launch_halo_cfg<128, 128, 8>(p, nsb, swap, grid, st); else launch_halo_cfg<128, 64, 8>(p, nsb, swap, grid, st);
         } else {
             if (bn == 128) launch_halo_cfg<128, 128>(p, nsb, swap, grid, st); else launch_halo_cfg<128, 64>(p, nsb, swap, grid, st);
         }

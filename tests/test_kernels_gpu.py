@@ -268,6 +268,32 @@ def test_gemm_conv_halo_rowbias_residual(ops, splitk):
     check(f"conv3x3_halo_rowbias_residual_k{splitk}", from_nhwc(out.float().cpu().numpy(), B, H, W), ref, rel_l2=1e-3)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,splitk", [(2, 64, 64, 1), (3, 128, 192, 1), (5, 320, 72, 0), (2, 1280, 1280, 0),
+                                                (4, 640, 320, 5), (1, 192, 128, 3)])
+def test_gemm_conv_halo8(ops, B, Cin, Cout, splitk):
+    """The two-samples-per-tile HALO variant for 8 x 8 images (the deepest level of a 64 x 64-latent UNet): odd batches leave
+    the last tile half empty, borders on all four sides of every sample, chunk-aligned split-K, N tails, and the fused
+    time-embedding row + residual epilogue; the query must report the HALO kernel."""
+    from minddiffusion_amd import ops as _ops
+    rng = np.random.RandomState(B * 1000 + Cin + Cout)
+    H = W = 8
+    x = h16(rng.standard_normal((B, Cin, H, W)))
+    w = h16(rng.standard_normal((Cout, Cin, 3, 3)) / math.sqrt(9 * Cin))
+    bv = rng.standard_normal(Cout).astype(np.float32)
+    emb = rng.standard_normal((B, Cout + 24)).astype(np.float32)
+    res = h16(rng.standard_normal((B, Cout, H, W)))
+    ref = O.conv2d(torch.tensor(x), torch.tensor(w), torch.tensor(bv)) + torch.tensor(emb[:, 16:16 + Cout])[:, :, None, None] \
+        + torch.tensor(res)
+    embd = dev32(emb)
+    a, wp = dev16(nhwc(x)), pack_conv(w)
+    out = ops.gemm(a, wp, Cout, B, H, W, Cin, bias=dev32(bv), ksize=3, splitk=splitk, rowbias=embd[:, 16:16 + Cout],
+                   rowbias_ld=Cout + 24, residual=dev16(nhwc(res)), residual_ld=Cout)
+    check(f"conv3x3_halo8_B{B}_{Cin}to{Cout}_k{splitk}", from_nhwc(out.float().cpu().numpy(), B, H, W), ref, rel_l2=1e-3)
+    d = _ops.make_gemm_desc(a, wp, Cout, B, H, W, Cin, torch.empty((B * 64, Cout), dtype=torch.float16, device=DEV), Cout,
+                            ksize=3, splitk=1)
+    assert _ops.gemm_query(d)[3] == 1, "8 x 8 stride-1 convs with Cin % 64 == 0 must take the HALO kernel"
+
+
 @pytest.mark.parametrize("M,C,splitk", [(256, 64, 1), (100, 320, 1), (64, 320, 2)])
 def test_gemm_geglu(ops, M, C, splitk):
     """GEGLU (attention.py:41-51): x, gate = split(proj(x)); x * gelu_tanh(gate), fused in the epilogue."""
