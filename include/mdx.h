@@ -62,6 +62,14 @@ size_t mdx_groupnorm_ws_floats(int B, int HW, int C, int groups);
 int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
                       void* y, int B, int HW, int groups, float eps, int silu, float* ws, mdx_stream_t s);
 
+/* GroupNorm whose statistics come from its producers' column partials (mdx_gemm_desc.colstats_out) instead of a reduction
+ * pass over the tensor: ONE launch (normalise + affine [+ SiLU]) and one read of x instead of two launches and two reads.
+ * cs1 / cs2: the producers' colstats buffers of x1 / x2 ([B * nrb][C][2] fp32), nrb1 / nrb2 = row blocks per sample
+ * (HW / rows per block).  Deterministic (fixed-order folds, no atomics). */
+int mdx_groupnorm_colstats_f16(const void* x1, int C1, const float* cs1, int nrb1, const void* x2, int C2, const float* cs2,
+                               int nrb2, const float* gamma, const float* beta, void* y, int B, int HW, int groups,
+                               float eps, int silu, mdx_stream_t s);
+
 /* Same with the FiLM modulation of GLIDE's ResBlock (Taichu-GLIDE/.../unet.py:203-208):
  *   y = silu?( GN(x) * (1 + scale[b][c]) + shift[b][c] ),  scale/shift fp32 rows of stride mod_ld. */
 int mdx_groupnorm_scaleshift_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,
@@ -120,6 +128,14 @@ typedef struct mdx_gemm_desc {
     const float* ln_s;
     int ln_nt;
     float ln_eps;
+    /* GroupNorm statistics from the producer (openaimodel.py:136,159: every GroupNorm input is a conv / Dense output): when
+     * set, the launch also writes, for every ROW BLOCK of its output and every output column n,
+     *   colstats_out[(row_block * N + n) * 2 + {0,1}] = {sum, sum of squares} of the fp16 values stored in that column,
+     * rows per block = the M tile (a HALO conv tile = one 8x16 pixel patch) for a single-pass launch, 64 for a split-K launch
+     * (its fused reduce kernel); mdx_gemm_query reports the number.  Per COLUMN, so that any consumer grouping -- channel
+     * concats, groups that are not aligned to the store granule -- can fold them (mdx_groupnorm_colstats_f16).  Plain row-major
+     * launches only (no GEGLU / transposed / n_split / LayerNorm fold / out_bs); tokens per sample % rows per block == 0. */
+    float* colstats_out;
     int tile_m;           /* 0 = auto (tuned table, then the cost model); 64 | 128 forces the M tile.  For tools/tune_gemm.py,
                              which measures the (tile_m, splitk) candidates of every UNet shape on the device. */
     int tile_n;           /* 0 = auto; 64 | 128 forces the N tile (same purpose; GEGLU always uses 128) */
@@ -139,10 +155,10 @@ size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d);
 /* Host-only validation of a descriptor (no launch): MDX_OK or MDX_E_INVALID with mdx_last_error() set. */
 int mdx_gemm_check(const mdx_gemm_desc* d);
 /* What mdx_gemm_f16 WOULD launch for this descriptor (host only, nothing is launched):
- * out5 = {tile_m, tile_n, splitk, kernel (0 = generic implicit GEMM, 1 = HALO 3x3 conv), 1 if the choice came from the
- * measured tile table csrc/gemm_tuned.inc}.  The parity tests assert with it that the table rows are hit at the
- * benchmarked shapes. */
-int mdx_gemm_query(const mdx_gemm_desc* d, int* out5);
+ * out6 = {tile_m, tile_n, splitk, kernel (0 = generic implicit GEMM, 1 = HALO 3x3 conv), 1 if the choice came from the
+ * measured tile table csrc/gemm_tuned.inc, rows per colstats_out row block (0 = this launch cannot produce column
+ * statistics)}.  The parity tests assert with it that the table rows are hit at the benchmarked shapes. */
+int mdx_gemm_query(const mdx_gemm_desc* d, int* out6);
 
 /* ---- CrossAttention core: softmax(q k^T * scale) v, flash-style (attention.py:138-152);
  *      the [b*h, N, N] score tensor of the reference is never materialised.

@@ -36,6 +36,10 @@ struct GnParams {
     const float* scale;   // optional FiLM modulation rows [B][mod_ld] (GLIDE ResBlock): y = GN(x)*(1+scale)+shift
     const float* shift;
     int mod_ld;
+    // statistics from the producers' column partials (mdx_gemm_desc.colstats_out) instead of gn_stats: [B * nrb][Cx][2]
+    const float* cs1;
+    const float* cs2;
+    int nrb1, nrb2;
 };
 
 __device__ __forceinline__ f16x8 gn_load(const GnParams& p, int b, int pix, int col) {
@@ -143,10 +147,43 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
     const int tid = threadIdx.x;
     const int ng = chs / p.cpg;
     const int g0 = col0 * 8 / p.cpg;
+    if (p.cs1) {
+        // statistics = the producers' per-column {sum, sumsq} of every row block of this sample, folded per channel (fixed
+        // order), then per group: no pass over the tensor.  The channel concat keeps its two sources' partial arrays apart.
+        float* csum = gstat + 64;                    // [chs][2]
+        for (int c = tid; c < chs; c += 256) {
+            const int ch = col0 * 8 + c;
+            const bool first = ch < p.C1;
+            const float2* base = reinterpret_cast<const float2*>(first ? p.cs1 : p.cs2);
+            const int cx = first ? p.C1 : p.C2, cc = first ? ch : ch - p.C1, nrb = first ? p.nrb1 : p.nrb2;
+            const float2* src = base + (size_t)b * nrb * cx + cc;
+            float su = 0.f, sq = 0.f;
+            int k = 0;
+            for (; k + 4 <= nrb; k += 4) {
+                const float2 v0 = src[(size_t)k * cx], v1 = src[(size_t)(k + 1) * cx], v2 = src[(size_t)(k + 2) * cx],
+                             v3 = src[(size_t)(k + 3) * cx];
+                su += v0.x; sq += v0.y; su += v1.x; sq += v1.y; su += v2.x; sq += v2.y; su += v3.x; sq += v3.y;
+            }
+            for (; k < nrb; ++k) {
+                const float2 v = src[(size_t)k * cx];
+                su += v.x;
+                sq += v.y;
+            }
+            csum[c * 2] = su;
+            csum[c * 2 + 1] = sq;
+        }
+        __syncthreads();
+    }
     {
         const int g = tid >> 3, j = tid & 7;
         float s = 0.f, q = 0.f;
-        if (g < ng) {
+        if (g < ng && p.cs1) {
+            const float* csum = gstat + 64;
+            for (int c = g * p.cpg + j; c < (g + 1) * p.cpg; c += 8) {
+                s += csum[c * 2];
+                q += csum[c * 2 + 1];
+            }
+        } else if (g < ng) {
             const float* w = p.ws + ((size_t)b * p.nblk * p.groups + g0 + g) * 2;
             for (int k = j; k < p.nblk; k += 8) {
                 s += w[(size_t)k * p.groups * 2];
@@ -465,8 +502,9 @@ extern "C" size_t mdx_groupnorm_ws_floats(int B, int HW, int C, int groups) {
 
 static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
                           const float* scale, const float* shift, int mod_ld, void* y, int B, int HW, int groups,
-                          float eps, int silu, float* ws, mdx_stream_t s) {
-    MDX_REQUIRE(x1 && gamma && beta && y && ws, "mdx_groupnorm_f16: null pointer");
+                          float eps, int silu, float* ws, mdx_stream_t s, const float* cs1 = nullptr, int nrb1 = 0,
+                          const float* cs2 = nullptr, int nrb2 = 0) {
+    MDX_REQUIRE(x1 && gamma && beta && y && (ws || cs1), "mdx_groupnorm_f16: null pointer");
     MDX_REQUIRE((C2 == 0) == (x2 == nullptr), "mdx_groupnorm_f16: x2/C2 mismatch");
     MDX_REQUIRE((scale == nullptr) == (shift == nullptr), "mdx_groupnorm_scaleshift_f16: scale/shift mismatch");
     const int C = C1 + C2;
@@ -496,7 +534,34 @@ static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const 
     p.scale = scale;
     p.shift = shift;
     p.mod_ld = mod_ld;
+    p.cs1 = cs1;
+    p.cs2 = cs2;
+    p.nrb1 = nrb1;
+    p.nrb2 = nrb2;
     hipStream_t st = (hipStream_t)s;
+    if (cs1) {
+        // one launch: gn_apply with its statistics folded from the producers' column partials.  Minimal column blocks
+        // (whole groups AND whole 16-byte chunks) keep the fold short: chs * nrb float2 loads per block.
+        MDX_REQUIRE(nrb1 > 0 && (C2 == 0 || (cs2 && nrb2 > 0)), "mdx_groupnorm_colstats_f16: missing column statistics");
+        const int lcm = p.cpg / gcd_i(p.cpg, 8) * 8;
+        const int L = lcm / 8;
+        MDX_REQUIRE(L <= 64, "mdx_groupnorm_colstats_f16: %d channels per group is not supported", p.cpg);
+        int cw = L * ((4 + L - 1) / L);      // >= 64 bytes per pixel row
+        if (cw > p.CC) cw = p.CC;
+        p.cw = cw;
+        p.ncb = (p.CC + cw - 1) / cw;
+        int nblk = (GN_TARGET_BLOCKS + p.ncb * B - 1) / (p.ncb * B);
+        const int max_by_pix = (HW + 3) / 4;
+        if (nblk > 256) nblk = 256;
+        if (nblk > max_by_pix) nblk = max_by_pix;
+        if (nblk < 1) nblk = 1;
+        p.pix = (HW + nblk - 1) / nblk;
+        p.nblk = (HW + p.pix - 1) / p.pix;
+        dim3 grid(p.nblk, p.ncb, B);
+        hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), ((size_t)cw * 8 * 2 + 64 + (size_t)cw * 8 * 2) * sizeof(float), st, p);
+        MDX_LAUNCH_CHECK("mdx_groupnorm_colstats_f16");
+        return MDX_OK;
+    }
     {
         // fused single-launch path when one block can walk all pixels of its column block quickly: <= 64 KiB per block,
         // i.e. the 16x16 and 8x8 latent levels (measured per shape: 8.7 vs 12.4 us at HW = 256, 7.5 vs 10.7 at HW = 64;
@@ -538,6 +603,14 @@ extern "C" int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2,
                                  const float* beta, void* y, int B, int HW, int groups, float eps, int silu,
                                  float* ws, mdx_stream_t s) {
     return groupnorm_impl(x1, C1, x2, C2, gamma, beta, nullptr, nullptr, 0, y, B, HW, groups, eps, silu, ws, s);
+}
+
+extern "C" int mdx_groupnorm_colstats_f16(const void* x1, int C1, const float* cs1, int nrb1, const void* x2, int C2,
+                                          const float* cs2, int nrb2, const float* gamma, const float* beta, void* y, int B,
+                                          int HW, int groups, float eps, int silu, mdx_stream_t s) {
+    MDX_REQUIRE(cs1, "mdx_groupnorm_colstats_f16: null column statistics");
+    return groupnorm_impl(x1, C1, x2, C2, gamma, beta, nullptr, nullptr, 0, y, B, HW, groups, eps, silu, nullptr, s, cs1, nrb1,
+                          cs2, nrb2);
 }
 
 extern "C" int mdx_groupnorm_scaleshift_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,

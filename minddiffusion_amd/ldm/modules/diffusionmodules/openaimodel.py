@@ -381,9 +381,13 @@ class UNetModel:
         TC = self.max_context_len
         P.B, P.H, P.W = B, H, W
 
+        producer = {}     # device address of a tensor -> the GEMM descriptor that wrote it last (planning order == run order)
+
         def add_gemm(oplist, **kw):
             d = ops.make_gemm_desc(**kw)
             descs.append(d)
+            if oplist is main:
+                producer[kw["out"].data_ptr()] = d
             fn = (lambda d=d: ops.gemm_run(d))
             if oplist is main:
                 ks, st, up = kw.get("ksize", 1), kw.get("stride", 1), kw.get("upsample", 0)
@@ -403,10 +407,18 @@ class UNetModel:
             Bq, HW, C1 = x1.shape
             C2 = 0 if x2 is None else x2.shape[2]
             gn_need[0] = max(gn_need[0], ops.groupnorm_ws_floats(Bq, HW, C1 + C2))
-            call = dict(x1=x1, x2=x2, g=g, b=b, eps=eps, silu=silu, out=out)
+            call = dict(x1=x1, x2=x2, g=g, b=b, eps=eps, silu=silu, out=out, cs=None, meta=len(meta),
+                        prod=(producer.get(x1.data_ptr()), None if x2 is None else producer.get(x2.data_ptr())))
+            producer.pop(out.data_ptr(), None)      # the GroupNorm output is not a GEMM output
             gn_calls.append(call)
-            emit(lambda c=call: ops.groupnorm(c["x1"], c["x2"], c["g"], c["b"], c["eps"], c["silu"], ws=P.gn_ws, out=c["out"]),
-                 "groupnorm", 0, 2, f"B={Bq} HW={HW} C={C1 + C2}")
+
+            def run(c=call):
+                if c["cs"] is not None:     # statistics from the producers' epilogues: one launch, one read of x
+                    cs1, n1, cs2, n2 = c["cs"]
+                    return ops.groupnorm_colstats(c["x1"], cs1, n1, c["x2"], cs2, n2, c["g"], c["b"], c["eps"], c["silu"],
+                                                  out=c["out"])
+                return ops.groupnorm(c["x1"], c["x2"], c["g"], c["b"], c["eps"], c["silu"], ws=P.gn_ws, out=c["out"])
+            emit(run, "groupnorm", 0, 2, f"B={Bq} HW={HW} C={C1 + C2}")
 
         # ---- time embedding (openaimodel.py:550-551, 150-157): 4 tiny launches
         mc, ted = self.model_channels, self.time_embed_dim
@@ -624,6 +636,41 @@ class UNetModel:
             d.workspace = P.gemm_ws.data_ptr()
             d.workspace_bytes = P.gemm_ws.numel() * 4
         P.gn_ws = torch.empty(max(gn_need[0], 4), dtype=f32, device=dev)
+        # ---- GroupNorm statistics from the producers (mdx_gemm_desc.colstats_out): every GroupNorm input of the UNet is a conv
+        # / Dense output (openaimodel.py:136,159,521; attention.py:83), so the launch that stores it can also emit per-column
+        # {sum, sumsq} of each of its row blocks; the GroupNorm then folds those instead of re-reading the tensor (gn_stats
+        # disappears: one launch and one read instead of two).  Done for the tensors that take the two-launch path today
+        # (>= 1024 pixels per sample); the small deep-level tensors already use the one-launch fused kernel.
+        P.colstats = {}
+        use_cs = os.environ.get("MDX_UNET_GN_COLSTATS", "1") != "0"
+        if True:
+            def stats_of(d, hw, cx):
+                if d is None or d.N != cx or d.out_ld != cx:
+                    return None
+                rows = ops.gemm_query(d)[5]
+                if rows <= 0 or hw % rows:
+                    return None
+                key = ctypes.addressof(d)
+                if key not in P.colstats:
+                    P.colstats[key] = torch.zeros((B * (hw // rows), cx, 2), dtype=f32, device=dev)
+                    d.colstats_out = P.colstats[key].data_ptr()
+                return P.colstats[key], hw // rows
+            for c in gn_calls:
+                Bq, HW, C1 = c["x1"].shape
+                C2 = 0 if c["x2"] is None else c["x2"].shape[2]
+                cpg = (C1 + C2) // 32
+                L = cpg // math.gcd(cpg, 8)          # chunk columns of the minimal whole-group column block
+                if L <= 64 and HW * L * 16 <= (64 << 10):
+                    meta[c["meta"]]["launches"] = 1
+                    continue                         # one-launch fused kernel (norm.hip groupnorm_impl)
+                if not use_cs:
+                    continue
+                s1 = stats_of(c["prod"][0], HW, C1)
+                s2 = stats_of(c["prod"][1], HW, C2) if C2 else (None, 0)
+                if s1 is None or s2 is None:
+                    continue
+                c["cs"] = (s1[0], s1[1], s2[0], s2[1])
+                meta[c["meta"]]["launches"] = 1
         P.main, P.ctxops, P.descs, P.meta = main, ctxops, descs, meta
         assert len(main) == len(meta)
         P.arena_bytes = A.total

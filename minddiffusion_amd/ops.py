@@ -71,6 +71,19 @@ def groupnorm(x1, x2, gamma, beta, eps, silu, ws=None, out=None, groups=32):
     return out
 
 
+def groupnorm_colstats(x1, cs1, nrb1, x2, cs2, nrb2, gamma, beta, eps, silu, out=None, groups=32):
+    """GroupNorm(groups)(cat(x1, x2)) [+SiLU] with the statistics folded from the producers' column partials
+    (mdx_gemm_desc.colstats_out): one launch, one read of x."""
+    B, HW, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[2]
+    if out is None:
+        out = torch.empty((B, HW, C1 + C2), dtype=f16, device=x1.device)
+    _lib.check(_lib.load().mdx_groupnorm_colstats_f16(_ptr(x1), C1, _ptr(cs1), int(nrb1), _ptr(x2), C2, _ptr(cs2), int(nrb2),
+                                                      _ptr(gamma), _ptr(beta), _ptr(out), B, HW, groups, float(eps),
+                                                      int(bool(silu)), _stream()), "mdx_groupnorm_colstats_f16")
+    return out
+
+
 def groupnorm_scaleshift(x1, x2, gamma, beta, scale, shift, mod_ld, eps, silu, ws=None, out=None, groups=32):
     """GLIDE ResBlock FiLM norm: silu?(GN(cat(x1,x2)) * (1 + scale[b]) + shift[b]); scale/shift fp32 views [B, C]."""
     _chk(x1, f16, "x1"); _chk(x2, f16, "x2")
@@ -185,7 +198,7 @@ def pack_conv_weight(w4d, cin_pad=None, cout_pad=None):
 def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, rowbias=None, rowbias_ld=0,
                    residual=None, residual_ld=0, ksize=1, stride=1, upsample=0, epilogue=EPI_NONE,
                    out_mode=OUT_ROWMAJOR, splitk=0, workspace=None, out_bs=0, out2=None, out2_ld=0, n_split=0, asym_pad=0,
-                   stats_out=None, ln_stats=None, ln_s=None, ln_eps=1e-5, tile_m=0, tile_n=0):
+                   stats_out=None, ln_stats=None, ln_s=None, ln_eps=1e-5, tile_m=0, tile_n=0, colstats_out=None):
     d = GemmDesc()
     d.a = a.data_ptr()
     d.a2 = 0 if a2 is None else a2.data_ptr()
@@ -213,6 +226,7 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
     d.ln_nt = 0 if ln_stats is None else (int(c1) + int(c2)) // 64
     d.ln_eps = float(ln_eps)
     d.tile_m, d.tile_n = int(tile_m), int(tile_n)
+    d.colstats_out = 0 if colstats_out is None else colstats_out.data_ptr()
     return d
 
 
@@ -234,8 +248,9 @@ def gemm_workspace_bytes(desc):
 
 
 def gemm_query(desc):
-    """(tile_m, tile_n, splitk, halo, from_tuned_table) mdx_gemm_f16 would use for this descriptor (no launch)."""
-    out = (ctypes.c_int * 5)()
+    """(tile_m, tile_n, splitk, halo, from_tuned_table, colstats rows per block) mdx_gemm_f16 would use for this
+    descriptor (no launch)."""
+    out = (ctypes.c_int * 6)()
     _lib.check(_lib.load().mdx_gemm_query(ctypes.byref(desc), out), "mdx_gemm_query")
     return tuple(int(v) for v in out)
 

@@ -573,3 +573,76 @@ def test_sampler_step(ops, cfg, order, sigma):
     check(f"sampler_step_cfg{int(cfg)}_o{order}_s{sigma}_x", x_out, xp, rel_l2=1e-5)
     check(f"sampler_step_cfg{int(cfg)}_o{order}_s{sigma}_p", p_out, px0, rel_l2=1e-5)
     check(f"sampler_step_cfg{int(cfg)}_o{order}_s{sigma}_e", e_out, e_t, rel_l2=1e-5)
+
+
+# --------------------------------------------------------------------------- GroupNorm statistics from the producer
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks,splitk", [
+    (2, 16, 16, 64, 128, 1, 1),      # generic kernel, single pass (row block = M tile)
+    (2, 16, 32, 128, 192, 3, 1),     # HALO conv: row block = one 8x16 patch
+    (2, 16, 16, 320, 320, 3, 3),     # split-K: the tiled reduce kernel (64-row blocks)
+    (3, 32, 32, 64, 320, 1, 2),      # split-K dense, N tail of the 64-column reduce tiles
+    (1, 64, 64, 64, 320, 3, 1),      # the 64x64-latent level
+])
+def test_gemm_colstats_and_groupnorm_from_them(ops, B, H, W, Cin, Cout, ks, splitk):
+    """mdx_gemm_desc.colstats_out: per-row-block, per-column {sum, sumsq} of the fp16 values the launch stores (bias,
+    time-embedding row and residual included), and mdx_groupnorm_colstats_f16 folding them -- against the two-launch GroupNorm
+    on the same tensor (bit-identical input, statistics summed in a different order) and the oracle."""
+    from minddiffusion_amd import ops as _ops
+    rng = np.random.RandomState(B + H + Cin + Cout + ks)
+    x = h16(rng.standard_normal((B, Cin, H, W)))
+    w = h16(rng.standard_normal((Cout, Cin, ks, ks)) / math.sqrt(ks * ks * Cin))
+    bv = rng.standard_normal(Cout).astype(np.float32)
+    emb = rng.standard_normal((B, Cout)).astype(np.float32)
+    res = h16(rng.standard_normal((B, Cout, H, W)))
+    a, wp = dev16(nhwc(x)), pack_conv(w)
+    out = torch.empty((B * H * W, Cout), dtype=torch.float16, device=DEV)
+    embd, resd = dev32(emb), dev16(nhwc(res))
+    d = _ops.make_gemm_desc(a, wp, Cout, B, H, W, Cin, out, Cout, bias=dev32(bv), ksize=ks, splitk=splitk, rowbias=embd,
+                            rowbias_ld=Cout, residual=resd, residual_ld=Cout)
+    need = _ops.gemm_workspace_bytes(d)
+    wsb = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=DEV)
+    d.workspace, d.workspace_bytes = wsb.data_ptr(), wsb.numel() * 4
+    rows = _ops.gemm_query(d)[5]
+    assert rows > 0 and (H * W) % rows == 0
+    nrb = H * W // rows
+    cs = torch.full((B * nrb, Cout, 2), float("nan"), dtype=torch.float32, device=DEV)
+    d.colstats_out = cs.data_ptr()
+    _ops.gemm_run(d)
+    o = out.float().view(B, H * W, Cout)
+    if rows == 128 and ks == 3:          # HALO patches: 8 rows x 16 columns of pixels
+        img = o.view(B, H // 8, 8, W // 16, 16, Cout).permute(0, 1, 3, 2, 4, 5).reshape(B * nrb, 128, Cout)
+    else:
+        img = o.reshape(B * nrb, rows, Cout)
+    check(f"colstats_sum_{ks}x{ks}_k{splitk}_rows{rows}", cs[..., 0], img.sum(1), rel_l2=1e-5)
+    check(f"colstats_sumsq_{ks}x{ks}_k{splitk}_rows{rows}", cs[..., 1], (img * img).sum(1), rel_l2=1e-5)
+    # consumer: GroupNorm(+SiLU) of cat(out, other) with the second source's statistics from a second producer
+    g = (1 + 0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    bt = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    o3 = out.view(B, H * W, Cout)
+    y_ref = _ops.groupnorm(o3, None, dev32(g), dev32(bt), 1e-5, True)
+    y = _ops.groupnorm_colstats(o3, cs, nrb, None, None, 0, dev32(g), dev32(bt), 1e-5, True)
+    check(f"groupnorm_from_colstats_{ks}x{ks}_k{splitk}", y, y_ref, rel_l2=2e-4, max_abs=4e-3)
+    ref = O.silu(O.group_norm(torch.tensor(from_nhwc(o.cpu().numpy().reshape(B, H * W, Cout), B, H, W)), torch.tensor(g),
+                              torch.tensor(bt), 1e-5))
+    check(f"groupnorm_from_colstats_vs_oracle_{ks}x{ks}_k{splitk}", from_nhwc(y.float().cpu().numpy(), B, H, W), ref, rel_l2=1e-3)
+
+
+def test_groupnorm_colstats_two_sources(ops):
+    """UNet output blocks: GroupNorm over cat(h, skip) (openaimodel.py:568) whose sources come from two producers with
+    different row-block sizes; groups straddle the source boundary (C = 192 + 64, 8 channels per group) and, for C = 960 =
+    640 + 320, are not aligned to the 8-channel store granule (30 channels per group)."""
+    from minddiffusion_amd import ops as _ops
+    for (C1, C2, HW, r1, r2) in ((192, 64, 1024, 128, 64), (640, 320, 4096, 64, 128)):
+        rng = np.random.RandomState(C1 + C2)
+        B = 2
+        x1 = h16(rng.standard_normal((B, HW, C1)) + 0.3)
+        x2 = h16(rng.standard_normal((B, HW, C2)) * 2 - 0.5)
+        st = lambda x, r: np.stack([x.reshape(B * (HW // r), r, -1).sum(1), (x.astype(np.float64) ** 2).reshape(B * (HW // r), r, -1).sum(1)], -1).astype(np.float32)
+        g = (1 + 0.1 * rng.standard_normal(C1 + C2)).astype(np.float32)
+        bt = (0.1 * rng.standard_normal(C1 + C2)).astype(np.float32)
+        y = _ops.groupnorm_colstats(dev16(x1), dev32(st(x1, r1)), HW // r1, dev16(x2), dev32(st(x2, r2)), HW // r2,
+                                    dev32(g), dev32(bt), 1e-6, False)
+        xc = np.concatenate([x1, x2], 2).transpose(0, 2, 1).reshape(B, C1 + C2, HW, 1)
+        ref = O.group_norm(torch.tensor(xc), torch.tensor(g), torch.tensor(bt), 1e-6)
+        got = y.float().cpu().numpy().transpose(0, 2, 1).reshape(B, C1 + C2, HW, 1)
+        check(f"groupnorm_colstats_two_sources_{C1}+{C2}", got, ref, rel_l2=1e-3)
