@@ -136,6 +136,9 @@ typedef struct mdx_gemm_desc {
      * concats, groups that are not aligned to the store granule -- can fold them (mdx_groupnorm_colstats_f16).  Plain row-major
      * launches only (no GEGLU / transposed / n_split / LayerNorm fold / out_bs); tokens per sample % rows per block == 0. */
     float* colstats_out;
+    int defer_reduce;     /* split-K launches only: write the fp32 slabs and do NOT launch the reduce -- the consumer,
+                             mdx_groupnorm_from_splitk_f16, sums them while it normalises (it must run before any other launch
+                             reuses the workspace).  mdx_gemm_f16 fails if the launch does not split. */
     int tile_m;           /* 0 = auto (tuned table, then the cost model); 64 | 128 forces the M tile.  For tools/tune_gemm.py,
                              which measures the (tile_m, splitk) candidates of every UNet shape on the device. */
     int tile_n;           /* 0 = auto; 64 | 128 forces the N tile (same purpose; GEGLU always uses 128) */
@@ -159,6 +162,17 @@ int mdx_gemm_check(const mdx_gemm_desc* d);
  * measured tile table csrc/gemm_tuned.inc, rows per colstats_out row block (0 = this launch cannot produce column
  * statistics)}.  The parity tests assert with it that the table rows are hit at the benchmarked shapes. */
 int mdx_gemm_query(const mdx_gemm_desc* d, int* out6);
+
+/* GroupNorm fused with the split-K reduce of its producer (the small tensors of the deep UNet levels, where one block
+ * normalises a whole (sample, column block) and the conv in front of it is always split): `prod` is the descriptor of a conv /
+ * Dense that ran with defer_reduce = 1.  One launch sums the slabs in slab order, applies the producer's bias / time-embedding
+ * row / residual, stores the producer's fp16 output, computes the statistics of those fp16 values and writes
+ * y = GroupNorm(out) [+ SiLU] -- bit-identical to the reduce kernel followed by mdx_groupnorm_f16.  Returns MDX_E_INVALID when
+ * the tensor does not fit the one-block-per-column-block scheme (the caller then must not defer). */
+int mdx_groupnorm_from_splitk_f16(const mdx_gemm_desc* prod, const float* gamma, const float* beta, void* y, int groups,
+                                  float eps, int silu, mdx_stream_t s);
+/* 1 if mdx_groupnorm_from_splitk_f16 can consume this producer (host only). */
+int mdx_groupnorm_from_splitk_ok(const mdx_gemm_desc* prod, int groups);
 
 /* ---- CrossAttention core: softmax(q k^T * scale) v, flash-style (attention.py:138-152);
  *      the [b*h, N, N] score tensor of the reference is never materialised.

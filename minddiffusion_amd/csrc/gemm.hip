@@ -1683,6 +1683,32 @@ extern "C" int mdx_gemm_query(const mdx_gemm_desc* d, int* out5) {
     return MDX_OK;
 }
 
+// Producer side of mdx_groupnorm_from_splitk_f16: the launch geometry of `d` as mdx_gemm_f16 resolves it.
+int mdx_internal_split_info(const mdx_gemm_desc* d, MdxSplitInfo* info) {
+    GemmParams p{};
+    int rc = fill_params(d, p);
+    if (rc != MDX_OK) return rc;
+    Resolved r;
+    rc = resolve_launch(d, p, r);
+    if (rc != MDX_OK) return rc;
+    MDX_REQUIRE(p.out_mode == MDX_OUT_ROWMAJOR && p.epilogue == MDX_EPI_NONE && !p.n_split && !p.ln_stats && !p.stats_out &&
+                    !p.out_bs && !p.colstats_out && p.out_ld == p.N && p.N % 8 == 0,
+                "deferred split-K reduce: plain dense row-major producers only");
+    info->ws = p.ws;
+    info->nsplit = r.ns;
+    info->M = p.M;
+    info->N = p.N;
+    info->HoWo = p.HoWo;
+    info->B = p.B;
+    info->bias = p.bias;
+    info->rowbias = p.rowbias;
+    info->rowbias_ld = p.rowbias_ld;
+    info->residual = p.residual;
+    info->residual_ld = p.residual_ld;
+    info->out = p.out;
+    return MDX_OK;
+}
+
 extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     GemmParams p{};
     int rc = fill_params(d, p);
@@ -1697,6 +1723,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     const bool halo = rs.halo;
     MDX_REQUIRE(!p.colstats_out || colstats_rows(p, rs) > 0,
                 "mdx_gemm_f16: this launch cannot produce column statistics (ask mdx_gemm_query first)");
+    MDX_REQUIRE(!d->defer_reduce || ns > 1, "mdx_gemm_f16: defer_reduce set but the launch does not split K");
     p.tiles_m = (p.M + c.bm - 1) / c.bm;
     p.tiles_n = (p.N + bn - 1) / bn;
     const bool fastk = (p.cin % 64 == 0) && (p.c2 == 0 || p.c1 % 64 == 0);
@@ -1740,7 +1767,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         ok = (bn == 128) ? launch_bn<128, 128>(cc, p, swap, fastk, grid, st) : launch_bn<128, 64>(cc, p, swap, fastk, grid, st);
     MDX_REQUIRE(ok, "mdx_gemm_f16: unsupported tile configuration bk=%d ns=%d", c.bk, c.ns);
     MDX_LAUNCH_CHECK("mdx_gemm_f16");
-    if (ns > 1) {
+    if (ns > 1 && !d->defer_reduce) {
         const int ncols = p.epilogue == MDX_EPI_GEGLU ? p.N / 2 : p.N;
         const size_t total = (size_t)p.M * (ncols / 8);
         int blocks = (int)((total + 255) / 256);

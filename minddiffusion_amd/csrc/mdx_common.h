@@ -35,6 +35,20 @@ void mdx_set_error(const char* fmt, ...);
         }                                                                             \
     } while (0)
 
+// What a consumer that sums a producer's split-K slabs itself (mdx_groupnorm_from_splitk_f16) needs to know about that
+// producer: filled by gemm.hip from the producer's descriptor with the SAME decision path as mdx_gemm_f16.
+struct MdxSplitInfo {
+    const float* ws;          // [nsplit][M][N] fp32 slabs
+    int nsplit, M, N, HoWo, B;
+    const float* bias;
+    const float* rowbias;
+    int rowbias_ld;
+    const f16* residual;
+    int residual_ld;
+    f16* out;                 // the producer's fp16 output [M][N] (out_ld == N)
+};
+int mdx_internal_split_info(const mdx_gemm_desc* d, MdxSplitInfo* info);
+
 // ---- device helpers
 // sigmoid(x) = 1 / (1 + 2^(-x log2 e)) on the raw transcendental units (v_exp_f32 + v_rcp_f32, 1 ulp each): an IEEE
 // division here costs ~10 VALU instructions per element and the epilogues / GroupNorm apply it to every output.

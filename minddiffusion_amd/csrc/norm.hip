@@ -267,8 +267,47 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
 // stores.  One launch instead of gn_stats + gn_apply for ~30 of the 61 GroupNorms of a UNet evaluation.
 constexpr int GNF_THREADS = 1024;
 constexpr int GNF_FOLD = 16;
+constexpr int GNF_KEEP = 6;      // SLAB variant: pixels a thread keeps in registers between the two passes
 
-__global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GnParams p) {
+// SLAB = true: the input is not a tensor but the fp32 split-K slabs of the conv / Dense that produces it
+// (mdx_groupnorm_from_splitk_f16): element (m, n) = fp16( bias[n] + sum_z ws[z][m][n] + rowbias[b][n] + residual[m][n] ),
+// the additions in exactly the order of splitk_reduce_kernel, so the result is bit-identical to reduce-then-GroupNorm.  The
+// producer's fp16 output is stored on the way (later consumers read it), the values stay in registers for the second pass.
+__device__ __forceinline__ f16x8 gn_slab_load(const MdxSplitInfo& sp, int b, int m, int n) {
+    float f[8];
+    if (sp.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(sp.bias + n), b1 = *reinterpret_cast<const float4*>(sp.bias + n + 4);
+        f[0] = b0.x; f[1] = b0.y; f[2] = b0.z; f[3] = b0.w; f[4] = b1.x; f[5] = b1.y; f[6] = b1.z; f[7] = b1.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    }
+    const size_t slab = (size_t)sp.M * sp.N;
+    const float* base = sp.ws + (size_t)m * sp.N + n;
+    for (int z = 0; z < sp.nsplit; ++z) {
+        const float4 s0 = *reinterpret_cast<const float4*>(base + (size_t)z * slab);
+        const float4 s1 = *reinterpret_cast<const float4*>(base + (size_t)z * slab + 4);
+        f[0] += s0.x; f[1] += s0.y; f[2] += s0.z; f[3] += s0.w; f[4] += s1.x; f[5] += s1.y; f[6] += s1.z; f[7] += s1.w;
+    }
+    if (sp.rowbias) {
+        const float4 r0 = *reinterpret_cast<const float4*>(sp.rowbias + (size_t)b * sp.rowbias_ld + n);
+        const float4 r1 = *reinterpret_cast<const float4*>(sp.rowbias + (size_t)b * sp.rowbias_ld + n + 4);
+        f[0] += r0.x; f[1] += r0.y; f[2] += r0.z; f[3] += r0.w; f[4] += r1.x; f[5] += r1.y; f[6] += r1.z; f[7] += r1.w;
+    }
+    if (sp.residual) {
+        const f16x8 r = *reinterpret_cast<const f16x8*>(sp.residual + (size_t)m * sp.residual_ld + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
+    }
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)f[e];
+    *reinterpret_cast<f16x8*>(sp.out + (size_t)m * sp.N + n) = o;
+    return o;
+}
+
+template <bool SLAB>
+__global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GnParams p, const MdxSplitInfo sp) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [trows][chs][2] partials, then the folds
     const int b = blockIdx.y, cb = blockIdx.x;
     const int col0 = cb * p.cw;
@@ -278,11 +317,28 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GnParams p)
     const int trows = GNF_THREADS / cols;
     const int tc = tid % cols, tr = tid / cols;
     const bool active = tr < trows;
+    f16x8 keep[SLAB ? GNF_KEEP : 1];
     if (active) {
         float s[8], q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
         int pix = tr;
+        if constexpr (SLAB) {
+#pragma unroll
+            for (int k = 0; k < GNF_KEEP; ++k) {
+                const int px = tr + k * trows;
+                if (px < p.HW) {
+                    keep[k] = gn_slab_load(sp, b, b * p.HW + px, (col0 + tc) * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = (float)keep[k][e];
+                        s[e] += f;
+                        q[e] += f * f;
+                    }
+                }
+            }
+            pix = p.HW;      // nothing left for the tensor loops below
+        }
         for (; pix + 7 * trows < p.HW; pix += 8 * trows) {
             f16x8 v[8];
 #pragma unroll
@@ -396,6 +452,12 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GnParams p)
         }
         *reinterpret_cast<f16x8*>(p.y + ((size_t)b * p.HW + pix) * p.C + (col0 + tc) * 8) = o;
     };
+    if constexpr (SLAB) {
+#pragma unroll
+        for (int k = 0; k < GNF_KEEP; ++k)
+            if (tr + k * trows < p.HW) apply(keep[k], tr + k * trows);
+        return;
+    }
     int pix = tr;
     for (; pix + 7 * trows < p.HW; pix += 8 * trows) {
         f16x8 v[8];
@@ -577,11 +639,11 @@ static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const 
             constexpr size_t lds = ((size_t)GNF_THREADS * 8 * 2 + (size_t)GNF_FOLD * 512 * 2 + 512 * 2 + 64 * 2 + 512 * 2) * sizeof(float);
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr_set = true;
             }
-            hipLaunchKernelGGL(gn_fused_kernel, dim3(p.ncb, B), dim3(GNF_THREADS), lds, st, p);
+            hipLaunchKernelGGL(gn_fused_kernel<false>, dim3(p.ncb, B), dim3(GNF_THREADS), lds, st, p, MdxSplitInfo{});
             MDX_LAUNCH_CHECK("mdx_groupnorm_f16(fused)");
             return MDX_OK;
         }
@@ -603,6 +665,60 @@ extern "C" int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2,
                                  const float* beta, void* y, int B, int HW, int groups, float eps, int silu,
                                  float* ws, mdx_stream_t s) {
     return groupnorm_impl(x1, C1, x2, C2, gamma, beta, nullptr, nullptr, 0, y, B, HW, groups, eps, silu, ws, s);
+}
+
+// Geometry of the one-block-per-(sample, column block) scheme for a producer output [B][HW][C]: 0 if it does not apply.
+static int gn_from_splitk_geometry(const MdxSplitInfo& sp, int groups, GnParams& p) {
+    if (groups <= 0 || groups > 32 || sp.N % groups || sp.N % 8 || sp.nsplit < 2) return 0;
+    p.C1 = p.C = sp.N;
+    p.C2 = 0;
+    p.CC1 = p.CC = sp.N / 8;
+    p.B = sp.B;
+    p.HW = sp.HoWo;
+    p.groups = groups;
+    p.cpg = sp.N / groups;
+    const int lcm = p.cpg / gcd_i(p.cpg, 8) * 8;
+    const int L = lcm / 8;
+    if (L > 64 || (size_t)p.HW * L * 16 > (64u << 10)) return 0;
+    p.cw = L > p.CC ? p.CC : L;
+    p.ncb = (p.CC + p.cw - 1) / p.cw;
+    p.nblk = 1;
+    p.pix = p.HW;
+    const int trows = GNF_THREADS / p.cw;
+    return (p.HW + trows - 1) / trows <= GNF_KEEP;
+}
+
+extern "C" int mdx_groupnorm_from_splitk_ok(const mdx_gemm_desc* prod, int groups) {
+    MdxSplitInfo sp{};
+    GnParams p{};
+    return prod && mdx_internal_split_info(prod, &sp) == MDX_OK && gn_from_splitk_geometry(sp, groups, p) ? 1 : 0;
+}
+
+extern "C" int mdx_groupnorm_from_splitk_f16(const mdx_gemm_desc* prod, const float* gamma, const float* beta, void* y,
+                                             int groups, float eps, int silu, mdx_stream_t s) {
+    MDX_REQUIRE(prod && gamma && beta && y, "mdx_groupnorm_from_splitk_f16: null pointer");
+    MdxSplitInfo sp{};
+    int rc = mdx_internal_split_info(prod, &sp);
+    if (rc != MDX_OK) return rc;
+    GnParams p{};
+    MDX_REQUIRE(sp.ws && gn_from_splitk_geometry(sp, groups, p),
+                "mdx_groupnorm_from_splitk_f16: producer does not split K or its output does not fit one block per column block");
+    p.x1 = sp.out;
+    p.gamma = gamma;
+    p.beta = beta;
+    p.y = (f16*)y;
+    p.eps = eps;
+    p.silu = silu;
+    constexpr size_t lds = ((size_t)GNF_THREADS * 8 * 2 + (size_t)GNF_FOLD * 512 * 2 + 512 * 2 + 64 * 2 + 512 * 2) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gn_fused_kernel<true>, dim3(p.ncb, sp.B), dim3(GNF_THREADS), lds, (hipStream_t)s, p, sp);
+    MDX_LAUNCH_CHECK("mdx_groupnorm_from_splitk_f16");
+    return MDX_OK;
 }
 
 extern "C" int mdx_groupnorm_colstats_f16(const void* x1, int C1, const float* cs1, int nrb1, const void* x2, int C2,

@@ -382,12 +382,14 @@ class UNetModel:
         P.B, P.H, P.W = B, H, W
 
         producer = {}     # device address of a tensor -> the GEMM descriptor that wrote it last (planning order == run order)
+        op_index = {}     # descriptor -> index of its op in `main`
 
         def add_gemm(oplist, **kw):
             d = ops.make_gemm_desc(**kw)
             descs.append(d)
             if oplist is main:
                 producer[kw["out"].data_ptr()] = d
+                op_index[ctypes.addressof(d)] = len(main)
             fn = (lambda d=d: ops.gemm_run(d))
             if oplist is main:
                 ks, st, up = kw.get("ksize", 1), kw.get("stride", 1), kw.get("upsample", 0)
@@ -413,6 +415,8 @@ class UNetModel:
             gn_calls.append(call)
 
             def run(c=call):
+                if c.get("fs") is not None:     # the producer deferred its split-K reduce to this GroupNorm (one launch for both)
+                    return ops.groupnorm_from_splitk(c["fs"], c["g"], c["b"], c["eps"], c["silu"], c["out"])
                 if c["cs"] is not None:     # statistics from the producers' epilogues: one launch, one read of x
                     cs1, n1, cs2, n2 = c["cs"]
                     return ops.groupnorm_colstats(c["x1"], cs1, n1, c["x2"], cs2, n2, c["g"], c["b"], c["eps"], c["silu"],
@@ -643,6 +647,7 @@ class UNetModel:
         # (>= 1024 pixels per sample); the small deep-level tensors already use the one-launch fused kernel.
         P.colstats = {}
         use_cs = os.environ.get("MDX_UNET_GN_COLSTATS", "1") != "0"
+        use_fs = os.environ.get("MDX_UNET_GN_SPLITK_FUSE", "1") != "0"
         if True:
             def stats_of(d, hw, cx):
                 if d is None or d.N != cx or d.out_ld != cx:
@@ -661,8 +666,17 @@ class UNetModel:
                 cpg = (C1 + C2) // 32
                 L = cpg // math.gcd(cpg, 8)          # chunk columns of the minimal whole-group column block
                 if L <= 64 and HW * L * 16 <= (64 << 10):
-                    meta[c["meta"]]["launches"] = 1
-                    continue                         # one-launch fused kernel (norm.hip groupnorm_impl)
+                    meta[c["meta"]]["launches"] = 1  # one-launch fused kernel (norm.hip groupnorm_impl)
+                    # ... which can also BE the split-K reduce of the conv right in front of it (the deep levels' convs always
+                    # split): the conv writes its slabs only, this launch sums them, stores the conv output and normalises
+                    d = c["prod"][0]
+                    if (use_fs and C2 == 0 and d is not None and d.N == C1 and d.out_ld == C1
+                            and op_index.get(ctypes.addressof(d)) == c["meta"] - 1 and ops.gemm_query(d)[2] > 1
+                            and ops.groupnorm_from_splitk_ok(d)):
+                        d.defer_reduce = 1
+                        c["fs"] = d
+                        meta[c["meta"] - 1]["launches"] = 1
+                    continue
                 if not use_cs:
                     continue
                 s1 = stats_of(c["prod"][0], HW, C1)

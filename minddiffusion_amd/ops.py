@@ -84,6 +84,18 @@ def groupnorm_colstats(x1, cs1, nrb1, x2, cs2, nrb2, gamma, beta, eps, silu, out
     return out
 
 
+def groupnorm_from_splitk_ok(desc, groups=32):
+    return bool(_lib.load().mdx_groupnorm_from_splitk_ok(ctypes.byref(desc), groups))
+
+
+def groupnorm_from_splitk(desc, gamma, beta, eps, silu, out, groups=32):
+    """GroupNorm fused with the split-K reduce of the conv / Dense `desc` (launched with defer_reduce = 1)."""
+    _lib.check(_lib.load().mdx_groupnorm_from_splitk_f16(ctypes.byref(desc), _ptr(gamma), _ptr(beta), _ptr(out), groups,
+                                                         float(eps), int(bool(silu)), _stream()),
+               "mdx_groupnorm_from_splitk_f16")
+    return out
+
+
 def groupnorm_scaleshift(x1, x2, gamma, beta, scale, shift, mod_ld, eps, silu, ws=None, out=None, groups=32):
     """GLIDE ResBlock FiLM norm: silu?(GN(cat(x1,x2)) * (1 + scale[b]) + shift[b]); scale/shift fp32 views [B, C]."""
     _chk(x1, f16, "x1"); _chk(x2, f16, "x2")

@@ -646,3 +646,55 @@ def test_groupnorm_colstats_two_sources(ops):
         ref = O.group_norm(torch.tensor(xc), torch.tensor(g), torch.tensor(bt), 1e-6)
         got = y.float().cpu().numpy().transpose(0, 2, 1).reshape(B, C1 + C2, HW, 1)
         check(f"groupnorm_colstats_two_sources_{C1}+{C2}", got, ref, rel_l2=1e-3)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks,splitk,silu", [
+    (2, 16, 16, 320, 320, 3, 5, True),      # HALO conv split over chunks, 16x16 level
+    (2, 8, 8, 1280, 1280, 3, 10, True),     # 8x8 level (two-sample HALO tiles), cpg = 40
+    (3, 8, 8, 640, 1920, 1, 2, False),      # dense, cpg = 60 (15-chunk column blocks), odd batch
+    (2, 16, 16, 128, 256, 3, 2, True),      # cpg = 8: one chunk per group
+])
+def test_groupnorm_fused_with_splitk_reduce(ops, B, H, W, Cin, Cout, ks, splitk, silu):
+    """mdx_gemm_desc.defer_reduce + mdx_groupnorm_from_splitk_f16: the GroupNorm launch sums the producer's split-K slabs
+    itself -- the conv output it stores and the normalised tensor must be BIT-IDENTICAL to reduce-kernel-then-GroupNorm."""
+    from minddiffusion_amd import ops as _ops
+    rng = np.random.RandomState(B + H + Cin + Cout)
+    x = h16(rng.standard_normal((B, Cin, H, W)))
+    w = h16(rng.standard_normal((Cout, Cin, ks, ks)) / math.sqrt(ks * ks * Cin))
+    a, wp = dev16(nhwc(x)), pack_conv(w)
+    bias, emb = dev32(rng.standard_normal(Cout).astype(np.float32)), dev32(rng.standard_normal((B, Cout)).astype(np.float32))
+    res = dev16(nhwc(h16(rng.standard_normal((B, Cout, H, W)))))
+    g, bt = dev32((1 + 0.1 * rng.standard_normal(Cout)).astype(np.float32)), dev32((0.1 * rng.standard_normal(Cout)).astype(np.float32))
+
+    def build(out):
+        d = _ops.make_gemm_desc(a, wp, Cout, B, H, W, Cin, out, Cout, bias=bias, ksize=ks, splitk=splitk, rowbias=emb,
+                                rowbias_ld=Cout, residual=res, residual_ld=Cout)
+        return d
+    out_a = torch.zeros((B, H * W, Cout), dtype=torch.float16, device=DEV)
+    out_b = torch.zeros_like(out_a)
+    da, db = build(out_a), build(out_b)
+    need = _ops.gemm_workspace_bytes(da)
+    assert need > 0
+    ws = torch.empty(need // 4, dtype=torch.float32, device=DEV)
+    for d in (da, db):
+        d.workspace, d.workspace_bytes = ws.data_ptr(), need
+    _ops.gemm_run(da)
+    y_a = _ops.groupnorm(out_a, None, g, bt, 1e-5, silu)
+    db.defer_reduce = 1
+    assert _ops.groupnorm_from_splitk_ok(db)
+    _ops.gemm_run(db)
+    assert float(out_b.abs().max()) == 0.0          # the deferred launch left the output to its consumer
+    y_b = torch.empty_like(out_b)
+    _ops.groupnorm_from_splitk(db, g, bt, 1e-5, silu, y_b)
+    assert torch.equal(out_a, out_b), "conv output written by the fused GroupNorm differs from the reduce kernel's"
+    assert torch.equal(y_a, y_b), "fused reduce + GroupNorm differs from reduce-then-GroupNorm"
+    xr = O.conv2d(torch.tensor(x), torch.tensor(w), bias.cpu(), padding=ks // 2) + emb.cpu()[:, :, None, None] \
+        + torch.tensor(from_nhwc(res.float().cpu().numpy(), B, H, W))
+    ref = O.group_norm(xr, g.cpu(), bt.cpu(), 1e-5)
+    check(f"groupnorm_from_splitk_{ks}x{ks}_{Cin}to{Cout}", from_nhwc(y_b.float().cpu().numpy(), B, H, W),
+          O.silu(ref) if silu else ref, rel_l2=2e-3)
+    # a producer that does not split cannot defer
+    dn = _ops.make_gemm_desc(a, wp, Cout, B, H, W, Cin, out_b, Cout, bias=bias, ksize=ks, splitk=1)
+    dn.defer_reduce = 1
+    with pytest.raises(Exception):
+        _ops.gemm_run(dn)
