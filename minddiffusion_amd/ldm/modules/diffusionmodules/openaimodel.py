@@ -647,11 +647,13 @@ class UNetModel:
         # (>= 1024 pixels per sample); the small deep-level tensors already use the one-launch fused kernel.
         P.colstats = {}
         use_cs = os.environ.get("MDX_UNET_GN_COLSTATS", "1") != "0"
-        use_fs = os.environ.get("MDX_UNET_GN_SPLITK_FUSE", "1") != "0"
+        # opt-in: measured SLOWER at UNet batch 2 (+0.6 % on the evaluation, profiles/r02_c_ab.txt): the fused launch has only
+        # (column blocks x samples) = 64 blocks to pull ~26 MB of slabs, the chip-wide reduce kernel it replaces has 2048
+        use_fs = os.environ.get("MDX_UNET_GN_SPLITK_FUSE", "0") == "1"
         if True:
             def stats_of(d, hw, cx):
-                if d is None or d.N != cx or d.out_ld != cx:
-                    return None
+                if d is None or d.N != cx or d.out_ld != cx or d.defer_reduce:
+                    return None      # (a deferred producer has no reduce launch to emit the statistics from)
                 rows = ops.gemm_query(d)[5]
                 if rows <= 0 or hw % rows:
                     return None
@@ -671,7 +673,8 @@ class UNetModel:
                     # split): the conv writes its slabs only, this launch sums them, stores the conv output and normalises
                     d = c["prod"][0]
                     if (use_fs and C2 == 0 and d is not None and d.N == C1 and d.out_ld == C1
-                            and op_index.get(ctypes.addressof(d)) == c["meta"] - 1 and ops.gemm_query(d)[2] > 1
+                            and not d.colstats_out and op_index.get(ctypes.addressof(d)) == c["meta"] - 1
+                            and ops.gemm_query(d)[2] > 1
                             and ops.groupnorm_from_splitk_ok(d)):
                         d.defer_reduce = 1
                         c["fs"] = d

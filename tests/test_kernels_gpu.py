@@ -596,8 +596,8 @@ def test_gemm_colstats_and_groupnorm_from_them(ops, B, H, W, Cin, Cout, ks, spli
     res = h16(rng.standard_normal((B, Cout, H, W)))
     a, wp = dev16(nhwc(x)), pack_conv(w)
     out = torch.empty((B * H * W, Cout), dtype=torch.float16, device=DEV)
-    embd, resd = dev32(emb), dev16(nhwc(res))
-    d = _ops.make_gemm_desc(a, wp, Cout, B, H, W, Cin, out, Cout, bias=dev32(bv), ksize=ks, splitk=splitk, rowbias=embd,
+    embd, resd, biasd = dev32(emb), dev16(nhwc(res)), dev32(bv)     # (descriptors hold raw pointers: keep the tensors alive)
+    d = _ops.make_gemm_desc(a, wp, Cout, B, H, W, Cin, out, Cout, bias=biasd, ksize=ks, splitk=splitk, rowbias=embd,
                             rowbias_ld=Cout, residual=resd, residual_ld=Cout)
     need = _ops.gemm_workspace_bytes(d)
     wsb = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=DEV)

@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "minddiffusion_amd", "csrc", "gemm_tuned.inc"))
     ap.add_argument("--merge", action="store_true", help="keep the entries already in --out (other batches / models)")
     ap.add_argument("--log", default=None)
+    ap.add_argument("--only-m", type=int, default=0, help="tune only the shapes with this M")
+    ap.add_argument("--only-ks", type=int, default=0, help="tune only the shapes with this kernel size")
     ap.add_argument("--insitu", type=int, default=2,
                     help="run this many of the plan's preceding ops between the flush and the timed launch (0 = all cold)")
     args = ap.parse_args()
@@ -103,12 +105,16 @@ def main():
     big_ws = torch.empty((256 << 20) // 4, dtype=torch.float32, device=dev)
     lines, log = [], []
     for (M, N, K, ks), d0 in sorted(shapes.items()):
+        if (args.only_m and M != args.only_m) or (args.only_ks and ks != args.only_ks):
+            continue
         kt = (K + 63) // 64
         halo = ks == 3 and d0.c2 == 0 and (d0.c1 % 64 == 0) and d0.W % 16 == 0 and d0.H % 8 == 0
+        halo8 = ks == 3 and d0.c2 == 0 and (d0.c1 % 64 == 0) and d0.W == 8 and d0.H == 8   # bm = 128: HALO, bm = 64: generic
 
         def cand(bm, ns, bn=0):
             d = GemmDesc.from_buffer_copy(d0)
             d.tile_m, d.splitk, d.tile_n = bm, ns, bn
+            d.defer_reduce, d.colstats_out = 0, 0      # time the launch with its own reduce, without the statistics epilogue
             d.workspace, d.workspace_bytes = big_ws.data_ptr(), big_ws.numel() * 4
             return d
         pre = pres.get((M, N, K, ks), ())
@@ -121,7 +127,7 @@ def main():
                 for ns in NS_CANDIDATES:
                     if ns > 1 and (kt // ns < 2 or ns * M * N * 4 > big_ws.numel() * 4):
                         continue
-                    if halo and ns > (d0.c1 // 64):
+                    if (halo or (halo8 and bm == 128)) and ns > (d0.c1 // 64):
                         continue
                     try:
                         t = time_desc(ops, cand(bm, ns, bn), flush, args.reps, pre)
