@@ -439,7 +439,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     }
 }
 
-template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK, int NW, bool ROLL = false>
+template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const GemmParams p) {
     // NW = 4 (2 x 2 waves) or 8 (4 x 2 waves, BM = 128 only).  The 8-wave form is for grids of at most one block per
     // CU: a wave's K-step is a serial chain (wait -> barrier -> DMA issue -> ds_read -> MFMA), so a lone 4-wave block
@@ -637,131 +637,56 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
     const int nt = kt_end - kt_begin;
     float bpre[16];
     gemm_bias_prefetch<BN, SWAP, NW>(p, n0, bpre);
-    if constexpr (ROLL) {
-        // ROLLED schedule (see conv3x3_halo_kernel, NSB = 4): the ring starts FULL (tiles 0 .. NS-1); k-steps 0 .. KS-2 of
-        // tile t read the next k-step's fragments and run their MFMAs; then ONE wait (lgkmcnt(0) + counted vmcnt that leaves
-        // NS-2 tiles in flight) + s_barrier publishes tile t+1 and releases tile t's stage; the last k-step issues the DMAs of
-        // tile t+NS into that stage and reads the fragments of (tile t+1, k-step 0) beside its MFMAs.
-        static_assert(NS >= 3, "the rolled schedule needs a ring of at least 3 stages");
 #pragma unroll
-        for (int i = 0; i < NS; ++i)
-            if (i < nt) stage_tile(kt_begin + i, i);
-        trace_mark(p, 1);
-        {
-            const int younger = min(NS - 1, nt - 1);
-            if (younger >= 3)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
-            else if (younger == 2)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-            else if (younger == 1)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    for (int i = 0; i < NS - 1; ++i)
+        if (i < nt) stage_tile(kt_begin + i, i);
+    int rd = 0;            // stage holding tile t
+    int wr = NS - 1;       // stage that tile t+NS-1 goes to
+    trace_mark(p, 1);
+    for (int t = 0; t < nt; ++t) {
+        // tiles t .. min(t+NS-2, nt-1) are outstanding; allow all but the oldest to stay in flight
+        const int ahead = min(NS - 2, nt - 1 - t);
+        if (NS >= 5 && ahead >= 3)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+        else if (NS >= 4 && ahead == 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (NS >= 3 && ahead == 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        trace_mark(p, 2);
+        if (t == 0) trace_mark(p, 2);
+        if (t + NS - 1 < nt) stage_tile(kt_begin + t + NS - 1, wr);
+        const char* sb = smem + rd * STAGE;
         f16x8 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(smem + a_row_off + i * 32 * ROWB + ((hi ^ swz) << 4));
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + ((hi ^ swz) << 4));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(smem + b_row_off + j * 32 * ROWB + ((hi ^ swz) << 4));
-        int rd = 0;
-        static_assert(KS % 2 == 0, "fragment double buffer parity carries across tiles");
-        for (int t = 0; t < nt; ++t) {
-            const char* sb = smem + rd * STAGE;
-            const int rd1 = (rd + 1 == NS) ? 0 : rd + 1;
-            const char* sb1 = smem + rd1 * STAGE;
-            const bool last = t + 1 >= nt;
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + ((hi ^ swz) << 4));
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int cur = s & 1, nxt = cur ^ 1;
-                if (s < KS - 1) {
-                    const int coff = (((2 * (s + 1) + hi) ^ swz) << 4);
+        for (int s = 0; s < KS; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s < KS - 1) {
+                const int coff = (((2 * (s + 1) + hi) ^ swz) << 4);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + coff);
+                for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + coff);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + coff);
-                } else if (!last) {
-                    const int younger = min(NS - 2, nt - 2 - t);      // tiles issued after tile t+1
-                    if (NS >= 4 && younger >= 2)
-                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LPT) : "memory");
-                    else if (younger >= 1)
-                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPT) : "memory");
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + coff);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (SWAP)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
                     else
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    if (t + NS < nt) stage_tile(kt_begin + t + NS, rd);
-                    const int coff = ((hi ^ swz) << 4);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f16x8*>(sb1 + a_row_off + i * 32 * ROWB + coff);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb1 + b_row_off + j * 32 * ROWB + coff);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
                 }
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if constexpr (SWAP)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
-                        else
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-                    }
-                __builtin_amdgcn_s_setprio(0);
-            }
-            rd = rd1;
         }
-    } else {
-    #pragma unroll
-        for (int i = 0; i < NS - 1; ++i)
-            if (i < nt) stage_tile(kt_begin + i, i);
-        int rd = 0;            // stage holding tile t
-        int wr = NS - 1;       // stage that tile t+NS-1 goes to
-        trace_mark(p, 1);
-        for (int t = 0; t < nt; ++t) {
-            // tiles t .. min(t+NS-2, nt-1) are outstanding; allow all but the oldest to stay in flight
-            const int ahead = min(NS - 2, nt - 1 - t);
-            if (NS >= 5 && ahead >= 3)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
-            else if (NS >= 4 && ahead == 2)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-            else if (NS >= 3 && ahead == 1)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t == 0) trace_mark(p, 2);
-            if (t + NS - 1 < nt) stage_tile(kt_begin + t + NS - 1, wr);
-            const char* sb = smem + rd * STAGE;
-            f16x8 af[2][TM], bf[2][TN];
-    #pragma unroll
-            for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + ((hi ^ swz) << 4));
-    #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + ((hi ^ swz) << 4));
-    #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int cur = s & 1, nxt = cur ^ 1;
-                if (s < KS - 1) {
-                    const int coff = (((2 * (s + 1) + hi) ^ swz) << 4);
-    #pragma unroll
-                    for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + coff);
-    #pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + coff);
-                }
-    #pragma unroll
-                for (int i = 0; i < TM; ++i)
-    #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if constexpr (SWAP)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
-                        else
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-                    }
-            }
-            rd = (rd + 1 == NS) ? 0 : rd + 1;
-            wr = (wr + 1 == NS) ? 0 : wr + 1;
-        }
+        rd = (rd + 1 == NS) ? 0 : rd + 1;
+        wr = (wr + 1 == NS) ? 0 : wr + 1;
     }
+
     __syncthreads();  // all waves done with the ring before the epilogue reuses it
     trace_mark(p, 3);
     gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{m0}, n0, split, bpre, tile_m);
@@ -918,166 +843,67 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     for (int i = 0; i < NSB - 1; ++i)
         if (i < nt) dma_b(kt_begin + i, i);
 
-    if constexpr (NSB == 4) {
-        // ROLLED schedule (NSB = 4): the per-tap wait -> barrier -> DMA issue -> first fragment read -> MFMA chain of the
-        // 2/3-stage loop below leaves the matrix pipe idle at every tap boundary (39 % of the wave time in s_waitcnt at
-        // UNet batch 16, profiles/r01_n_halo_pmc_b16.md).  Here ONE barrier sits in the middle of a tap's MFMA stream:
-        //     k-steps 0..2 of tap t:  read the fragments of the next k-step, 4 MFMAs
-        //     lgkmcnt(0); vmcnt(2 tiles in flight); s_barrier   -> tile t+1 is published, every wave is done with tile t
-        //     k-step 3:  issue the DMAs of tile t+4 into tile t's stage (+ one halo slice of the next chunk),
-        //                read the fragments of (tap t+1, k-step 0), 4 MFMAs
-        // so a tap never starts with LDS latency or DMA issue, a tile has three taps (~1.5 us) to land, and the counted
-        // vmcnt never drains.
-        auto frag_addr = [&](int tap, int hb, int (&a_row)[TM], int (&a_key)[TM]) {
+    int t = 0;
+    int rd = 0, wr = NSB - 1;
+    trace_mark(p, 1);
+    for (int c = c_begin; c < c_end; ++c) {
+        const int hb = (c - c_begin) & 1;
+        const bool more = c + 1 < c_end;
+        for (int tap = 0; tap < 9; ++tap, ++t) {
+            // weight tiles t .. t+NSB-2 (and at most one halo slice, older than tile t+1) are outstanding
+            if (NSB >= 3 && t + 1 < nt)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BJ) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t == 0) trace_mark(p, 2);
+            if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
+            if (t + NSB - 1 < nt) dma_b(kt_begin + t + NSB - 1, wr);
+
             const int ky = tap / 3, kx = tap - ky * 3;
             const int dq = ky * HWD + kx;
+            int a_row[TM], a_key[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                a_row[i] = hb * HALO_BYTES + (hp0[i] + dq) * 128;
+                const int hp = hp0[i] + dq;
+                a_row[i] = hb * HALO_BYTES + hp * 128;
                 if constexpr (PW == 16)
-                    a_key[i] = ((((l31 & 15) + kx) >> 1) & 7) << 4;
-                else
+                    a_key[i] = ((((l31 & 15) + kx) >> 1) & 7) << 4;   // swizzle key = halo COLUMN / 2 (see the loader)
+                else   // halo column (l31 & 7) + kx, halo row parity ((l31 >> 3) + ky) & 1 (i * 4 rows keep the parity)
                     a_key[i] = (((((l31 & 7) + kx) >> 1) & 3) | ((((l31 >> 3) + ky) & 1) << 2)) << 4;
             }
-        };
-        // the ring starts full: tile NSB-1 too (the loop issues tile t+NSB during tap t)
-        if (NSB - 1 < nt) dma_b(kt_begin + NSB - 1, NSB - 1);
-        // tile 0 and the first halo must be visible before the loop; up to three younger tiles stay in flight
-        if (nt > 3)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * BJ) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        trace_mark(p, 2);
-        f16x8 af[2][TM], bf[2][TN];
-        int a_row[TM], a_key[TM], n_row[TM], n_key[TM];
-        frag_addr(0, 0, a_row, a_key);
+            const char* sb = smem + rd * B_BYTES;
+            f16x8 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + ((hi << 4) ^ a_key[i]));
+            for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + ((hi << 4) ^ a_key[i]));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(smem + b_row_off + j * 32 * 128 + ((hi ^ swz_b) << 4));
-        int t = 0;
-        int rd = 0;
-        for (int c = c_begin; c < c_end; ++c) {
-            const int hb = (c - c_begin) & 1;
-            const bool more = c + 1 < c_end;
-            for (int tap = 0; tap < 9; ++tap, ++t) {
-                const char* sb = smem + rd * B_BYTES;
-                const int rd1 = (rd + 1 == NSB) ? 0 : rd + 1;
-                const char* sb1 = smem + rd1 * B_BYTES;
-                const bool last = t + 1 >= nt;
-                if (!last) frag_addr(tap == 8 ? 0 : tap + 1, tap == 8 ? hb ^ 1 : hb, n_row, n_key);
+            for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + ((hi ^ swz_b) << 4));
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int cur = s & 1, nxt = cur ^ 1;
-                    if (s < 3) {
+            for (int s = 0; s < 4; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                if (s < 3) {
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            af[nxt][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + (((2 * (s + 1) + hi) << 4) ^ a_key[i]));
+                    for (int i = 0; i < TM; ++i)
+                        af[nxt][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + (((2 * (s + 1) + hi) << 4) ^ a_key[i]));
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + (((2 * (s + 1) + hi) ^ swz_b) << 4));
-                    } else if (!last) {
-                        // every fragment of tile t is in registers: publish tile t+1, release tile t's stage
-                        const int younger = nt - 2 - t;      // weight tiles issued after tile t+1 (up to NSB - 2 = 2)
-                        if (younger >= 2)
-                            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * BJ) : "memory");
-                        else if (younger == 1)
-                            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BJ) : "memory");
+                    for (int j = 0; j < TN; ++j)
+                        bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + (((2 * (s + 1) + hi) ^ swz_b) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (SWAP)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
                         else
-                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                        if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
-                        if (t + NSB < nt) dma_b(kt_begin + t + NSB, rd);
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            af[nxt][i] = *reinterpret_cast<const f16x8*>(smem + n_row[i] + ((hi << 4) ^ n_key[i]));
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb1 + b_row_off + j * 32 * 128 + ((hi ^ swz_b) << 4));
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
                     }
-                    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            if constexpr (SWAP)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
-                            else
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-                        }
-                    __builtin_amdgcn_s_setprio(0);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    a_row[i] = n_row[i];
-                    a_key[i] = n_key[i];
-                }
-                rd = rd1;
             }
-        }
-    } else {
-        int t = 0;
-        int rd = 0, wr = NSB - 1;
-        trace_mark(p, 1);
-        for (int c = c_begin; c < c_end; ++c) {
-            const int hb = (c - c_begin) & 1;
-            const bool more = c + 1 < c_end;
-            for (int tap = 0; tap < 9; ++tap, ++t) {
-                // weight tiles t .. t+NSB-2 (and at most one halo slice, older than tile t+1) are outstanding
-                if (NSB >= 3 && t + 1 < nt)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BJ) : "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (t == 0) trace_mark(p, 2);
-                if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
-                if (t + NSB - 1 < nt) dma_b(kt_begin + t + NSB - 1, wr);
-
-                const int ky = tap / 3, kx = tap - ky * 3;
-                const int dq = ky * HWD + kx;
-                int a_row[TM], a_key[TM];
-    #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int hp = hp0[i] + dq;
-                    a_row[i] = hb * HALO_BYTES + hp * 128;
-                    if constexpr (PW == 16)
-                        a_key[i] = ((((l31 & 15) + kx) >> 1) & 7) << 4;   // swizzle key = halo COLUMN / 2 (see the loader)
-                    else   // halo column (l31 & 7) + kx, halo row parity ((l31 >> 3) + ky) & 1 (i * 4 rows keep the parity)
-                        a_key[i] = (((((l31 & 7) + kx) >> 1) & 3) | ((((l31 >> 3) + ky) & 1) << 2)) << 4;
-                }
-                const char* sb = smem + rd * B_BYTES;
-                f16x8 af[2][TM], bf[2][TN];
-    #pragma unroll
-                for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + ((hi << 4) ^ a_key[i]));
-    #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + ((hi ^ swz_b) << 4));
-    #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int cur = s & 1, nxt = cur ^ 1;
-                    if (s < 3) {
-    #pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            af[nxt][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + (((2 * (s + 1) + hi) << 4) ^ a_key[i]));
-    #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + (((2 * (s + 1) + hi) ^ swz_b) << 4));
-                    }
-    #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-    #pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            if constexpr (SWAP)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
-                            else
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-                        }
-                }
-                rd = (rd + 1 == NSB) ? 0 : rd + 1;
-                wr = (wr + 1 == NSB) ? 0 : wr + 1;
-            }
+            rd = (rd + 1 == NSB) ? 0 : rd + 1;
+            wr = (wr + 1 == NSB) ? 0 : wr + 1;
         }
     }
+
     __syncthreads();
     trace_mark(p, 3);
     if constexpr (PW == 16)
@@ -1401,7 +1227,6 @@ int pick_bn(const GemmParams& p) {
 
 struct GemmCfg {
     int bm, bn, bk, ns;
-    int roll = 0;   // generic kernel: rolled K-loop (one mid-tile barrier, 4-stage ring)
 };
 
 // Tile configuration.  Experiments: MDX_GEMM_CFG="bk,ns" overrides (bk in {32,64}, ns in {2,3,4}).
@@ -1493,39 +1318,38 @@ Tiling choose_tiling(const GemmParams& p, int bn, int forced_ns, int forced_bm) 
     return best;
 }
 
-template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK, int NW, bool ROLL = false>
+template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK, int NW>
 void launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t ring = (size_t)NS * (BM + BN) * BK * 2;
     constexpr size_t epi = (size_t)(BM > BN ? BM : BN) * ((BM > BN ? BN : BM) + 8) * 2 + 4096;  // staged C tile
     constexpr size_t lds = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, BK, NS, SWAP, FASTK, NW, ROLL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, BK, NS, SWAP, FASTK, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, NS, SWAP, FASTK, NW, ROLL>), grid, dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, NS, SWAP, FASTK, NW>), grid, dim3(NW * 64), lds, st, p);
 }
 
-template <int BM, int BN, int BK, int NS, int NW, bool ROLL = false>
+template <int BM, int BN, int BK, int NS, int NW>
 void launch_cfg(const GemmParams& p, bool swap, bool fastk, dim3 grid, hipStream_t st) {
     if (swap) {
         if (fastk)
-            launch_one<BM, BN, BK, NS, true, true, NW, ROLL>(p, grid, st);
+            launch_one<BM, BN, BK, NS, true, true, NW>(p, grid, st);
         else
-            launch_one<BM, BN, BK, NS, true, false, NW, ROLL>(p, grid, st);
+            launch_one<BM, BN, BK, NS, true, false, NW>(p, grid, st);
     } else {
         if (fastk)
-            launch_one<BM, BN, BK, NS, false, true, NW, ROLL>(p, grid, st);
+            launch_one<BM, BN, BK, NS, false, true, NW>(p, grid, st);
         else
-            launch_one<BM, BN, BK, NS, false, false, NW, ROLL>(p, grid, st);
+            launch_one<BM, BN, BK, NS, false, false, NW>(p, grid, st);
     }
 }
 
 template <int BM, int BN>
 bool launch_bn(const GemmCfg& c, const GemmParams& p, bool swap, bool fastk, dim3 grid, hipStream_t st) {
-    if (c.roll) launch_cfg<BM, BN, 64, 4, 4, true>(p, swap, fastk, grid, st);      // rolled schedule, 4-stage ring
-    else if (c.bk == 64 && c.ns == 2) launch_cfg<BM, BN, 64, 2, 4>(p, swap, fastk, grid, st);
+    if (c.bk == 64 && c.ns == 2) launch_cfg<BM, BN, 64, 2, 4>(p, swap, fastk, grid, st);
     else if (c.bk == 64 && c.ns == 3) launch_cfg<BM, BN, 64, 3, 4>(p, swap, fastk, grid, st);
     else if (BM == 128 && c.bk == 64 && c.ns == 4) launch_cfg<128, BN, 64, 4, 4>(p, swap, fastk, grid, st);
     else if (BM == 128 && c.bk == 64 && c.ns == 5) launch_cfg<128, BN, 64, 5, 4>(p, swap, fastk, grid, st);
@@ -1550,9 +1374,7 @@ void launch_halo(const GemmParams& p, dim3 grid, hipStream_t st) {
 
 template <int BM, int BN, int PW = 16>
 void launch_halo_cfg(const GemmParams& p, int nsb, bool swap, dim3 grid, hipStream_t st) {
-    if (nsb == 4) {     // rolled schedule (one mid-tap barrier, 4-deep weight ring)
-        if (swap) launch_halo<BM, BN, 4, true, PW>(p, grid, st); else launch_halo<BM, BN, 4, false, PW>(p, grid, st);
-    } else if (nsb == 3) {
+    if (nsb == 3) {
         if (swap) launch_halo<BM, BN, 3, true, PW>(p, grid, st); else launch_halo<BM, BN, 3, false, PW>(p, grid, st);
     } else {
         if (swap) launch_halo<BM, BN, 2, true, PW>(p, grid, st); else launch_halo<BM, BN, 2, false, PW>(p, grid, st);
@@ -1743,8 +1565,6 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         // on the split-K'd small-M layers); otherwise 2 stages keep 2-3 blocks resident per CU.
         cc.ns = (ntiles * ns <= 256) ? 3 : 2;
     }
-    static const int roll_env = getenv("MDX_GEMM_ROLL") ? atoi(getenv("MDX_GEMM_ROLL")) : 0;
-    cc.roll = roll_env;
     const bool swap = (ns == 1) && (p.out_mode == MDX_OUT_ROWMAJOR);
     bool ok;
     if (halo) {
@@ -1752,7 +1572,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         // UNet shape); 256-pixel patches own the CU, so the LDS left over goes to a third stage
         int nsb = c.bm == 256 ? 3 : 2;
         static const char* envn = getenv("MDX_HALO_NSB");
-        if (envn && atoi(envn) >= 2 && atoi(envn) <= 4) nsb = atoi(envn);
+        if (envn && atoi(envn) >= 2 && atoi(envn) <= 3) nsb = atoi(envn);
         if (c.bm == 256) {
             if (bn == 128) launch_halo_cfg<256, 128>(p, nsb, swap, grid, st); else launch_halo_cfg<256, 64>(p, nsb, swap, grid, st);
         } else if (halo8_eligible(p)) {
