@@ -65,10 +65,11 @@ int mdx_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const floa
 /* GroupNorm whose statistics come from its producers' column partials (mdx_gemm_desc.colstats_out) instead of a reduction
  * pass over the tensor: ONE launch (normalise + affine [+ SiLU]) and one read of x instead of two launches and two reads.
  * cs1 / cs2: the producers' colstats buffers of x1 / x2 ([B * nrb][C][2] fp32), nrb1 / nrb2 = row blocks per sample
- * (HW / rows per block).  Deterministic (fixed-order folds, no atomics). */
+ * (HW / rows per block).  scale / shift: optional FiLM rows as in mdx_groupnorm_scaleshift_f16 (NULL for the plain norm).
+ * Deterministic (fixed-order folds, no atomics). */
 int mdx_groupnorm_colstats_f16(const void* x1, int C1, const float* cs1, int nrb1, const void* x2, int C2, const float* cs2,
-                               int nrb2, const float* gamma, const float* beta, void* y, int B, int HW, int groups,
-                               float eps, int silu, mdx_stream_t s);
+                               int nrb2, const float* gamma, const float* beta, const float* scale, const float* shift,
+                               int mod_ld, void* y, int B, int HW, int groups, float eps, int silu, mdx_stream_t s);
 
 /* Same with the FiLM modulation of GLIDE's ResBlock (Taichu-GLIDE/.../unet.py:203-208):
  *   y = silu?( GN(x) * (1 + scale[b][c]) + shift[b][c] ),  scale/shift fp32 rows of stride mod_ld. */

@@ -50,7 +50,8 @@ SIGNATURES = {
     "mdx_groupnorm_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_int, c_float, c_int, c_void_p, c_void_p]),
     "mdx_groupnorm_colstats_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
-                                           c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+                                           c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float,
+                                           c_int, c_void_p]),
     "mdx_groupnorm_from_splitk_f16": (c_int, [ctypes.POINTER(GemmDesc), c_void_p, c_void_p, c_void_p, c_int, c_float, c_int,
                                               c_void_p]),
     "mdx_groupnorm_from_splitk_ok": (c_int, [ctypes.POINTER(GemmDesc), c_int]),

@@ -722,11 +722,12 @@ extern "C" int mdx_groupnorm_from_splitk_f16(const mdx_gemm_desc* prod, const fl
 }
 
 extern "C" int mdx_groupnorm_colstats_f16(const void* x1, int C1, const float* cs1, int nrb1, const void* x2, int C2,
-                                          const float* cs2, int nrb2, const float* gamma, const float* beta, void* y, int B,
-                                          int HW, int groups, float eps, int silu, mdx_stream_t s) {
+                                          const float* cs2, int nrb2, const float* gamma, const float* beta,
+                                          const float* scale, const float* shift, int mod_ld, void* y, int B, int HW,
+                                          int groups, float eps, int silu, mdx_stream_t s) {
     MDX_REQUIRE(cs1, "mdx_groupnorm_colstats_f16: null column statistics");
-    return groupnorm_impl(x1, C1, x2, C2, gamma, beta, nullptr, nullptr, 0, y, B, HW, groups, eps, silu, nullptr, s, cs1, nrb1,
-                          cs2, nrb2);
+    return groupnorm_impl(x1, C1, x2, C2, gamma, beta, scale, shift, mod_ld, y, B, HW, groups, eps, silu, nullptr, s, cs1,
+                          nrb1, cs2, nrb2);
 }
 
 extern "C" int mdx_groupnorm_scaleshift_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,

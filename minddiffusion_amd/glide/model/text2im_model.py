@@ -290,9 +290,19 @@ class Text2ImUNet:
             main.append(fn)
             meta.append({"kind": kind, "flops": int(flops), "launches": launches, "info": info})
 
+        producer, gn_calls = {}, []     # tensor address -> the GEMM descriptor that wrote it last; GroupNorm calls
+        _arena_get = A.get
+
+        def _get(shape, dtype=f16):     # a buffer handed out again is no longer "the output of that GEMM" (pools, attention, ...)
+            t = _arena_get(shape, dtype)
+            producer.pop(t.data_ptr(), None)
+            return t
+        A.get = _get
+
         def gemm(**kw):
             d = ops.make_gemm_desc(**kw)
             descs.append(d)
+            producer[kw["out"].data_ptr()] = d
             ks, st, up = kw.get("ksize", 1), kw.get("stride", 1), kw.get("upsample", 0)
             hs_, ws2 = (2 * kw["H"], 2 * kw["W"]) if up else (kw["H"], kw["W"])
             pad = 1 if ks == 3 else 0
@@ -306,12 +316,20 @@ class Text2ImUNet:
             Bq, HW, C1 = x1.shape
             C = C1 + (0 if x2 is None else x2.shape[2])
             gn_need[0] = max(gn_need[0], ops.groupnorm_ws_floats(Bq, HW, C))
-            if scale is None:
-                emit(lambda: ops.groupnorm(x1, x2, g, b, 1e-5, silu, ws=P.gn_ws, out=out), "groupnorm", 0, 2,
-                     f"B={Bq} HW={HW} C={C}")
-            else:
-                emit(lambda: ops.groupnorm_scaleshift(x1, x2, g, b, scale, shift, self._emb_total, 1e-5, silu,
-                                                      ws=P.gn_ws, out=out), "groupnorm", 0, 2, f"B={Bq} HW={HW} C={C}")
+            call = dict(x1=x1, x2=x2, cs=None, meta=len(meta),
+                        prod=(producer.get(x1.data_ptr()), None if x2 is None else producer.get(x2.data_ptr())))
+            producer.pop(out.data_ptr(), None)
+            gn_calls.append(call)
+
+            def run(c=call):
+                if c["cs"] is not None:      # statistics from the producers' epilogues (ops.wire_groupnorm_colstats)
+                    cs1, n1, cs2, n2 = c["cs"]
+                    return ops.groupnorm_colstats(x1, cs1, n1, x2, cs2, n2, g, b, 1e-5, silu, out=out, scale=scale,
+                                                  shift=shift, mod_ld=self._emb_total if scale is not None else 0)
+                if scale is None:
+                    return ops.groupnorm(x1, x2, g, b, 1e-5, silu, ws=P.gn_ws, out=out)
+                return ops.groupnorm_scaleshift(x1, x2, g, b, scale, shift, self._emb_total, 1e-5, silu, ws=P.gn_ws, out=out)
+            emit(run, "groupnorm", 0, 2, f"B={Bq} HW={HW} C={C}")
 
         def dense(src, rows_b, tokens, cin, nout, wt, bias=None, residual=None, epilogue=ops.EPI_NONE, out=None,
                   out_ld=None, out_mode=ops.OUT_ROWMAJOR, out_bs=0, src2=None, c2=0):
@@ -493,6 +511,10 @@ class Text2ImUNet:
             d.workspace = P.gemm_ws.data_ptr()
             d.workspace_bytes = P.gemm_ws.numel() * 4
         P.gn_ws = torch.empty(gn_need[0], dtype=f32, device=dev)
+        P.colstats = {}
+        import os
+        ops.wire_groupnorm_colstats(gn_calls if os.environ.get("MDX_UNET_GN_COLSTATS", "1") != "0" else [], meta, B, dev,
+                                    P.colstats)
         P.main, P.meta, P.descs, P.arena = main, meta, descs, A
         P.keep = (t_emb, cat_in, emb, xf_out)
         P.graph, P.graph_failed = None, False

@@ -382,6 +382,13 @@ class UNetModel:
         P.B, P.H, P.W = B, H, W
 
         producer = {}     # device address of a tensor -> the GEMM descriptor that wrote it last (planning order == run order)
+        _arena_get = A.get
+
+        def _get(shape, dtype=f16):     # a buffer handed out again is no longer "the output of that GEMM"
+            t = _arena_get(shape, dtype)
+            producer.pop(t.data_ptr(), None)
+            return t
+        A.get = _get
         op_index = {}     # descriptor -> index of its op in `main`
 
         def add_gemm(oplist, **kw):
@@ -646,48 +653,32 @@ class UNetModel:
         # disappears: one launch and one read instead of two).  Done for the tensors that take the two-launch path today
         # (>= 1024 pixels per sample); the small deep-level tensors already use the one-launch fused kernel.
         P.colstats = {}
-        use_cs = os.environ.get("MDX_UNET_GN_COLSTATS", "1") != "0"
-        # opt-in: measured SLOWER at UNet batch 2 (+0.6 % on the evaluation, profiles/r02_c_ab.txt): the fused launch has only
-        # (column blocks x samples) = 64 blocks to pull ~26 MB of slabs, the chip-wide reduce kernel it replaces has 2048
-        use_fs = os.environ.get("MDX_UNET_GN_SPLITK_FUSE", "0") == "1"
-        if True:
-            def stats_of(d, hw, cx):
-                if d is None or d.N != cx or d.out_ld != cx or d.defer_reduce:
-                    return None      # (a deferred producer has no reduce launch to emit the statistics from)
-                rows = ops.gemm_query(d)[5]
-                if rows <= 0 or hw % rows:
-                    return None
-                key = ctypes.addressof(d)
-                if key not in P.colstats:
-                    P.colstats[key] = torch.zeros((B * (hw // rows), cx, 2), dtype=f32, device=dev)
-                    d.colstats_out = P.colstats[key].data_ptr()
-                return P.colstats[key], hw // rows
+        # opt-in: the one-launch GroupNorm of the deep levels can also BE the split-K reduce of the conv right in front of it
+        # (mdx_gemm_desc.defer_reduce).  Measured SLOWER at UNet batch 2 (+0.7 % on the evaluation, profiles/r02_c_ab.txt): the
+        # fused launch has only (column blocks x samples) = 64 blocks to pull ~26 MB of slabs, the chip-wide reduce kernel it
+        # replaces has 2048.
+        if os.environ.get("MDX_UNET_GN_SPLITK_FUSE", "0") == "1":
             for c in gn_calls:
-                Bq, HW, C1 = c["x1"].shape
-                C2 = 0 if c["x2"] is None else c["x2"].shape[2]
-                cpg = (C1 + C2) // 32
-                L = cpg // math.gcd(cpg, 8)          # chunk columns of the minimal whole-group column block
+                _, HW, C1 = c["x1"].shape
+                cpg = C1 // 32
+                L = cpg // math.gcd(cpg, 8)
+                d = c["prod"][0]
+                if (c["x2"] is None and L <= 64 and HW * L * 16 <= (64 << 10) and d is not None and d.N == C1
+                        and d.out_ld == C1 and op_index.get(ctypes.addressof(d)) == c["meta"] - 1
+                        and ops.gemm_query(d)[2] > 1 and ops.groupnorm_from_splitk_ok(d)):
+                    d.defer_reduce = 1
+                    c["fs"] = d
+                    meta[c["meta"] - 1]["launches"] = 1
+        if os.environ.get("MDX_UNET_GN_COLSTATS", "1") != "0":
+            ops.wire_groupnorm_colstats(gn_calls, meta, B, dev, P.colstats)
+        else:
+            ops.wire_groupnorm_colstats([], meta, B, dev, P.colstats)
+            for c in gn_calls:      # launch accounting of the one-launch fused kernel
+                _, HW, C1 = c["x1"].shape
+                cpg = (C1 + (0 if c["x2"] is None else c["x2"].shape[2])) // 32
+                L = cpg // math.gcd(cpg, 8)
                 if L <= 64 and HW * L * 16 <= (64 << 10):
-                    meta[c["meta"]]["launches"] = 1  # one-launch fused kernel (norm.hip groupnorm_impl)
-                    # ... which can also BE the split-K reduce of the conv right in front of it (the deep levels' convs always
-                    # split): the conv writes its slabs only, this launch sums them, stores the conv output and normalises
-                    d = c["prod"][0]
-                    if (use_fs and C2 == 0 and d is not None and d.N == C1 and d.out_ld == C1
-                            and not d.colstats_out and op_index.get(ctypes.addressof(d)) == c["meta"] - 1
-                            and ops.gemm_query(d)[2] > 1
-                            and ops.groupnorm_from_splitk_ok(d)):
-                        d.defer_reduce = 1
-                        c["fs"] = d
-                        meta[c["meta"] - 1]["launches"] = 1
-                    continue
-                if not use_cs:
-                    continue
-                s1 = stats_of(c["prod"][0], HW, C1)
-                s2 = stats_of(c["prod"][1], HW, C2) if C2 else (None, 0)
-                if s1 is None or s2 is None:
-                    continue
-                c["cs"] = (s1[0], s1[1], s2[0], s2[1])
-                meta[c["meta"]]["launches"] = 1
+                    meta[c["meta"]]["launches"] = 1
         P.main, P.ctxops, P.descs, P.meta = main, ctxops, descs, meta
         assert len(main) == len(meta)
         P.arena_bytes = A.total

@@ -71,16 +71,18 @@ def groupnorm(x1, x2, gamma, beta, eps, silu, ws=None, out=None, groups=32):
     return out
 
 
-def groupnorm_colstats(x1, cs1, nrb1, x2, cs2, nrb2, gamma, beta, eps, silu, out=None, groups=32):
-    """GroupNorm(groups)(cat(x1, x2)) [+SiLU] with the statistics folded from the producers' column partials
-    (mdx_gemm_desc.colstats_out): one launch, one read of x."""
+def groupnorm_colstats(x1, cs1, nrb1, x2, cs2, nrb2, gamma, beta, eps, silu, out=None, groups=32, scale=None, shift=None,
+                       mod_ld=0):
+    """GroupNorm(groups)(cat(x1, x2)) [* (1 + scale) + shift] [+SiLU] with the statistics folded from the producers' column
+    partials (mdx_gemm_desc.colstats_out): one launch, one read of x."""
     B, HW, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[2]
     if out is None:
         out = torch.empty((B, HW, C1 + C2), dtype=f16, device=x1.device)
     _lib.check(_lib.load().mdx_groupnorm_colstats_f16(_ptr(x1), C1, _ptr(cs1), int(nrb1), _ptr(x2), C2, _ptr(cs2), int(nrb2),
-                                                      _ptr(gamma), _ptr(beta), _ptr(out), B, HW, groups, float(eps),
-                                                      int(bool(silu)), _stream()), "mdx_groupnorm_colstats_f16")
+                                                      _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift), int(mod_ld),
+                                                      _ptr(out), B, HW, groups, float(eps), int(bool(silu)), _stream()),
+               "mdx_groupnorm_colstats_f16")
     return out
 
 
@@ -381,3 +383,39 @@ def vae_gaussian_sample(moments, zc, noise, out):
     _lib.check(_lib.load().mdx_vae_gaussian_sample_f32(_ptr(moments), ld, _ptr(noise), _ptr(out), B, zc, HW, _stream()),
                "mdx_vae_gaussian_sample_f32")
     return out
+
+
+def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
+    """Plan-time post-pass shared by the UNet planners (run AFTER the split-K workspace is patched into the descriptors, so
+    that mdx_gemm_query sees the real split factors): every GroupNorm whose inputs are GEMM outputs and that would take the
+    two-launch path (>= ~1k pixels per sample) gets its statistics from its producers' epilogues
+    (mdx_gemm_desc.colstats_out) -- gn_stats and its read pass disappear.  gn_calls: dicts with x1, x2, prod = (desc of x1's
+    producer, desc of x2's producer), meta = index into `meta`; sets call["cs"] = (cs1, nrb1, cs2, nrb2).  `table` keeps the
+    statistics buffers alive (descriptor address -> tensor)."""
+    import math
+    for c in gn_calls:
+        _, HW, C1 = c["x1"].shape
+        C2 = 0 if c["x2"] is None else c["x2"].shape[2]
+        cpg = (C1 + C2) // 32
+        L = cpg // math.gcd(cpg, 8)           # chunk columns of the minimal whole-group column block
+        if L <= 64 and HW * L * 16 <= (64 << 10):
+            meta[c["meta"]]["launches"] = 1   # the one-launch fused kernel (norm.hip groupnorm_impl)
+            continue
+
+        def stats_of(d, cx):
+            if d is None or d.N != cx or d.out_ld != cx or d.defer_reduce:
+                return None
+            rows = gemm_query(d)[5]
+            if rows <= 0 or HW % rows:
+                return None
+            key = ctypes.addressof(d)
+            if key not in table:
+                table[key] = torch.zeros((batch * (HW // rows), cx, 2), dtype=f32, device=device)
+                d.colstats_out = table[key].data_ptr()
+            return table[key], HW // rows
+        s1 = stats_of(c["prod"][0], C1)
+        s2 = stats_of(c["prod"][1], C2) if C2 else (None, 0)
+        if s1 is None or s2 is None:
+            continue
+        c["cs"] = (s1[0], s1[1], s2[0], s2[1])
+        meta[c["meta"]]["launches"] = 1

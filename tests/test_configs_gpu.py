@@ -50,7 +50,7 @@ def _assert_tuned_rows_hit(plan, name, min_hits):
     for d in plan.descs:
         M = d.B * d.H * d.W
         key = (M, d.N, d.ksize * d.ksize * (d.c1 + d.c2), d.ksize)
-        tm, tn, ns, halo, tuned = ops.gemm_query(d)
+        tm, tn, ns, halo, tuned = ops.gemm_query(d)[:5]
         kinds.add((tm, tn, halo))
         if key in table and d.stride == 1 and not d.upsample and tuned:
             bm, bn, tns = table[key]
