@@ -20,8 +20,6 @@
 // (MDX_OUT_TRANSPOSED), which keeps every LDS read of this kernel wide and conflict-light.
 #include "mdx_common.h"
 
-#include <stdlib.h>
-
 #include <type_traits>
 
 namespace {
@@ -39,25 +37,22 @@ struct AttnParams {
     int causal;                  // 1: key j is visible to query i only if j <= i (text encoder, text_encoder.py:136-139)
 };
 
+constexpr int BQ = 128;
 constexpr int BKV = 64;
 
-// NW = waves per block (32 queries each): 4 -> 128-query blocks; 2 -> 64-query blocks for the launches that would leave the
-// chip unevenly loaded with 128 (SDv2 64x64 latent, UNet batch 2: 320 blocks on 256 CUs put two blocks on 64 CUs and one on
-// the rest; 640 half-size blocks spread 2-3 per CU).
-template <int D, int NW>
-__global__ __launch_bounds__(NW * 64, (D <= 80 ? 2 : 1)) void attn_kernel(const AttnParams p) {
-    constexpr int BQ = NW * 32;
+template <int D>
+__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const AttnParams p) {
     static_assert(D % 8 == 0 && D <= 160, "head dim must be a multiple of 8, <= 160");
     constexpr int KS = (D + 15) / 16;          // k-steps of QK^T (contraction over d, zero-padded to 16)
     constexpr int DT = (D + 31) / 32;          // 32-row d tiles of O^T
     constexpr int KCH = (2 * KS <= 8) ? 8 : (2 * KS <= 16 ? 16 : 32);   // 16-B chunks per K row in LDS
     constexpr int K_ROWB = KCH * 16;           // 128 | 256 | 512 bytes
     constexpr int K_RPI = 64 / KCH;            // K rows covered by one DMA instruction (8 | 4 | 2)
-    constexpr int K_DMA = BKV / K_RPI / NW;    // K DMA instructions per wave per tile
+    constexpr int K_DMA = BKV / K_RPI / 4;     // K DMA instructions per wave per tile
     constexpr int K_BYTES = BKV * K_ROWB;      // [key][d]
     constexpr int V_ROWB = 128;                // [d][64 keys]
     constexpr int V_ROWS = DT * 32;
-    constexpr int V_DMA = (V_ROWS / 8 + NW - 1) / NW;   // V DMA instructions per wave per tile (8 rows each)
+    constexpr int V_DMA = (V_ROWS / 8 + 3) / 4;   // V DMA instructions per wave per tile (8 rows each)
     constexpr int V_BYTES = V_ROWS * V_ROWB;
     constexpr int STAGE = K_BYTES + V_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -273,27 +268,20 @@ __global__ __launch_bounds__(NW * 64, (D <= 80 ? 2 : 1)) void attn_kernel(const 
     }
 }
 
-template <int D, int NW>
+template <int D>
 void launch_attn(const AttnParams& p, dim3 grid, hipStream_t st) {
     constexpr int KS = (D + 15) / 16, DT = (D + 31) / 32;
     constexpr int KCH = (2 * KS <= 8) ? 8 : (2 * KS <= 16 ? 16 : 32);
     constexpr size_t stage = (size_t)BKV * KCH * 16 + (size_t)DT * 32 * 128;
-    constexpr size_t ostage = (size_t)NW * 32 * (DT * 32 + 8) * 2;
+    constexpr size_t ostage = (size_t)4 * 32 * (DT * 32 + 8) * 2;
     constexpr size_t lds = (2 * stage > ostage ? 2 * stage : ostage);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, NW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_kernel<D, NW>), grid, dim3(NW * 64), lds, st, p);
-}
-
-template <int D>
-void launch_attn_nw(const AttnParams& p, int nw, hipStream_t st) {
-    const int bq = nw * 32;
-    dim3 grid((p.Nq + bq - 1) / bq, p.heads, p.B);
-    if (nw == 2) launch_attn<D, 2>(p, grid, st); else launch_attn<D, 4>(p, grid, st);
+    hipLaunchKernelGGL(attn_kernel<D>, grid, dim3(256), lds, st, p);
 }
 
 }  // namespace
@@ -321,16 +309,13 @@ static int attention_impl(const void* q, long q_bs, int q_ld, const void* k, lon
     MDX_REQUIRE(kbytes <= 0x80000000ull && vbytes <= 0x80000000ull, "mdx_attention_f16: K/V extent too large");
     p.k_bytes = (unsigned)kbytes;
     p.vt_bytes = (unsigned)vbytes;
+    dim3 grid((Nq + BQ - 1) / BQ, heads, B);
     hipStream_t st = (hipStream_t)s;
-    // 64-query blocks while 128-query blocks would not give every CU at least four blocks to balance with
-    static const int env_nw = getenv("MDX_ATTN_NW") ? atoi(getenv("MDX_ATTN_NW")) : 0;
-    const long blocks128 = (long)((Nq + 127) / 128) * heads * B;
-    const int nw = (env_nw == 2 || env_nw == 4) ? env_nw : (blocks128 < 1024 ? 2 : 4);
     switch (D) {
-        case 40: launch_attn_nw<40>(p, nw, st); break;
-        case 64: launch_attn_nw<64>(p, nw, st); break;
-        case 80: launch_attn_nw<80>(p, nw, st); break;
-        default: launch_attn_nw<160>(p, nw, st); break;
+        case 40: launch_attn<40>(p, grid, st); break;
+        case 64: launch_attn<64>(p, grid, st); break;
+        case 80: launch_attn<80>(p, grid, st); break;
+        default: launch_attn<160>(p, grid, st); break;
     }
     MDX_LAUNCH_CHECK("mdx_attention_f16");
     return MDX_OK;

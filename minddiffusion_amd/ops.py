@@ -406,8 +406,9 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
             if d is None or d.N != cx or d.out_ld != cx or d.defer_reduce:
                 return None
             rows = gemm_query(d)[5]
-            if rows <= 0 or HW % rows:
-                return None
+            if rows <= 0 or HW % rows or HW // rows > 64:
+                return None      # (> 64 row blocks per sample: the fold in every gn_apply block would outweigh the pass it saves --
+                                 #  measured on the 256x256 / 128x128 levels of the GLIDE up-sampler, profiles/r02_e_ab.txt)
             key = ctypes.addressof(d)
             if key not in table:
                 table[key] = torch.zeros((batch * (HW // rows), cx, 2), dtype=f32, device=device)
