@@ -1194,12 +1194,24 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
 
 // Measured (tile_m, tile_n, splitk) per UNet shape: tools/tune_gemm.py times every candidate on the device with cold
 // weights and writes gemm_tuned.inc.  Shapes that are not in the table fall through to pick_bn / the cost model.
+// A row is keyed by shape AND launch variant: the same (M, N, K) occurs with different epilogues / operand forms in one UNet
+// (proj_in, attention out + residual + row statistics, LayerNorm-fold consumers ...), and a split or tile that was measured
+// for one of them says nothing about the others.  var1 = variant + 1; 0 (rows written before the key existed) = any variant,
+// consulted only when no exact row matches.
 struct TunedEntry {
     int M, N, K, ksize, bm, bn, ns;   // bn 0 = pick_bn's default
+    int var1;
 };
 static const TunedEntry g_tuned[] = {
 #include "gemm_tuned.inc"
-    {0, 0, 0, 0, 0, 0, 0}};
+    {0, 0, 0, 0, 0, 0, 0, 0}};
+
+// Launch variant of a descriptor (tools/tune_gemm.py computes the same number from the mdx_gemm_desc fields).
+int tuned_variant(const GemmParams& p) {
+    return (p.c2 > 0 ? 1 : 0) | (p.epilogue << 1) | (p.n_split ? 8 : 0) | (p.ln_stats ? 16 : 0) | (p.stats_out ? 32 : 0) |
+           (p.out_mode == MDX_OUT_TRANSPOSED ? 64 : 0) | (p.colstats_out ? 128 : 0) | (p.residual ? 256 : 0) |
+           (p.rowbias ? 512 : 0);
+}
 
 bool halo_eligible(const GemmParams& p, int bm);
 
@@ -1207,10 +1219,18 @@ const TunedEntry* lookup_tuned(const GemmParams& p) {
     static const bool use_table = !(getenv("MDX_GEMM_TUNED") && atoi(getenv("MDX_GEMM_TUNED")) == 0) &&
                                   !getenv("MDX_GEMM_BM") && !getenv("MDX_GEMM_BN");
     if (!use_table || p.bn_hint || p.stride != 1 || p.upsample) return nullptr;
+    const int var1 = tuned_variant(p) + 1;
+    const TunedEntry* any = nullptr;
     for (const TunedEntry* e = g_tuned; e->M; ++e)
-        if (e->M == p.M && e->N == p.N && e->K == p.K && e->ksize == p.ksize)
-            return (e->bm >= 128 || !halo_eligible(p, 128)) ? e : nullptr;
-    return nullptr;
+        if (e->M == p.M && e->N == p.N && e->K == p.K && e->ksize == p.ksize) {
+            if (e->var1 == var1) {
+                any = e;
+                break;
+            }
+            if (e->var1 == 0 && !any) any = e;
+        }
+    if (!any) return nullptr;
+    return (any->bm >= 128 || !halo_eligible(p, 128)) ? any : nullptr;
 }
 
 int pick_bn(const GemmParams& p) {

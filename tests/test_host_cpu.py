@@ -294,19 +294,22 @@ def test_layernorm_fold_host_algebra():
 
 
 def test_tuned_tile_table_is_well_formed():
-    """csrc/gemm_tuned.inc (tools/tune_gemm.py): one {M, N, K, ksize, tile_m, tile_n, splitk} row per shape."""
+    """csrc/gemm_tuned.inc (tools/tune_gemm.py): one {M, N, K, ksize, tile_m, tile_n, splitk[, variant + 1]} row per shape and
+    launch variant (rows without the 8th field predate the variant key and match any variant)."""
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "minddiffusion_amd", "csrc",
                         "gemm_tuned.inc")
     seen = set()
     for ln in open(path):
         if ln.lstrip().startswith("//") or not ln.strip():
             continue
-        m = re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},", ln)
+        m = re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?\},", ln)
         assert m, ln
-        M, N, K, ks, bm, bn, ns = map(int, m.groups())
+        M, N, K, ks, bm, bn, ns = map(int, m.groups()[:7])
+        var1 = int(m.group(8) or 0)
         assert M > 0 and N % 8 == 0 and K > 0 and ks in (1, 3) and bm in (64, 128) and bn in (0, 64, 128) and 1 <= ns <= 32
-        assert (M, N, K, ks) not in seen, f"duplicate shape {ln}"
-        seen.add((M, N, K, ks))
+        assert 0 <= var1 <= 1024
+        assert (M, N, K, ks, var1) not in seen, f"duplicate shape {ln}"
+        seen.add((M, N, K, ks, var1))
 
 
 def test_unet_plan_folds_layernorm_into_its_gemms(monkeypatch):
@@ -343,11 +346,13 @@ def test_tuned_table_drives_the_split_choice():
     lib = _lib.load()
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "minddiffusion_amd", "csrc",
                         "gemm_tuned.inc")
-    rows = [tuple(map(int, m.groups())) for m in
-            (re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},", ln) for ln in open(path)) if m]
+    rows = [tuple(int(g or 0) for g in m.groups()) for m in
+            (re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?\},", ln) for ln in open(path)) if m]
+    plain = {r[:4] for r in rows if r[7] in (0, 1)}
     checked = 0
-    for M, N, K, ks, bm, bn, ns in rows:
-        if ks != 1 or M % 64 or K % 64:      # dense rows are enough to pin the hook-up (B=1, H=M tokens, W=1)
+    for M, N, K, ks, bm, bn, ns, var1 in rows:
+        # dense rows of the plain variant (or wildcard rows of shapes without a plain-variant row) pin the hook-up
+        if ks != 1 or M % 64 or K % 64 or var1 > 1 or (var1 == 0 and sum(1 for r in rows if r[:4] == (M, N, K, ks)) > 1):
             continue
         a = torch.zeros((1,), dtype=torch.float16)      # pointers are never dereferenced on this path
         d = ops.make_gemm_desc(a, a, N, 1, M, 1, K, a, N)

@@ -26,6 +26,13 @@ sys.path.insert(0, ROOT)
 NS_CANDIDATES = [1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 20]
 
 
+def variant(d):
+    """Launch variant of a descriptor: gemm.hip tuned_variant()."""
+    return ((1 if d.c2 > 0 else 0) | (d.epilogue << 1) | (8 if d.n_split else 0) | (16 if d.ln_stats else 0)
+            | (32 if d.stats_out else 0) | (64 if d.out_mode == 1 else 0) | (128 if d.colstats_out else 0)
+            | (256 if d.residual else 0) | (512 if d.rowbias else 0))
+
+
 def time_desc(ops, d, flush, reps, pre=()):
     ts = []
     for r in range(reps):
@@ -93,18 +100,18 @@ def main():
             if d.stride != 1 or d.upsample:
                 continue
             M, N, K = d.B * d.H * d.W, d.N, d.ksize * d.ksize * (d.c1 + d.c2)
-            shapes.setdefault((M, N, K, d.ksize), d)
+            shapes.setdefault((M, N, K, d.ksize, variant(d)), d)
         if args.insitu > 0:     # first op of the plan that issues each shape (closures carry their descriptor as a default)
             for i, fn in enumerate(P.main):
                 dd = (getattr(fn, "__defaults__", None) or (None,))[0]
                 if isinstance(dd, GemmDesc) and dd.stride == 1 and not dd.upsample:
-                    key = (dd.B * dd.H * dd.W, dd.N, dd.ksize * dd.ksize * (dd.c1 + dd.c2), dd.ksize)
+                    key = (dd.B * dd.H * dd.W, dd.N, dd.ksize * dd.ksize * (dd.c1 + dd.c2), dd.ksize, variant(dd))
                     if key not in pres:
                         pres[key] = list(P.main[max(0, i - args.insitu):i])
                         shapes[key] = dd
     big_ws = torch.empty((256 << 20) // 4, dtype=torch.float32, device=dev)
     lines, log = [], []
-    for (M, N, K, ks), d0 in sorted(shapes.items()):
+    for (M, N, K, ks, var), d0 in sorted(shapes.items()):
         if (args.only_m and M != args.only_m) or (args.only_ks and ks != args.only_ks):
             continue
         kt = (K + 63) // 64
@@ -114,10 +121,10 @@ def main():
         def cand(bm, ns, bn=0):
             d = GemmDesc.from_buffer_copy(d0)
             d.tile_m, d.splitk, d.tile_n = bm, ns, bn
-            d.defer_reduce, d.colstats_out = 0, 0      # time the launch with its own reduce, without the statistics epilogue
+            d.defer_reduce = 0      # time the launch with its own reduce
             d.workspace, d.workspace_bytes = big_ws.data_ptr(), big_ws.numel() * 4
             return d
-        pre = pres.get((M, N, K, ks), ())
+        pre = pres.get((M, N, K, ks, var), ())
         auto = cand(0, 0)
         t_auto = time_desc(ops, auto, flush, args.reps, pre)
         best = (t_auto, 0, 0, 0)
@@ -139,24 +146,26 @@ def main():
         t_auto2 = time_desc(ops, auto, flush, args.reps, pre)     # re-measure the baseline: drift guard
         t_ref = min(t_auto, t_auto2)
         keep = best[1] and best[0] < t_ref * (1 - args.gain) and best[0] < t_ref - 0.5
-        msg = (f"M={M:6d} N={N:6d} K={K:6d} k{ks} halo={int(halo)}: model {t_ref:7.2f} us | best bm={best[1]:3d} bn={best[3]:3d} ns={best[2]:2d} "
+        msg = (f"M={M:6d} N={N:6d} K={K:6d} k{ks} v{var:<4d} halo={int(halo)}: model {t_ref:7.2f} us | best bm={best[1]:3d} bn={best[3]:3d} ns={best[2]:2d} "
                f"{best[0]:7.2f} us {'KEEP' if keep else ''}")
         print(msg, flush=True)
         log.append(msg)
         if keep:
-            lines.append((M, N, K, ks, best[1], best[3], best[2], t_ref, best[0]))
+            lines.append((M, N, K, ks, best[1], best[3], best[2], t_ref, best[0], var))
     old = []
     if args.merge and os.path.exists(args.out):
         for ln in open(args.out):
-            m = re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},(.*)", ln)
-            if m and (int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4))) not in {l[:4] for l in lines}:
-                old.append(ln.rstrip("\n"))
+            m = re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?\},(.*)", ln)
+            if m:
+                key = (int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(8) or 0))
+                if key not in {l[:4] + (l[9] + 1,) for l in lines}:
+                    old.append(ln.rstrip("\n"))
     with open(args.out, "w") as f:
-        f.write("// generated by tools/tune_gemm.py -- {M, N, K, ksize, tile_m, tile_n (0 = default), splitk}: measured on MI355X, cold weights\n")
+        f.write("// generated by tools/tune_gemm.py -- {M, N, K, ksize, tile_m, tile_n (0 = default), splitk[, launch variant + 1]}: measured on MI355X, cold weights\n")
         for ln in old:
             f.write(ln + "\n")
-        for M, N, K, ks, bm, bn, ns, t0, t1 in lines:
-            f.write(f"    {{{M}, {N}, {K}, {ks}, {bm}, {bn}, {ns}}},   // {args.model} B={B} latent={h}: {t0:.1f} -> {t1:.1f} us\n")
+        for M, N, K, ks, bm, bn, ns, t0, t1, var in lines:
+            f.write(f"    {{{M}, {N}, {K}, {ks}, {bm}, {bn}, {ns}, {var + 1}}},   // {args.model} B={B} latent={h}: {t0:.1f} -> {t1:.1f} us\n")
     if args.log:
         with open(args.log, "w") as f:
             f.write("\n".join(log) + "\n")
