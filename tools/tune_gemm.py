@@ -122,9 +122,12 @@ def main():
             d = GemmDesc.from_buffer_copy(d0)
             d.tile_m, d.splitk, d.tile_n = bm, ns, bn
             d.defer_reduce = 0      # time the launch with its own reduce
+            if d.colstats_out:      # the plan's buffer is sized for the plan's row blocks: candidates get one that fits 64-row blocks
+                d.colstats_out = cs_scratch.data_ptr()
             d.workspace, d.workspace_bytes = big_ws.data_ptr(), big_ws.numel() * 4
             return d
         pre = pres.get((M, N, K, ks, var), ())
+        cs_scratch = torch.empty(((M + 63) // 64) * N * 2 + 16, dtype=torch.float32, device=dev) if d0.colstats_out else None
         auto = cand(0, 0)
         t_auto = time_desc(ops, auto, flush, args.reps, pre)
         best = (t_auto, 0, 0, 0)
