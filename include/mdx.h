@@ -137,6 +137,7 @@ typedef struct mdx_gemm_desc {
      * concats, groups that are not aligned to the store granule -- can fold them (mdx_groupnorm_colstats_f16).  Plain row-major
      * launches only (no GEGLU / transposed / n_split / LayerNorm fold / out_bs); tokens per sample % rows per block == 0. */
     float* colstats_out;
+    int colstats_cap;     /* row blocks colstats_out has room for: a launch that would write more fails (MDX_E_INVALID) */
     int defer_reduce;     /* split-K launches only: write the fp32 slabs and do NOT launch the reduce -- the consumer,
                              mdx_groupnorm_from_splitk_f16, sums them while it normalises (it must run before any other launch
                              reuses the workspace).  mdx_gemm_f16 fails if the launch does not split. */

@@ -1563,8 +1563,13 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     const int bn = rs.bn;
     int ns = rs.ns;
     const bool halo = rs.halo;
-    MDX_REQUIRE(!p.colstats_out || colstats_rows(p, rs) > 0,
-                "mdx_gemm_f16: this launch cannot produce column statistics (ask mdx_gemm_query first)");
+    if (p.colstats_out) {
+        const int rows = colstats_rows(p, rs);
+        MDX_REQUIRE(rows > 0, "mdx_gemm_f16: this launch cannot produce column statistics (ask mdx_gemm_query first)");
+        MDX_REQUIRE((p.M + rows - 1) / rows <= d->colstats_cap,
+                    "mdx_gemm_f16: colstats_out holds %d row blocks, this launch writes %d (%d rows each)", d->colstats_cap,
+                    (p.M + rows - 1) / rows, rows);
+    }
     MDX_REQUIRE(!d->defer_reduce || ns > 1, "mdx_gemm_f16: defer_reduce set but the launch does not split K");
     p.tiles_m = (p.M + c.bm - 1) / c.bm;
     p.tiles_n = (p.N + bn - 1) / bn;

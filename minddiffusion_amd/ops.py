@@ -241,6 +241,7 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
     d.ln_eps = float(ln_eps)
     d.tile_m, d.tile_n = int(tile_m), int(tile_n)
     d.colstats_out = 0 if colstats_out is None else colstats_out.data_ptr()
+    d.colstats_cap = 0 if colstats_out is None else int(colstats_out.shape[0])
     return d
 
 
@@ -405,15 +406,22 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
         def stats_of(d, cx):
             if d is None or d.N != cx or d.out_ld != cx or d.defer_reduce:
                 return None
+            key = ctypes.addressof(d)
+            if key in table:
+                return table[key]
+            # The statistics epilogue is part of the launch VARIANT the tile table is keyed by: ask with the field already set
+            # (any non-null value), or the row blocks the query reports are those of a different tile / split choice than the
+            # launch will make (a 64-row split-K reduce writing into a buffer sized for 128-row tiles).
+            d.colstats_out = 8
             rows = gemm_query(d)[5]
             if rows <= 0 or HW % rows or HW // rows > 64:
+                d.colstats_out = 0
                 return None      # (> 64 row blocks per sample: the fold in every gn_apply block would outweigh the pass it saves --
                                  #  measured on the 256x256 / 128x128 levels of the GLIDE up-sampler, profiles/r02_e_ab.txt)
-            key = ctypes.addressof(d)
-            if key not in table:
-                table[key] = torch.zeros((batch * (HW // rows), cx, 2), dtype=f32, device=device)
-                d.colstats_out = table[key].data_ptr()
-            return table[key], HW // rows
+            buf = torch.zeros((batch * (HW // rows), cx, 2), dtype=f32, device=device)
+            d.colstats_out, d.colstats_cap = buf.data_ptr(), batch * (HW // rows)
+            table[key] = (buf, HW // rows)
+            return table[key]
         s1 = stats_of(c["prod"][0], C1)
         s2 = stats_of(c["prod"][1], C2) if C2 else (None, 0)
         if s1 is None or s2 is None:

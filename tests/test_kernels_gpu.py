@@ -606,7 +606,10 @@ def test_gemm_colstats_and_groupnorm_from_them(ops, B, H, W, Cin, Cout, ks, spli
     assert rows > 0 and (H * W) % rows == 0
     nrb = H * W // rows
     cs = torch.full((B * nrb, Cout, 2), float("nan"), dtype=torch.float32, device=DEV)
-    d.colstats_out = cs.data_ptr()
+    d.colstats_out, d.colstats_cap = cs.data_ptr(), B * nrb - 1
+    with pytest.raises(Exception):          # a buffer that is one row block short is refused, not overrun
+        _ops.gemm_run(d)
+    d.colstats_cap = B * nrb
     _ops.gemm_run(d)
     o = out.float().view(B, H * W, Cout)
     if rows == 128 and ks == 3:          # HALO patches: 8 rows x 16 columns of pixels

@@ -35,9 +35,10 @@ PY
       rm -rf gpurun_out/prof_bench; head -30 $OUT/bench_kernel_stats.md ;;
     pmc)
       for c in FETCH_SIZE WRITE_SIZE; do
-        timeout 300 rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc/$c -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $OUT/pmc_$c.log 2>&1
+        timeout 400 rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc/$c -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $OUT/pmc_$c.log 2>&1
+        tail -2 $OUT/pmc_$c.log
       done
-      python tools/pmc_traffic.py gpurun_out/pmc > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err; rm -rf gpurun_out/pmc; cat $OUT/pmc_traffic.json | head -40 ;;
+      python tools/pmc_traffic.py gpurun_out/pmc "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph (the timed configuration launched eagerly: rocprofv3 --pmc segfaults on hipGraph replay; same kernels, same launch mix)" > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err; rm -rf gpurun_out/pmc; cat $OUT/pmc_traffic.json | head -60; cat $OUT/pmc_traffic.err | tail -3 ;;
     opprof)
       timeout 200 python tools/op_profile.py --batch 2 --top 400 > $OUT/op_profile_b2.txt 2>&1; head -8 $OUT/op_profile_b2.txt ;;
     *) echo "unknown stage $stage" ;;

@@ -50,11 +50,11 @@ def load(db_path, counter):
 
 def main():
     root = sys.argv[1]
+    command = sys.argv[2] if len(sys.argv) > 2 else "python tools/op_profile.py --batch 2 --passes 1"
     fetch = load(f"{root}/FETCH_SIZE/pmc_results.db", "FETCH_SIZE")
     write = load(f"{root}/WRITE_SIZE/pmc_results.db", "WRITE_SIZE")
     evals = fetch["attention"][0] / 32.0 if fetch["attention"][0] else 1.0   # 32 attention launches per SDv2 UNet eval
-    out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- "
-                      "python tools/op_profile.py --batch 2 --passes 1",
+    out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- " + command,
            "unet_evals_in_trace": evals,
            "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B); MALL hits included",
            "families": {}}

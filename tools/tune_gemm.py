@@ -123,7 +123,7 @@ def main():
             d.tile_m, d.splitk, d.tile_n = bm, ns, bn
             d.defer_reduce = 0      # time the launch with its own reduce
             if d.colstats_out:      # the plan's buffer is sized for the plan's row blocks: candidates get one that fits 64-row blocks
-                d.colstats_out = cs_scratch.data_ptr()
+                d.colstats_out, d.colstats_cap = cs_scratch.data_ptr(), (M + 63) // 64
             d.workspace, d.workspace_bytes = big_ws.data_ptr(), big_ws.numel() * 4
             return d
         pre = pres.get((M, N, K, ks, var), ())
