@@ -252,7 +252,7 @@ def pmc_traffic(gemm_launches_now):
         fam = doc["families"]
         g, r = fam["gemm"], fam.get("splitk_reduce", {"launches_per_eval": 0, "read_MB_per_eval": 0, "write_MB_per_eval": 0})
         n = g["launches_per_eval"] + r["launches_per_eval"]
-        if abs(n - gemm_launches_now) > 0.5:
+        if abs(n - gemm_launches_now) > 0.01 * gemm_launches_now:    # (the trace averages over evaluations: not an integer)
             return None, (f"profiles/{PMC_FILE} holds {n:.0f} GEMM-family launches per evaluation, this build issues "
                           f"{gemm_launches_now}: stale PMC passes, not reported")
         total = (g["read_MB_per_eval"] + g["write_MB_per_eval"] + r["read_MB_per_eval"] + r["write_MB_per_eval"]) * 1e6
