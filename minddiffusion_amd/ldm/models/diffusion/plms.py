@@ -115,9 +115,13 @@ class _SamplerBase:
                       dropout_masks=None, step_noises=None):
         if mask is not None and x0 is None:
             raise ValueError("mask blending needs x0 (plms.py:154)")
-        if quantize_denoised or score_corrector is not None:
-            # both need objects the reference's CLIs never construct (a VQ first stage with .quantize, a score corrector)
-            raise NotImplementedError("quantize_x0 / score_corrector are never set by the reference's CLIs")
+        # quantize_x0 / score_corrector (plms.py:199-201, 218-219) call into caller-supplied objects (a first stage with
+        # .quantize, a corrector with .modify_score) between the pieces of the fused step; see step() below
+        if score_corrector is not None and self.model.parameterization != "eps":
+            raise AssertionError('score_corrector needs parameterization == "eps" (plms.py:200)')
+        if quantize_denoised and not hasattr(getattr(self.model, "first_stage_model", None), "quantize"):
+            raise MdxError("quantize_x0 needs model.first_stage_model.quantize (plms.py:219)")
+        corrector_kwargs = corrector_kwargs or {}
         if not 0. <= float(noise_dropout) < 1.:
             raise ValueError("noise_dropout must be in [0, 1)")
         # hybrid (inpainting) conditioning: {"c_concat": mask + masked-image latent, "c_crossattn": text} (inpaint.py:84-88,
@@ -212,9 +216,29 @@ class _SamplerBase:
 
         drop_count, noise_count = [0], [0]
 
-        def step(x, eps_u, eps_c, index, coef, olds, e_out, x_out, p_out):
+        hook_e = torch.empty_like(img) if score_corrector is not None else None
+        hook_x = torch.empty_like(img) if score_corrector is not None else None
+        hook_p = torch.empty_like(img) if quantize_denoised else None
+
+        def step(x, eps_u, eps_c, index, coef, olds, e_out, x_out, p_out, xm=None, tm=None):
+            """One get_x_prev_and_pred_x0 (plms.py:210-228) on e' = coef[0] * e_t + sum coef[k] * olds[k-1], e_t = the
+            CFG-combined model output (optionally written to e_out).  xm / tm: the image and timestep the model output
+            was evaluated at (what a score corrector is handed, plms.py:201)."""
             a_t, a_prev = np.float32(alphas[index]), np.float32(alphas_prev[index])
             sigma_t = np.float32(sigmas[index])
+            if score_corrector is not None:
+                # e_t leaves the fused kernel (pass 1: CFG combine only), goes through the caller's modify_score, and
+                # re-enters as a single NHWC fp16 model output (pass 2: multistep mix + update)
+                ops.sampler_step(x, eps_u, eps_c, eps_c.shape[-1], scale, [], (1., 0., 0., 0.), 1., 0., 1., 0., 0., None,
+                                 hook_e, hook_x, None)
+                tvec = torch.full((b,), int(tm), device=dev, dtype=torch.long)
+                e_mod = score_corrector.modify_score(self.model, hook_e, x if xm is None else xm, tvec, cond,
+                                                     **corrector_kwargs)
+                e_mod = torch.as_tensor(e_mod).to(device=dev, dtype=torch.float32).contiguous()
+                if tuple(e_mod.shape) != tuple(x.shape):
+                    raise MdxError(f"score_corrector returned shape {tuple(e_mod.shape)}, expected {tuple(x.shape)}")
+                eps_c = ops.nchw_to_nhwc(e_mod, (x.shape[1] + 7) // 8 * 8)
+                eps_u = None
             noise = None
             if float(sigma_t) != 0.0:
                 if step_noises is not None:   # tests inject the k-th N(0,1) draw to compare with the oracle (eta != 0)
@@ -232,9 +256,17 @@ class _SamplerBase:
                         keep = (torch.rand(x.shape, device=dev, generator=self.generator) >= noise_dropout).to(torch.float32)
                     drop_count[0] += 1
                     noise = noise * keep / (1. - float(noise_dropout))
+            if quantize_denoised and p_out is None:
+                p_out = hook_p
             ops.sampler_step(x, eps_u, eps_c, eps_c.shape[-1], scale, olds, coef,
                              np.sqrt(a_t), np.float32(sqrt_one_minus_alphas[index]), np.sqrt(a_prev),
                              np.sqrt(np.float32(1.) - a_prev - sigma_t ** 2), sigma_t, noise, e_out, x_out, p_out)
+            if quantize_denoised:
+                # pred_x0, _, *_ = first_stage_model.quantize(pred_x0) (plms.py:218-219); x_prev is linear in pred_x0
+                q = self.model.first_stage_model.quantize(p_out)[0]
+                q = torch.as_tensor(q).to(device=dev, dtype=torch.float32)
+                x_out.add_((q - p_out) * float(np.sqrt(a_prev)))
+                p_out.copy_(q)
 
         for i, step_t in enumerate(time_range):
             index = total_steps - i - 1
@@ -248,23 +280,25 @@ class _SamplerBase:
                 img = img_orig * mask + (1. - mask) * img
             eps_u, eps_c, _keep = model_eps(img, i)
             if not self.multistep:
-                step(img, eps_u, eps_c, index, (1., 0., 0., 0.), [], None, x_next, pred_x0)
+                step(img, eps_u, eps_c, index, (1., 0., 0., 0.), [], None, x_next, pred_x0, tm=step_t)
             else:
                 e_buf = pool.pop()
                 n_old = len(hist)
                 if n_old == 0:
                     # Pseudo Improved Euler (2nd order), plms.py:231-235: S+1 UNet calls in total
-                    step(img, eps_u, eps_c, index, (1., 0., 0., 0.), [], e_buf, x_next, None)
-                    eps_u2, eps_c2, _keep2 = model_eps(x_next, min(i + 1, total_steps - 1))
-                    step(img, eps_u2, eps_c2, index, (.5, .5, 0., 0.), [e_buf], None, x_next, pred_x0)
+                    step(img, eps_u, eps_c, index, (1., 0., 0., 0.), [], e_buf, x_next, None, tm=step_t)
+                    i_next = min(i + 1, total_steps - 1)
+                    eps_u2, eps_c2, _keep2 = model_eps(x_next, i_next)
+                    step(img, eps_u2, eps_c2, index, (.5, .5, 0., 0.), [e_buf], None, x_next, pred_x0,
+                         xm=x_next, tm=time_range[i_next])
                 elif n_old == 1:  # Adams-Bashforth 2, plms.py:236-238
-                    step(img, eps_u, eps_c, index, (3. / 2, -1. / 2, 0., 0.), hist[:1], e_buf, x_next, pred_x0)
+                    step(img, eps_u, eps_c, index, (3. / 2, -1. / 2, 0., 0.), hist[:1], e_buf, x_next, pred_x0, tm=step_t)
                 elif n_old == 2:  # AB-3, plms.py:239-241
                     step(img, eps_u, eps_c, index, (23. / 12, -16. / 12, 5. / 12, 0.), hist[:2], e_buf, x_next,
-                         pred_x0)
+                         pred_x0, tm=step_t)
                 else:             # AB-4, plms.py:242-244
                     step(img, eps_u, eps_c, index, (55. / 24, -59. / 24, 37. / 24, -9. / 24), hist[:3], e_buf,
-                         x_next, pred_x0)
+                         x_next, pred_x0, tm=step_t)
                 hist.insert(0, e_buf)
                 if len(hist) > 3:
                     pool.append(hist.pop())

@@ -83,9 +83,15 @@ class UNetModel:
             assert num_heads != -1, "Either num_heads or num_head_channels has to be set"
         if not use_spatial_transformer:
             raise NotImplementedError("AttentionBlock is an empty stub in the reference (openaimodel.py:208-242)")
-        if dims != 2 or num_classes is not None or use_scale_shift_norm or resblock_updown or transformer_depth != 1 \
-                or n_embed is not None or not conv_resample:
-            raise NotImplementedError("configuration outside the reference's shipped SD / Wukong YAMLs")
+        if dims != 2:
+            raise NotImplementedError("dims != 2: the image UNet is the only instantiation on the denoising path")
+        self.conv_resample = bool(conv_resample)
+        self.num_classes = num_classes
+        self.use_scale_shift_norm = bool(use_scale_shift_norm)
+        self.resblock_updown = bool(resblock_updown)
+        self.transformer_depth = int(transformer_depth)
+        self.n_embed = n_embed                       # predict_codebook_ids (openaimodel.py:344, 527-531)
+        assert self.transformer_depth >= 1
         self.image_size = image_size
         self.in_channels = in_channels
         self.model_channels = model_channels
@@ -103,7 +109,8 @@ class UNetModel:
         self.time_embed_dim = model_channels * 4
         self.input_blocks, self.middle_block, self.output_blocks = self._structure()
         self.cin_pad = _round_up(in_channels, 8)
-        self.cout_pad = _round_up(out_channels, 8)
+        self.final_channels = out_channels if n_embed is None else int(n_embed)
+        self.cout_pad = _round_up(self.final_channels, 8)
         self.w = None          # packed device weights
         self._plans = {}
         self._ctx_key = None
@@ -139,7 +146,7 @@ class UNetModel:
                 inb.append(layers)
                 chans.append(ch)
             if level != len(self.channel_mult) - 1:
-                inb.append([("down", ch)])
+                inb.append([("resdown", ch, ch) if self.resblock_updown else ("down", ch)])
                 chans.append(ch)
                 ds *= 2
         nh, dh = self._heads(ch, nh)
@@ -154,7 +161,7 @@ class UNetModel:
                     nh, dh = self._heads(ch, nh)
                     layers.append(("st", ch, nh, dh))
                 if level and i == self.num_res_blocks:
-                    layers.append(("up", ch))
+                    layers.append(("resup", ch, ch) if self.resblock_updown else ("up", ch))
                     ds //= 2
                 outb.append(layers)
         return inb, mid, outb
@@ -174,19 +181,22 @@ class UNetModel:
         mc, ted, ctx = self.model_channels, self.time_embed_dim, self.context_dim
         s = {"time_embed.0.weight": (ted, mc), "time_embed.0.bias": (ted,),
              "time_embed.2.weight": (ted, ted), "time_embed.2.bias": (ted,)}
+        if self.num_classes is not None:
+            s["label_emb.embedding_table"] = (self.num_classes, ted)
+        ssn = 2 if self.use_scale_shift_norm else 1
         for pre, layer in self._named_layers():
             kind = layer[0]
             if kind == "conv":
                 s[pre + "conv.weight"] = (layer[2], layer[1], 3, 3)
                 s[pre + "conv.bias"] = (layer[2],)
-            elif kind == "res":
+            elif kind in ("res", "resdown", "resup"):
                 cin, cout = layer[1], layer[2]
                 s[pre + "in_layers_norm.gamma"] = (cin,)
                 s[pre + "in_layers_norm.beta"] = (cin,)
                 s[pre + "in_layers_conv.conv.weight"] = (cout, cin, 3, 3)
                 s[pre + "in_layers_conv.conv.bias"] = (cout,)
-                s[pre + "emb_layers.1.weight"] = (cout, ted)
-                s[pre + "emb_layers.1.bias"] = (cout,)
+                s[pre + "emb_layers.1.weight"] = (ssn * cout, ted)
+                s[pre + "emb_layers.1.bias"] = (ssn * cout,)
                 s[pre + "out_layers_norm.gamma"] = (cout,)
                 s[pre + "out_layers_norm.beta"] = (cout,)
                 s[pre + "out_layers_conv.conv.weight"] = (cout, cout, 3, 3)
@@ -202,30 +212,36 @@ class UNetModel:
                 s[pre + "proj_in.bias"] = (inner,)
                 s[pre + "proj_out.weight"] = (ch, inner) if self.use_linear else (ch, inner, 1, 1)
                 s[pre + "proj_out.bias"] = (ch,)
-                t = pre + "transformer_blocks.0."
-                for a, cd in (("attn1.", inner), ("attn2.", ctx)):
-                    s[t + a + "to_q.weight"] = (inner, inner)
-                    s[t + a + "to_k.weight"] = (inner, cd)
-                    s[t + a + "to_v.weight"] = (inner, cd)
-                    s[t + a + "to_out.0.weight"] = (inner, inner)
-                    s[t + a + "to_out.0.bias"] = (inner,)
-                s[t + "ff.net.0.proj.weight"] = (inner * 8, inner)
-                s[t + "ff.net.0.proj.bias"] = (inner * 8,)
-                s[t + "ff.net.2.weight"] = (inner, inner * 4)
-                s[t + "ff.net.2.bias"] = (inner,)
-                for n in ("norm1", "norm2", "norm3"):
-                    s[t + n + ".gamma"] = (inner,)
-                    s[t + n + ".beta"] = (inner,)
-            elif kind == "down":
+                for k in range(self.transformer_depth):
+                    t = pre + f"transformer_blocks.{k}."
+                    for a, cd in (("attn1.", inner), ("attn2.", ctx)):
+                        s[t + a + "to_q.weight"] = (inner, inner)
+                        s[t + a + "to_k.weight"] = (inner, cd)
+                        s[t + a + "to_v.weight"] = (inner, cd)
+                        s[t + a + "to_out.0.weight"] = (inner, inner)
+                        s[t + a + "to_out.0.bias"] = (inner,)
+                    s[t + "ff.net.0.proj.weight"] = (inner * 8, inner)
+                    s[t + "ff.net.0.proj.bias"] = (inner * 8,)
+                    s[t + "ff.net.2.weight"] = (inner, inner * 4)
+                    s[t + "ff.net.2.bias"] = (inner,)
+                    for n in ("norm1", "norm2", "norm3"):
+                        s[t + n + ".gamma"] = (inner,)
+                        s[t + n + ".beta"] = (inner,)
+            elif kind == "down" and self.conv_resample:     # Downsample(use_conv=False) is a parameter-free average pool
                 s[pre + "op.conv.weight"] = (layer[1], layer[1], 3, 3)
                 s[pre + "op.conv.bias"] = (layer[1],)
-            elif kind == "up":
+            elif kind == "up" and self.conv_resample:
                 s[pre + "conv.conv.weight"] = (layer[1], layer[1], 3, 3)
                 s[pre + "conv.conv.bias"] = (layer[1],)
         s["out.0.gamma"] = (mc,)
         s["out.0.beta"] = (mc,)
         s["out.2.conv.weight"] = (self.out_channels, mc, 3, 3)
         s["out.2.conv.bias"] = (self.out_channels,)
+        if self.n_embed is not None:        # the reference builds `out` as well (openaimodel.py:520-531); only id_predictor runs
+            s["id_predictor.0.gamma"] = (mc,)
+            s["id_predictor.0.beta"] = (mc,)
+            s["id_predictor.1.conv.weight"] = (self.n_embed, mc, 1, 1)
+            s["id_predictor.1.conv.bias"] = (self.n_embed,)
         return s
 
     # ------------------------------------------------------------------ weights
@@ -262,6 +278,8 @@ class UNetModel:
         w["te0.b"] = self._dev(P["time_embed.0.bias"], f32)
         w["te2.w"] = self._dev(P["time_embed.2.weight"], f16)
         w["te2.b"] = self._dev(P["time_embed.2.bias"], f32)
+        if self.num_classes is not None:
+            w["label_emb"] = self._dev(P["label_emb.embedding_table"], f32)
         emb_w, emb_b, self._emb_off = [], [], {}
         off = 0
         for pre, layer in self._named_layers():
@@ -269,7 +287,7 @@ class UNetModel:
             if kind == "conv":
                 w[pre + "w"] = self._pack_conv(P[pre + "conv.weight"], cin_pad=self.cin_pad)
                 w[pre + "b"] = self._dev(P[pre + "conv.bias"], f32)
-            elif kind == "res":
+            elif kind in ("res", "resdown", "resup"):
                 cin, cout = layer[1], layer[2]
                 for n in ("in_layers_norm", "out_layers_norm"):
                     w[pre + n + ".g"] = self._dev(P[pre + n + ".gamma"], f32)
@@ -284,7 +302,7 @@ class UNetModel:
                 emb_w.append(self._dev(P[pre + "emb_layers.1.weight"], f16))
                 emb_b.append(self._dev(P[pre + "emb_layers.1.bias"], f32))
                 self._emb_off[pre] = off
-                off += cout
+                off += cout * (2 if self.use_scale_shift_norm else 1)
             elif kind == "st":
                 inner = layer[2] * layer[3]
                 w[pre + "norm.g"] = self._dev(P[pre + "norm.gamma"], f32)
@@ -293,56 +311,63 @@ class UNetModel:
                     wt = self._dev(P[pre + n + ".weight"], f16)
                     w[pre + n + ".w"] = self._pack_dense(wt.reshape(wt.shape[0], wt.shape[1]))  # 1x1 conv == Dense in NHWC
                     w[pre + n + ".b"] = self._dev(P[pre + n + ".bias"], f32)
-                t = pre + "transformer_blocks.0."
-                # self-attention: ONE [q | k | v] projection launch; the q|k columns are stored row-major and the v columns
-                # transposed (mdx_gemm_desc.n_split), which needs 2 * inner to be a multiple of 128
-                wq, wk, wv = (self._dev(P[t + f"attn1.to_{n}.weight"], f16) for n in "qkv")
-                for n in ("norm1", "norm2", "norm3"):
-                    w[t + n + ".g"] = self._dev(P[t + n + ".gamma"], f32)
-                    w[t + n + ".b"] = self._dev(P[t + n + ".beta"], f32)
-                # LayerNorm fold (mdx_gemm_desc.ln_stats): norm1/2/3 disappear into the GEMMs around them -- the consumer
-                # weights become gamma (.) W, with S = row sums and W beta (+ b) as the bias (ops.fold_layernorm)
-                fold = inner % 64 == 0 and os.environ.get("MDX_UNET_LN_FOLD", "1") != "0"
+                for k in range(self.transformer_depth):
+                    t = pre + f"transformer_blocks.{k}."
+                    # self-attention: ONE [q | k | v] projection launch; the q|k columns are stored row-major and the v columns
+                    # transposed (mdx_gemm_desc.n_split), which needs 2 * inner to be a multiple of 128
+                    wq, wk, wv = (self._dev(P[t + f"attn1.to_{n}.weight"], f16) for n in "qkv")
+                    for n in ("norm1", "norm2", "norm3"):
+                        w[t + n + ".g"] = self._dev(P[t + n + ".gamma"], f32)
+                        w[t + n + ".b"] = self._dev(P[t + n + ".beta"], f32)
+                    # LayerNorm fold (mdx_gemm_desc.ln_stats): norm1/2/3 disappear into the GEMMs around them -- the consumer
+                    # weights become gamma (.) W, with S = row sums and W beta (+ b) as the bias (ops.fold_layernorm)
+                    fold = inner % 64 == 0 and os.environ.get("MDX_UNET_LN_FOLD", "1") != "0"
 
-                def put(name, wt, norm, bias=None):
-                    if fold:
-                        wt, w[name + ".s"], w[name + ".cb"] = ops.fold_layernorm(wt, w[t + norm + ".g"], w[t + norm + ".b"], bias)
-                    w[name + ".w"] = self._pack_dense(wt)
-                if (2 * wq.shape[0]) % 128 == 0 and os.environ.get("MDX_UNET_QKV_MERGE", "1") != "0":
-                    put(t + "attn1.qkv", torch.cat([wq, wk, wv], 0), "norm1")
-                else:   # fall back to a [q | k] launch and a transposed-store v launch
-                    w[t + "attn1.qk.w"] = self._pack_dense(torch.cat([wq, wk], 0))
-                    w[t + "attn1.v.w"] = self._pack_dense(wv)
-                put(t + "attn2.q", self._dev(P[t + "attn2.to_q.weight"], f16), "norm2")
-                w[t + "attn2.k.w"] = self._pack_dense(P[t + "attn2.to_k.weight"])
-                w[t + "attn2.v.w"] = self._pack_dense(P[t + "attn2.to_v.weight"])
-                for a in ("attn1", "attn2"):
-                    w[t + a + ".o.w"] = self._pack_dense(P[t + a + ".to_out.0.weight"])
-                    w[t + a + ".o.b"] = self._dev(P[t + a + ".to_out.0.bias"], f32)
-                # GEGLU (attention.py:41-51): interleave 64 'x' rows with their 64 'gate' rows per 128-wide tile
-                gw = self._dev(P[t + "ff.net.0.proj.weight"], f16)
-                gb = self._dev(P[t + "ff.net.0.proj.bias"], f32)
-                half = 4 * inner
-                assert half % 64 == 0
-                nt = half // 64
-                w[t + "ff1.b"] = torch.stack([gb[:half].reshape(nt, 64), gb[half:].reshape(nt, 64)], 1).reshape(-1).contiguous()
-                put(t + "ff1", torch.stack([gw[:half].reshape(nt, 64, inner), gw[half:].reshape(nt, 64, inner)], 1)
-                    .reshape(2 * half, inner), "norm3", w[t + "ff1.b"])
-                w[t + "ff2.w"] = self._pack_dense(P[t + "ff.net.2.weight"])
-                w[t + "ff2.b"] = self._dev(P[t + "ff.net.2.bias"], f32)
-            elif kind == "down":
+                    def put(name, wt, norm, bias=None):
+                        if fold:
+                            wt, w[name + ".s"], w[name + ".cb"] = ops.fold_layernorm(wt, w[t + norm + ".g"], w[t + norm + ".b"], bias)
+                        w[name + ".w"] = self._pack_dense(wt)
+                    if (2 * wq.shape[0]) % 128 == 0 and os.environ.get("MDX_UNET_QKV_MERGE", "1") != "0":
+                        put(t + "attn1.qkv", torch.cat([wq, wk, wv], 0), "norm1")
+                    else:   # fall back to a [q | k] launch and a transposed-store v launch
+                        w[t + "attn1.qk.w"] = self._pack_dense(torch.cat([wq, wk], 0))
+                        w[t + "attn1.v.w"] = self._pack_dense(wv)
+                    put(t + "attn2.q", self._dev(P[t + "attn2.to_q.weight"], f16), "norm2")
+                    w[t + "attn2.k.w"] = self._pack_dense(P[t + "attn2.to_k.weight"])
+                    w[t + "attn2.v.w"] = self._pack_dense(P[t + "attn2.to_v.weight"])
+                    for a in ("attn1", "attn2"):
+                        w[t + a + ".o.w"] = self._pack_dense(P[t + a + ".to_out.0.weight"])
+                        w[t + a + ".o.b"] = self._dev(P[t + a + ".to_out.0.bias"], f32)
+                    # GEGLU (attention.py:41-51): interleave 64 'x' rows with their 64 'gate' rows per 128-wide tile
+                    gw = self._dev(P[t + "ff.net.0.proj.weight"], f16)
+                    gb = self._dev(P[t + "ff.net.0.proj.bias"], f32)
+                    half = 4 * inner
+                    assert half % 64 == 0
+                    nt = half // 64
+                    w[t + "ff1.b"] = torch.stack([gb[:half].reshape(nt, 64), gb[half:].reshape(nt, 64)], 1).reshape(-1).contiguous()
+                    put(t + "ff1", torch.stack([gw[:half].reshape(nt, 64, inner), gw[half:].reshape(nt, 64, inner)], 1)
+                        .reshape(2 * half, inner), "norm3", w[t + "ff1.b"])
+                    w[t + "ff2.w"] = self._pack_dense(P[t + "ff.net.2.weight"])
+                    w[t + "ff2.b"] = self._dev(P[t + "ff.net.2.bias"], f32)
+            elif kind == "down" and self.conv_resample:
                 w[pre + "w"] = self._pack_conv(P[pre + "op.conv.weight"])
                 w[pre + "b"] = self._dev(P[pre + "op.conv.bias"], f32)
-            elif kind == "up":
+            elif kind == "up" and self.conv_resample:
                 w[pre + "w"] = self._pack_conv(P[pre + "conv.conv.weight"])
                 w[pre + "b"] = self._dev(P[pre + "conv.conv.bias"], f32)
         w["emb.w"] = torch.cat(emb_w, 0).contiguous()
         w["emb.b"] = torch.cat(emb_b, 0).contiguous()
         self._emb_total = off
-        w["out.g"] = self._dev(P["out.0.gamma"], f32)
-        w["out.b"] = self._dev(P["out.0.beta"], f32)
-        w["out.w"] = self._pack_conv(P["out.2.conv.weight"], cout_pad=self.cout_pad)
-        w["out.cb"] = self._pad_vec(P["out.2.conv.bias"], self.cout_pad)
+        if self.n_embed is None:
+            w["out.g"] = self._dev(P["out.0.gamma"], f32)
+            w["out.b"] = self._dev(P["out.0.beta"], f32)
+            w["out.w"] = self._pack_conv(P["out.2.conv.weight"], cout_pad=self.cout_pad)
+            w["out.cb"] = self._pad_vec(P["out.2.conv.bias"], self.cout_pad)
+        else:
+            w["out.g"] = self._dev(P["id_predictor.0.gamma"], f32)
+            w["out.b"] = self._dev(P["id_predictor.0.beta"], f32)
+            w["out.w"] = self._pack_conv(P["id_predictor.1.conv.weight"], cout_pad=self.cout_pad)
+            w["out.cb"] = self._pad_vec(P["id_predictor.1.conv.bias"], self.cout_pad)
         self.w = w
         self._plans = {}
         self._ctx_key = None
@@ -412,11 +437,11 @@ class UNetModel:
 
         gn_calls = []
 
-        def add_gn(x1, x2, g, b, eps, silu, out):
+        def add_gn(x1, x2, g, b, eps, silu, out, scale=None, shift=None):
             Bq, HW, C1 = x1.shape
             C2 = 0 if x2 is None else x2.shape[2]
             gn_need[0] = max(gn_need[0], ops.groupnorm_ws_floats(Bq, HW, C1 + C2))
-            call = dict(x1=x1, x2=x2, g=g, b=b, eps=eps, silu=silu, out=out, cs=None, meta=len(meta),
+            call = dict(x1=x1, x2=x2, g=g, b=b, eps=eps, silu=silu, out=out, cs=None, meta=len(meta), film=scale is not None,
                         prod=(producer.get(x1.data_ptr()), None if x2 is None else producer.get(x2.data_ptr())))
             producer.pop(out.data_ptr(), None)      # the GroupNorm output is not a GEMM output
             gn_calls.append(call)
@@ -427,7 +452,11 @@ class UNetModel:
                 if c["cs"] is not None:     # statistics from the producers' epilogues: one launch, one read of x
                     cs1, n1, cs2, n2 = c["cs"]
                     return ops.groupnorm_colstats(c["x1"], cs1, n1, c["x2"], cs2, n2, c["g"], c["b"], c["eps"], c["silu"],
-                                                  out=c["out"])
+                                                  out=c["out"], scale=scale, shift=shift,
+                                                  mod_ld=self._emb_total if scale is not None else 0)
+                if scale is not None:       # use_scale_shift_norm: GN(h) * (1 + scale) + shift (openaimodel.py:193-198)
+                    return ops.groupnorm_scaleshift(c["x1"], c["x2"], c["g"], c["b"], scale, shift, self._emb_total, c["eps"],
+                                                    c["silu"], ws=P.gn_ws, out=c["out"])
                 return ops.groupnorm(c["x1"], c["x2"], c["g"], c["b"], c["eps"], c["silu"], ws=P.gn_ws, out=c["out"])
             emit(run, "groupnorm", 0, 2, f"B={Bq} HW={HW} C={C1 + C2}")
 
@@ -440,6 +469,9 @@ class UNetModel:
         emit(lambda: ops.timestep_embedding(P.t_static, mc, out=t_emb), "small")
         emit(lambda: ops.dense_small(t_emb, w["te0.w"], w["te0.b"], act_out=True, out=e1), "small", 2 * B * mc * ted)
         emit(lambda: ops.dense_small(e1, w["te2.w"], w["te2.b"], out=emb), "small", 2 * B * ted * ted)
+        if self.num_classes is not None:    # emb + label_emb(y) (openaimodel.py:552-554): a [B, ted] row gather, outside the graph
+            P.y_static = torch.zeros((B,), dtype=torch.long, device=dev)
+            emit(lambda: emb.add_(w["label_emb"].index_select(0, P.y_static)), "small")
         emit(lambda: ops.dense_small(emb, w["emb.w"], w["emb.b"], act_in=True, out=P.emb_all), "small",
              2 * B * ted * self._emb_total)
         P.temb_ops = len(main)   # main[:temb_ops] only fill P.emb_all: skipped when the caller hands the rows in
@@ -481,91 +513,125 @@ class UNetModel:
                 ln_stats[(rows, width)] = torch.zeros((rows, width // 64, 2), dtype=f32, device=dev)
             return ln_stats[(rows, width)]
 
-        def resblock(pre, x, x2, cin, cout, h, wd):
-            """ResBlock.construct openaimodel.py:176-205; x2 = skip tensor of the (virtual) concat."""
+        def resblock(pre, x, x2, cin, cout, h, wd, mode=None):
+            """ResBlock.construct openaimodel.py:176-205; x2 = skip tensor of the (virtual) concat.  mode 'up' / 'down' is the
+            resblock_updown form: nearest-2x / 2x2 average pooling of BOTH the normalised branch and the skip input
+            (the nearest-2x of the branch is folded into conv1's gather)."""
             c2 = 0 if x2 is None else x2.shape[2]
             hw = h * wd
             a = A.get((B, hw, cin))
             add_gn(x, x2, w[pre + "in_layers_norm.g"], w[pre + "in_layers_norm.b"], 1e-5, True, a)
             eoff = self._emb_off[pre]
-            rowbias = P.emb_all[:, eoff:eoff + cout]  # view: pointer = base + eoff, ld = emb_total
-            hbuf, _, _ = conv3(a, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd, rowbias=rowbias)
+            film = self.use_scale_shift_norm
+            rowbias = None if film else P.emb_all[:, eoff:eoff + cout]  # view: pointer = base + eoff, ld = emb_total
+            if mode == "up":
+                assert x2 is None and cin == cout
+                hbuf, ho, wo = conv3(a, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd, upsample=1, rowbias=rowbias)
+                xs = A.get((B, ho * wo, cin))
+                emit(lambda x=x, xs=xs: ops.upsample_nearest2x(x, B, h, wd, cin, out=xs), "small")
+            elif mode == "down":
+                assert x2 is None and cin == cout
+                ap = A.get((B, hw // 4, cin))
+                emit(lambda a=a, ap=ap: ops.avgpool2x2(a, B, h, wd, cin, out=ap), "small")
+                hbuf, ho, wo = conv3(ap, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h // 2, wd // 2, rowbias=rowbias)
+                A.release(ap)
+                xs = A.get((B, hw // 4, cin))
+                emit(lambda x=x, xs=xs: ops.avgpool2x2(x, B, h, wd, cin, out=xs), "small")
+            else:
+                hbuf, ho, wo = conv3(a, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd, rowbias=rowbias)
+                xs = x
             A.release(a)
-            a2 = A.get((B, hw, cout))
-            add_gn(hbuf, None, w[pre + "out_layers_norm.g"], w[pre + "out_layers_norm.b"], 1e-5, True, a2)
+            a2 = A.get((B, ho * wo, cout))
+            if film:
+                add_gn(hbuf, None, w[pre + "out_layers_norm.g"], w[pre + "out_layers_norm.b"], 1e-5, True, a2,
+                       scale=P.emb_all[:, eoff:eoff + cout], shift=P.emb_all[:, eoff + cout:eoff + 2 * cout])
+            else:
+                add_gn(hbuf, None, w[pre + "out_layers_norm.g"], w[pre + "out_layers_norm.b"], 1e-5, True, a2)
             A.release(hbuf)
             if cin != cout:
                 skip = dense(main, x, B, hw, cin, cout, w[pre + "skip.w"], bias=w[pre + "skip.b"], src2=x2, c2=c2)
             else:
                 assert x2 is None
-                skip = x
-            out, _, _ = conv3(a2, cout, cout, w[pre + "conv2.w"], w[pre + "conv2.b"], h, wd, residual=skip)
+                skip = xs
+            out, _, _ = conv3(a2, cout, cout, w[pre + "conv2.w"], w[pre + "conv2.b"], ho, wo, residual=skip)
             A.release(a2)
             if skip is not x:
                 A.release(skip)
-            return out
+            return out, ho, wo
 
         def transformer(pre, x, ch, heads, dh, h, wd):
-            """SpatialTransformer.construct attention.py:237-256 + BasicTransformerBlock :181-185 (NHWC == tokens)."""
+            """SpatialTransformer.construct attention.py:237-256 + `transformer_depth` BasicTransformerBlocks :181-185
+            (NHWC == tokens)."""
             n = h * wd
             inner = heads * dh
             scale = dh ** -0.5
-            t = pre + "transformer_blocks.0."
             a = A.get((B, n, ch))
             add_gn(x, None, w[pre + "norm.g"], w[pre + "norm.b"], 1e-6, False, a)
             # LayerNorm fold: `st` receives the row statistics from each producer of the token stream
-            st = stats_buf(B * n, inner) if (t + "attn2.q.s") in w else None
-            fold1 = st is not None and (t + "attn1.qkv.s") in w
+            t0 = pre + "transformer_blocks.0."
+            st = stats_buf(B * n, inner) if (t0 + "attn2.q.s") in w else None
+            fold1 = st is not None and (t0 + "attn1.qkv.s") in w
 
             def consumer(name):   # kwargs of a GEMM that consumes LN(rows) with folded weights
                 return dict(bias=w[name + ".cb"], ln_stats=st, ln_s=w[name + ".s"], ln_eps=1e-5)
             tok = dense(main, a, B, n, ch, inner, w[pre + "proj_in.w"], bias=w[pre + "proj_in.b"],
                         stats_out=st if fold1 else None)
             A.release(a)
-            # --- attn1 (self)
-            ln = A.get((B, n, inner))
-            if not fold1:
-                emit(lambda ln=ln, tok=tok: ops.layernorm(tok, w[t + "norm1.g"], w[t + "norm1.b"], 1e-5, out=ln), "layernorm")
-            vt = A.get((B, inner, n))
-            if (t + "attn1.qkv.w") in w:
-                qk = A.get((B, n, 2 * inner))
-                add_gemm(main, a=tok if fold1 else ln, w=w[t + "attn1.qkv.w"], N=3 * inner, B=B, H=n, W=1, c1=inner, out=qk,
-                         out_ld=2 * inner, out2=vt, out2_ld=n, n_split=2 * inner, **(consumer(t + "attn1.qkv") if fold1 else {}))
-            else:
-                qk = dense(main, ln, B, n, inner, 2 * inner, w[t + "attn1.qk.w"])
-                dense(main, ln, B, n, inner, inner, w[t + "attn1.v.w"], out=vt, out_ld=n, out_mode=ops.OUT_TRANSPOSED)
-            o = ln  # reuse: ln is dead after the projections
-            emit(lambda qk=qk, vt=vt, o=o: ops.attention(
-                qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
-                n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner),
-                "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
-            tok2 = dense(main, o, B, n, inner, inner, w[t + "attn1.o.w"], bias=w[t + "attn1.o.b"], residual=tok, stats_out=st)
-            A.release(qk); A.release(vt); A.release(tok)
-            # --- attn2 (cross): K / V^T of the context are produced by the context plan
-            if st is None:
-                emit(lambda ln=ln, tok2=tok2: ops.layernorm(tok2, w[t + "norm2.g"], w[t + "norm2.b"], 1e-5, out=ln), "layernorm")
-                q2 = dense(main, ln, B, n, inner, inner, w[t + "attn2.q.w"])
-            else:
-                q2 = dense(main, tok2, B, n, inner, inner, w[t + "attn2.q.w"], **consumer(t + "attn2.q"))
-            kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
-            vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
-            ctx_kv[pre] = (kc, vtc)
-            emit(lambda q2=q2, kc=kc, vtc=vtc, o=o: ops.attention(
-                q2.data_ptr(), kc.data_ptr(), vtc.data_ptr(), o.data_ptr(), B, heads, dh, n, P.ctx_len, scale,
-                n * inner, inner, TC * inner, inner, inner * TC, TC, n * inner, inner),
-                "attention", 4 * B * heads * n * 77 * dh, 1, f"cross B={B} h={heads} N={n} d={dh}")
-            tok3 = dense(main, o, B, n, inner, inner, w[t + "attn2.o.w"], bias=w[t + "attn2.o.b"], residual=tok2, stats_out=st)
-            A.release(q2); A.release(tok2)
-            # --- feed-forward (GEGLU fused in the first GEMM's epilogue)
-            if st is None:
-                emit(lambda ln=ln, tok3=tok3: ops.layernorm(tok3, w[t + "norm3.g"], w[t + "norm3.b"], 1e-5, out=ln), "layernorm")
-                g = dense(main, ln, B, n, inner, 8 * inner, w[t + "ff1.w"], bias=w[t + "ff1.b"], epilogue=ops.EPI_GEGLU)
-            else:
-                g = dense(main, tok3, B, n, inner, 8 * inner, w[t + "ff1.w"], epilogue=ops.EPI_GEGLU, **consumer(t + "ff1"))
-            tok4 = dense(main, g, B, n, 4 * inner, inner, w[t + "ff2.w"], bias=w[t + "ff2.b"], residual=tok3)
-            A.release(g); A.release(tok3); A.release(ln)
-            out = dense(main, tok4, B, n, inner, ch, w[pre + "proj_out.w"], bias=w[pre + "proj_out.b"], residual=x)
-            A.release(tok4)
+            for k in range(self.transformer_depth):
+                t = pre + f"transformer_blocks.{k}."
+                last = k == self.transformer_depth - 1
+                # --- attn1 (self)
+                ln = A.get((B, n, inner))
+                if not fold1:
+                    emit(lambda ln=ln, tok=tok, t=t: ops.layernorm(tok, w[t + "norm1.g"], w[t + "norm1.b"], 1e-5, out=ln),
+                         "layernorm")
+                vt = A.get((B, inner, n))
+                if (t + "attn1.qkv.w") in w:
+                    qk = A.get((B, n, 2 * inner))
+                    add_gemm(main, a=tok if fold1 else ln, w=w[t + "attn1.qkv.w"], N=3 * inner, B=B, H=n, W=1, c1=inner, out=qk,
+                             out_ld=2 * inner, out2=vt, out2_ld=n, n_split=2 * inner,
+                             **(consumer(t + "attn1.qkv") if fold1 else {}))
+                else:
+                    qk = dense(main, ln, B, n, inner, 2 * inner, w[t + "attn1.qk.w"])
+                    dense(main, ln, B, n, inner, inner, w[t + "attn1.v.w"], out=vt, out_ld=n, out_mode=ops.OUT_TRANSPOSED)
+                o = ln  # reuse: ln is dead after the projections
+                emit(lambda qk=qk, vt=vt, o=o: ops.attention(
+                    qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
+                    n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner),
+                    "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
+                tok2 = dense(main, o, B, n, inner, inner, w[t + "attn1.o.w"], bias=w[t + "attn1.o.b"], residual=tok,
+                             stats_out=st)
+                A.release(qk); A.release(vt); A.release(tok)
+                # --- attn2 (cross): K / V^T of the context are produced by the context plan
+                if st is None:
+                    emit(lambda ln=ln, tok2=tok2, t=t: ops.layernorm(tok2, w[t + "norm2.g"], w[t + "norm2.b"], 1e-5, out=ln),
+                         "layernorm")
+                    q2 = dense(main, ln, B, n, inner, inner, w[t + "attn2.q.w"])
+                else:
+                    q2 = dense(main, tok2, B, n, inner, inner, w[t + "attn2.q.w"], **consumer(t + "attn2.q"))
+                kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
+                vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
+                ctx_kv[t] = (kc, vtc)
+                emit(lambda q2=q2, kc=kc, vtc=vtc, o=o: ops.attention(
+                    q2.data_ptr(), kc.data_ptr(), vtc.data_ptr(), o.data_ptr(), B, heads, dh, n, P.ctx_len, scale,
+                    n * inner, inner, TC * inner, inner, inner * TC, TC, n * inner, inner),
+                    "attention", 4 * B * heads * n * 77 * dh, 1, f"cross B={B} h={heads} N={n} d={dh}")
+                tok3 = dense(main, o, B, n, inner, inner, w[t + "attn2.o.w"], bias=w[t + "attn2.o.b"], residual=tok2,
+                             stats_out=st)
+                A.release(q2); A.release(tok2)
+                # --- feed-forward (GEGLU fused in the first GEMM's epilogue)
+                if st is None:
+                    emit(lambda ln=ln, tok3=tok3, t=t: ops.layernorm(tok3, w[t + "norm3.g"], w[t + "norm3.b"], 1e-5, out=ln),
+                         "layernorm")
+                    g = dense(main, ln, B, n, inner, 8 * inner, w[t + "ff1.w"], bias=w[t + "ff1.b"], epilogue=ops.EPI_GEGLU)
+                else:
+                    g = dense(main, tok3, B, n, inner, 8 * inner, w[t + "ff1.w"], epilogue=ops.EPI_GEGLU, **consumer(t + "ff1"))
+                # the next block's norm1 reads its row statistics from this block's last producer
+                tok = dense(main, g, B, n, 4 * inner, inner, w[t + "ff2.w"], bias=w[t + "ff2.b"], residual=tok3,
+                            stats_out=st if (fold1 and not last) else None)
+                A.release(g); A.release(tok3); A.release(ln)
+            out = dense(main, tok, B, n, inner, ch, w[pre + "proj_out.w"], bias=w[pre + "proj_out.b"], residual=x)
+            A.release(tok)
             return out
 
         # ---- context plan: to_k / to_v of attn2 for every SpatialTransformer (attention.py:119-121)
@@ -576,64 +642,66 @@ class UNetModel:
         h, wd = H, W
         hs = []
         cur = None
+
+        def held(t):        # still needed as a skip connection?
+            return any(t is s_[0] for s_ in hs)
+
+        def layer_op(pre, layer, cur, skip, h, wd):
+            kind = layer[0]
+            if kind == "res":
+                return resblock(pre, cur, skip, layer[1], layer[2], h, wd)
+            if kind in ("resdown", "resup"):
+                return resblock(pre, cur, None, layer[1], layer[2], h, wd, mode=kind[3:])
+            if kind == "st":
+                return transformer(pre, cur, layer[1], layer[2], layer[3], h, wd), h, wd
+            if kind == "down":          # Downsample openaimodel.py:63-88
+                if self.conv_resample:
+                    return conv3(cur, layer[1], layer[1], w[pre + "w"], w[pre + "b"], h, wd, stride=2)
+                new = A.get((B, (h // 2) * (wd // 2), layer[1]))
+                emit(lambda cur=cur, new=new: ops.avgpool2x2(cur, B, h, wd, layer[1], out=new), "small")
+                return new, h // 2, wd // 2
+            if kind == "up":            # Upsample openaimodel.py:33-60 (the nearest-2x is folded into the conv's gather)
+                if self.conv_resample:
+                    return conv3(cur, layer[1], layer[1], w[pre + "w"], w[pre + "b"], h, wd, upsample=1)
+                new = A.get((B, 4 * h * wd, layer[1]))
+                emit(lambda cur=cur, new=new: ops.upsample_nearest2x(cur, B, h, wd, layer[1], out=new), "small")
+                return new, 2 * h, 2 * wd
+            raise ValueError(kind)
+
         for i, blk in enumerate(self.input_blocks):
             for j, layer in enumerate(blk):
                 pre = f"input_blocks.{i}.{j}."
-                kind = layer[0]
-                if kind == "conv":
+                if layer[0] == "conv":
                     cur, h, wd = conv3(xin, self.cin_pad, layer[2], w[pre + "w"], w[pre + "b"], h, wd)
                     A.release(xin)
-                elif kind == "res":
-                    new = resblock(pre, cur, None, layer[1], layer[2], h, wd)
-                    if not any(cur is s[0] for s in hs):
-                        A.release(cur)
-                    cur = new
-                elif kind == "st":
-                    new = transformer(pre, cur, layer[1], layer[2], layer[3], h, wd)
+                    continue
+                new, h2, w2 = layer_op(pre, layer, cur, None, h, wd)
+                if not held(cur):
                     A.release(cur)
-                    cur = new
-                elif kind == "down":
-                    new, h2, w2 = conv3(cur, layer[1], layer[1], w[pre + "w"], w[pre + "b"], h, wd, stride=2)
-                    if not any(cur is s[0] for s in hs):
-                        A.release(cur)
-                    cur, h, wd = new, h2, w2
+                cur, h, wd = new, h2, w2
             hs.append((cur, h, wd))
         for j, layer in enumerate(self.middle_block):
-            pre = f"middle_block.{j}."
-            if layer[0] == "res":
-                new = resblock(pre, cur, None, layer[1], layer[2], h, wd)
-            else:
-                new = transformer(pre, cur, layer[1], layer[2], layer[3], h, wd)
-            if not any(cur is s[0] for s in hs):
+            new, h, wd = layer_op(f"middle_block.{j}.", layer, cur, None, h, wd)
+            if not held(cur):
                 A.release(cur)
             cur = new
         for i, blk in enumerate(self.output_blocks):
             skip, sh, sw = hs.pop()
             assert (sh, sw) == (h, wd)
             for j, layer in enumerate(blk):
-                pre = f"output_blocks.{i}.{j}."
-                kind = layer[0]
-                if kind == "res":
-                    new = resblock(pre, cur, skip, layer[1], layer[2], h, wd)
-                    A.release(cur)
+                new, h, wd = layer_op(f"output_blocks.{i}.{j}.", layer, cur, skip if j == 0 else None, h, wd)
+                A.release(cur)
+                if j == 0:
                     A.release(skip)
-                    cur = new
-                elif kind == "st":
-                    new = transformer(pre, cur, layer[1], layer[2], layer[3], h, wd)
-                    A.release(cur)
-                    cur = new
-                elif kind == "up":
-                    new, h, wd = conv3(cur, layer[1], layer[1], w[pre + "w"], w[pre + "b"], h, wd, upsample=1)
-                    A.release(cur)
-                    cur = new
+                cur = new
         a = A.get((B, h * wd, mc))
-        add_gn(cur, None, w["out.g"], w["out.b"], 1e-5, True, a)
+        # `out` = GroupNorm -> SiLU -> 3x3 conv; predict_codebook_ids: `id_predictor` = GroupNorm -> 1x1 conv (:520-531, 573-576)
+        add_gn(cur, None, w["out.g"], w["out.b"], 1e-5, self.n_embed is None, a)
         P.eps_nhwc = torch.empty((B, h * wd, self.cout_pad), dtype=f16, device=dev)
         add_gemm(main, a=a, w=w["out.w"], N=self.cout_pad, B=B, H=h, W=wd, c1=mc, out=P.eps_nhwc, out_ld=self.cout_pad,
-                 bias=w["out.cb"], ksize=3)
+                 bias=w["out.cb"], ksize=3 if self.n_embed is None else 1)
 
-        for pre, (kc, vtc) in ctx_kv.items():
-            t = pre + "transformer_blocks.0."
+        for t, (kc, vtc) in ctx_kv.items():
             inner = kc.shape[2]
             add_gemm(ctxops, a=P.ctx_pad, w=w[t + "attn2.k.w"], N=inner, B=B, H=TC, W=1, c1=self.context_dim, out=kc,
                      out_ld=inner)
@@ -663,7 +731,7 @@ class UNetModel:
                 cpg = C1 // 32
                 L = cpg // math.gcd(cpg, 8)
                 d = c["prod"][0]
-                if (c["x2"] is None and L <= 64 and HW * L * 16 <= (64 << 10) and d is not None and d.N == C1
+                if (c["x2"] is None and not c["film"] and L <= 64 and HW * L * 16 <= (64 << 10) and d is not None and d.N == C1
                         and d.out_ld == C1 and op_index.get(ctypes.addressof(d)) == c["meta"] - 1
                         and ops.gemm_query(d)[2] > 1 and ops.groupnorm_from_splitk_ok(d)):
                     d.defer_reduce = 1
@@ -722,6 +790,9 @@ class UNetModel:
         once per run instead of once per step) and passes row i to forward_nhwc(..., temb=row)."""
         if self.w is None:
             raise MdxError("UNetModel: load_state_dict() must be called before time_embedding_table()")
+        if self.num_classes is not None:
+            raise MdxError("UNetModel: a class-conditional UNet adds label_emb(y) before the ResBlock projections; "
+                           "there is no timestep-only table")
         t = torch.as_tensor(t, dtype=f32).to(self.device).reshape(-1).contiguous()
         w = self.w
         e0 = ops.timestep_embedding(t, self.model_channels)
@@ -729,10 +800,15 @@ class UNetModel:
         e2 = ops.dense_small(e1, w["te2.w"], w["te2.b"])
         return ops.dense_small(e2, w["emb.w"], w["emb.b"], act_in=True)
 
-    def forward_nhwc(self, x, timesteps, context, temb=None):
+    def forward_nhwc(self, x, timesteps, context, temb=None, y=None):
         """Run the UNet; returns the plan's static NHWC fp16 eps buffer [B, H*W, 8] (first 4 channels valid).
         The buffer is overwritten by the next call.  temb: optional row(s) of time_embedding_table() for `timesteps`
-        ([emb_total] or [B, emb_total]); the time-embedding launches are then skipped."""
+        ([emb_total] or [B, emb_total]); the time-embedding launches are then skipped.  y: [B] class labels of a
+        class-conditional UNet (num_classes)."""
+        if (y is not None) != (self.num_classes is not None):      # openaimodel.py:545-547
+            raise MdxError("UNetModel: must specify y if and only if the model is class-conditional")
+        if y is not None and temb is not None:
+            raise MdxError("UNetModel: time_embedding_table() rows do not carry the label embedding; pass timesteps with y")
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
             raise MdxError("UNetModel: x must be a CUDA(HIP) tensor (no CPU fallback)")
         B, C, H, W = x.shape
@@ -748,6 +824,13 @@ class UNetModel:
         else:
             P.t_static.copy_(timesteps.to(device=self.device, dtype=f32) if isinstance(timesteps, torch.Tensor)
                              else torch.as_tensor(timesteps, dtype=f32, device=self.device))
+            if y is not None:
+                yy = torch.as_tensor(y).to(device=self.device, dtype=torch.long).reshape(-1)
+                if yy.shape[0] != B:
+                    raise MdxError(f"UNetModel: y has {yy.shape[0]} labels for a batch of {B}")
+                if int(yy.min()) < 0 or int(yy.max()) >= self.num_classes:
+                    raise MdxError(f"UNetModel: class label outside [0, {self.num_classes})")
+                P.y_static.copy_(yy)
             for op in P.main[:P.temb_ops]:
                 op()
         if self.use_graph and not P.graph_failed:
@@ -782,10 +865,9 @@ class UNetModel:
 
     def construct(self, x, timesteps=None, context=None, y=None):
         """openaimodel.py:536-576.  x [N,C,H,W], timesteps [N], context [N,T,context_dim] -> eps [N,C,H,W] fp32."""
-        assert y is None, "class-conditional UNet is not part of the reference's shipped configs"
-        eps = self.forward_nhwc(x, timesteps, context)
+        eps = self.forward_nhwc(x, timesteps, context, y=y)
         B, _, H, W = x.shape
-        return ops.nhwc_to_nchw(eps, self.out_channels, H, W)
+        return ops.nhwc_to_nchw(eps, self.final_channels, H, W)
 
     __call__ = construct
     forward = construct

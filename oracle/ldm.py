@@ -184,7 +184,9 @@ def unet_structure(cfg):
 
     Each block is a list of layer descriptors:
       ('conv', cin, cout) | ('res', cin, cout) | ('st', ch, heads, dim_head)
-      | ('down', ch) | ('up', ch)
+      | ('down', ch) | ('up', ch) | ('resdown', ch, ch) | ('resup', ch, ch)   (the last two: resblock_updown=True)
+    The cfg-level switches (use_scale_shift_norm, conv_resample, transformer_depth, num_classes, n_embed) do not change the
+    block lists, only what a layer of a kind does.
     """
     mc = cfg["model_channels"]
     nh_cfg = cfg.get("num_heads", -1)
@@ -218,7 +220,7 @@ def unet_structure(cfg):
             input_blocks.append(layers)
             chans.append(ch)
         if level != len(cm) - 1:
-            input_blocks.append([("down", ch)])
+            input_blocks.append([("resdown", ch, ch) if cfg.get("resblock_updown", False) else ("down", ch)])
             chans.append(ch)
             ds *= 2
     num_heads, dim_head = heads_for(ch, num_heads)
@@ -233,7 +235,7 @@ def unet_structure(cfg):
                 num_heads, dim_head = heads_for(ch, num_heads)
                 layers.append(("st", ch, num_heads, dim_head))
             if level and i == cfg["num_res_blocks"]:
-                layers.append(("up", ch))
+                layers.append(("resup", ch, ch) if cfg.get("resblock_updown", False) else ("up", ch))
                 ds //= 2
             output_blocks.append(layers)
     return input_blocks, middle, output_blocks
@@ -248,15 +250,26 @@ class UNetOracle:
         self.input_blocks, self.middle, self.output_blocks = unet_structure(cfg)
 
     # -- layers ---------------------------------------------------------------
-    def _res(self, pre, x, emb):
-        """ResBlock.construct openaimodel.py:176-205 (use_scale_shift_norm=False, no up/down)."""
+    def _res(self, pre, x, emb, mode=None):
+        """ResBlock.construct openaimodel.py:176-205.  mode 'up' / 'down': the resblock_updown form, where nearest-2x /
+        2x2 average pooling (Upsample / Downsample with use_conv=False, :33-88) act on BOTH the normalised branch and the
+        skip input; use_scale_shift_norm: GroupNorm(h) * (1 + scale) + shift from a 2x-wide emb projection (:193-198)."""
         p = self.p
         h = group_norm(x, p[pre + "in_layers_norm.gamma"], p[pre + "in_layers_norm.beta"], 1e-5)
         h = silu(h)
+        if mode == "up":
+            h, x = upsample_nearest2x(h), upsample_nearest2x(x)
+        elif mode == "down":
+            h, x = r16(F.avg_pool2d(h, 2)), r16(F.avg_pool2d(x, 2))
         h = conv2d(h, p[pre + "in_layers_conv.conv.weight"], p[pre + "in_layers_conv.conv.bias"])
         emb_out = dense(silu(emb), p[pre + "emb_layers.1.weight"], p[pre + "emb_layers.1.bias"])
-        h = r16(h + emb_out[:, :, None, None])
-        h = group_norm(h, p[pre + "out_layers_norm.gamma"], p[pre + "out_layers_norm.beta"], 1e-5)
+        if self.cfg.get("use_scale_shift_norm", False):
+            scale, shift = emb_out[:, :, None, None].chunk(2, dim=1)
+            h = group_norm(h, p[pre + "out_layers_norm.gamma"], p[pre + "out_layers_norm.beta"], 1e-5)
+            h = r16(r16(h * r16(1 + scale)) + shift)
+        else:
+            h = r16(h + emb_out[:, :, None, None])
+            h = group_norm(h, p[pre + "out_layers_norm.gamma"], p[pre + "out_layers_norm.beta"], 1e-5)
         h = silu(h)
         h = conv2d(h, p[pre + "out_layers_conv.conv.weight"], p[pre + "out_layers_conv.conv.bias"])
         if (pre + "skip_connection.conv.weight") in p:
@@ -297,15 +310,16 @@ class UNetOracle:
         x = x.reshape(b, c, h * w).permute(0, 2, 1)
         if use_linear:
             x = dense(x, p[pre + "proj_in.weight"], p[pre + "proj_in.bias"])
-        t = pre + "transformer_blocks.0."
-        x = r16(self._attn(t + "attn1.", layer_norm(x, p[t + "norm1.gamma"], p[t + "norm1.beta"], 1e-5), None, heads) + x)
-        x = r16(self._attn(t + "attn2.", layer_norm(x, p[t + "norm2.gamma"], p[t + "norm2.beta"], 1e-5), context, heads) + x)
-        y = layer_norm(x, p[t + "norm3.gamma"], p[t + "norm3.beta"], 1e-5)
-        y = dense(y, p[t + "ff.net.0.proj.weight"], p[t + "ff.net.0.proj.bias"])  # GEGLU attention.py:41-51
-        a, gate = y.chunk(2, dim=-1)
-        y = r16(a * gelu_tanh(gate))
-        y = dense(y, p[t + "ff.net.2.weight"], p[t + "ff.net.2.bias"])
-        x = r16(y + x)
+        for k in range(self.cfg.get("transformer_depth", 1)):      # attention.py:221-224, 248-249
+            t = pre + f"transformer_blocks.{k}."
+            x = r16(self._attn(t + "attn1.", layer_norm(x, p[t + "norm1.gamma"], p[t + "norm1.beta"], 1e-5), None, heads) + x)
+            x = r16(self._attn(t + "attn2.", layer_norm(x, p[t + "norm2.gamma"], p[t + "norm2.beta"], 1e-5), context, heads) + x)
+            y = layer_norm(x, p[t + "norm3.gamma"], p[t + "norm3.beta"], 1e-5)
+            y = dense(y, p[t + "ff.net.0.proj.weight"], p[t + "ff.net.0.proj.bias"])  # GEGLU attention.py:41-51
+            a, gate = y.chunk(2, dim=-1)
+            y = r16(a * gelu_tanh(gate))
+            y = dense(y, p[t + "ff.net.2.weight"], p[t + "ff.net.2.bias"])
+            x = r16(y + x)
         if use_linear:
             x = dense(x, p[pre + "proj_out.weight"], p[pre + "proj_out.bias"])
         x = x.reshape(b, h, w, c).permute(0, 3, 1, 2)
@@ -322,22 +336,33 @@ class UNetOracle:
             return self._res(pre, h, emb)
         if kind == "st":
             return self._st(pre, h, context, layer[2])
+        if kind in ("resdown", "resup"):
+            return self._res(pre, h, emb, mode=kind[3:])
+        conv_resample = self.cfg.get("conv_resample", True)
         if kind == "down":  # Downsample openaimodel.py:63-88
+            if not conv_resample:
+                return r16(F.avg_pool2d(h, 2))
             return conv2d(h, p[pre + "op.conv.weight"], p[pre + "op.conv.bias"], stride=2, padding=1)
         if kind == "up":  # Upsample openaimodel.py:33-60
+            if not conv_resample:
+                return upsample_nearest2x(h)
             return conv2d(upsample_nearest2x(h), p[pre + "conv.conv.weight"], p[pre + "conv.conv.bias"])
         raise ValueError(kind)
 
     # -- forward --------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, x, timesteps, context):
+    def forward(self, x, timesteps, context, y=None):
         p = self.p
+        assert (y is not None) == (self.cfg.get("num_classes") is not None), \
+            "must specify y if and only if the model is class-conditional"      # openaimodel.py:545-547
         x = r16(torch.as_tensor(x, dtype=torch.float32))              # apply_model casts x_noisy / cond (ddpm.py:291-292)
         context = r16(torch.as_tensor(context, dtype=torch.float32))
         timesteps = torch.as_tensor(timesteps)
         t_emb = timestep_embedding(timesteps, self.cfg["model_channels"])
         emb = dense(t_emb, p["time_embed.0.weight"], p["time_embed.0.bias"])
         emb = dense(silu(emb), p["time_embed.2.weight"], p["time_embed.2.bias"])
+        if y is not None:       # openaimodel.py:552-554
+            emb = r16(emb + r16(p["label_emb.embedding_table"])[torch.as_tensor(np.asarray(y), dtype=torch.long)])
         hs = []
         h = x
         for i, block in enumerate(self.input_blocks):
@@ -350,6 +375,9 @@ class UNetOracle:
             h = torch.cat([h, hs.pop()], dim=1)
             for j, layer in enumerate(block):
                 h = self._layer(f"output_blocks.{i}.{j}.", layer, h, emb, context)
+        if self.cfg.get("n_embed") is not None:      # predict_codebook_ids: GroupNorm -> 1x1 conv, no SiLU (:527-531, 573-574)
+            h = group_norm(h, p["id_predictor.0.gamma"], p["id_predictor.0.beta"], 1e-5)
+            return conv2d(h, p["id_predictor.1.conv.weight"], p["id_predictor.1.conv.bias"], padding=0)
         h = silu(group_norm(h, p["out.0.gamma"], p["out.0.beta"], 1e-5))
         return conv2d(h, p["out.2.conv.weight"], p["out.2.conv.bias"])
 
@@ -363,24 +391,28 @@ def unet_param_shapes(cfg):
     ted = 4 * mc
     ctx = cfg["context_dim"]
     use_linear = cfg.get("use_linear_in_transformer", False)
+    ssn = 2 if cfg.get("use_scale_shift_norm", False) else 1
+    conv_resample = cfg.get("conv_resample", True)
     shapes = {
         "time_embed.0.weight": (ted, mc), "time_embed.0.bias": (ted,),
         "time_embed.2.weight": (ted, ted), "time_embed.2.bias": (ted,),
     }
+    if cfg.get("num_classes") is not None:
+        shapes["label_emb.embedding_table"] = (cfg["num_classes"], ted)
 
     def add_layer(pre, layer):
         kind = layer[0]
         if kind == "conv":
             shapes[pre + "conv.weight"] = (layer[2], layer[1], 3, 3)
             shapes[pre + "conv.bias"] = (layer[2],)
-        elif kind == "res":
+        elif kind in ("res", "resdown", "resup"):
             cin, cout = layer[1], layer[2]
             shapes[pre + "in_layers_norm.gamma"] = (cin,)
             shapes[pre + "in_layers_norm.beta"] = (cin,)
             shapes[pre + "in_layers_conv.conv.weight"] = (cout, cin, 3, 3)
             shapes[pre + "in_layers_conv.conv.bias"] = (cout,)
-            shapes[pre + "emb_layers.1.weight"] = (cout, ted)
-            shapes[pre + "emb_layers.1.bias"] = (cout,)
+            shapes[pre + "emb_layers.1.weight"] = (ssn * cout, ted)
+            shapes[pre + "emb_layers.1.bias"] = (ssn * cout,)
             shapes[pre + "out_layers_norm.gamma"] = (cout,)
             shapes[pre + "out_layers_norm.beta"] = (cout,)
             shapes[pre + "out_layers_conv.conv.weight"] = (cout, cout, 3, 3)
@@ -401,24 +433,25 @@ def unet_param_shapes(cfg):
                 shapes[pre + "proj_out.weight"] = (ch, inner, 1, 1)
             shapes[pre + "proj_in.bias"] = (inner,)
             shapes[pre + "proj_out.bias"] = (ch,)
-            t = pre + "transformer_blocks.0."
-            for a, cd in (("attn1.", inner), ("attn2.", ctx)):
-                shapes[t + a + "to_q.weight"] = (inner, inner)
-                shapes[t + a + "to_k.weight"] = (inner, cd)
-                shapes[t + a + "to_v.weight"] = (inner, cd)
-                shapes[t + a + "to_out.0.weight"] = (inner, inner)
-                shapes[t + a + "to_out.0.bias"] = (inner,)
-            shapes[t + "ff.net.0.proj.weight"] = (inner * 8, inner)
-            shapes[t + "ff.net.0.proj.bias"] = (inner * 8,)
-            shapes[t + "ff.net.2.weight"] = (inner, inner * 4)
-            shapes[t + "ff.net.2.bias"] = (inner,)
-            for n in ("norm1", "norm2", "norm3"):
-                shapes[t + n + ".gamma"] = (inner,)
-                shapes[t + n + ".beta"] = (inner,)
-        elif kind == "down":
+            for k in range(cfg.get("transformer_depth", 1)):
+                t = pre + f"transformer_blocks.{k}."
+                for a, cd in (("attn1.", inner), ("attn2.", ctx)):
+                    shapes[t + a + "to_q.weight"] = (inner, inner)
+                    shapes[t + a + "to_k.weight"] = (inner, cd)
+                    shapes[t + a + "to_v.weight"] = (inner, cd)
+                    shapes[t + a + "to_out.0.weight"] = (inner, inner)
+                    shapes[t + a + "to_out.0.bias"] = (inner,)
+                shapes[t + "ff.net.0.proj.weight"] = (inner * 8, inner)
+                shapes[t + "ff.net.0.proj.bias"] = (inner * 8,)
+                shapes[t + "ff.net.2.weight"] = (inner, inner * 4)
+                shapes[t + "ff.net.2.bias"] = (inner,)
+                for n in ("norm1", "norm2", "norm3"):
+                    shapes[t + n + ".gamma"] = (inner,)
+                    shapes[t + n + ".beta"] = (inner,)
+        elif kind == "down" and conv_resample:        # Downsample(use_conv=False) is a parameter-free 2x2 average pool
             shapes[pre + "op.conv.weight"] = (layer[1], layer[1], 3, 3)
             shapes[pre + "op.conv.bias"] = (layer[1],)
-        elif kind == "up":
+        elif kind == "up" and conv_resample:
             shapes[pre + "conv.conv.weight"] = (layer[1], layer[1], 3, 3)
             shapes[pre + "conv.conv.bias"] = (layer[1],)
 
@@ -434,6 +467,11 @@ def unet_param_shapes(cfg):
     shapes["out.0.beta"] = (mc,)
     shapes["out.2.conv.weight"] = (cfg["out_channels"], mc, 3, 3)
     shapes["out.2.conv.bias"] = (cfg["out_channels"],)
+    if cfg.get("n_embed") is not None:
+        shapes["id_predictor.0.gamma"] = (mc,)
+        shapes["id_predictor.0.beta"] = (mc,)
+        shapes["id_predictor.1.conv.weight"] = (cfg["n_embed"], mc, 1, 1)
+        shapes["id_predictor.1.conv.bias"] = (cfg["n_embed"],)
     return shapes
 
 
@@ -497,7 +535,8 @@ class ModelOracle:
 def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0.0,
            unconditional_guidance_scale=1.0, unconditional_conditioning=None, noise_fn=None,
            temperature=1.0, log_every_t=100, mask=None, x0=None, blend_noises=None, timesteps=None,
-           ddim_use_original_steps=False, noise_dropout=0.0, dropout_masks=None):
+           ddim_use_original_steps=False, noise_dropout=0.0, dropout_masks=None, score_corrector=None,
+           corrector_kwargs=None, quantize_x0=False):
     """PLMSSampler.sample/plms_sampling/p_sample_plms (plms.py:69-247).
 
     sampler='ddim' applies get_x_prev_and_pred_x0 (plms.py:210-228) with e'=e_t each step
@@ -505,6 +544,9 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
     timesteps / ddim_use_original_steps: plms.py:134-142, 205-208 (a prefix of the DDIM grid, or every DDPM step with the
     model's own alphas_cumprod tables).  noise_dropout: plms.py:224-225 `ops.dropout(noise, p)` = zero with probability p,
     survivors scaled by 1/(1-p); dropout_masks[k] (1 = keep) is the k-th draw.
+    score_corrector / corrector_kwargs: plms.py:199-201 (every model output goes through
+    `score_corrector.modify_score(model, e_t, x, t, c, **corrector_kwargs)`); quantize_x0: plms.py:218-219
+    (`pred_x0, _, *_ = model.first_stage_model.quantize(pred_x0)`).
     Returns (samples, intermediates).
     """
     if sampler == "plms" and eta != 0:
@@ -553,12 +595,17 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
 
     def get_model_output(x, t):  # plms.py:188-203
         if uc is None or scale == 1.0:
-            return model.apply_model(x, t, wrap(cond, 1))
-        x_in = torch.cat([x, x], 0)
-        t_in = torch.cat([t, t], 0)
-        c_in = wrap(torch.cat([uc, cond], 0), 2)
-        e_u, e_c = model.apply_model(x_in, t_in, c_in).chunk(2, dim=0)
-        return r16(e_u + r16(scale * r16(e_c - e_u)))     # fp16 mode: eps is an fp16 tensor, each op rounds (plms.py:197)
+            e_t = model.apply_model(x, t, wrap(cond, 1))
+        else:
+            x_in = torch.cat([x, x], 0)
+            t_in = torch.cat([t, t], 0)
+            c_in = wrap(torch.cat([uc, cond], 0), 2)
+            e_u, e_c = model.apply_model(x_in, t_in, c_in).chunk(2, dim=0)
+            e_t = r16(e_u + r16(scale * r16(e_c - e_u)))     # fp16 mode: eps is an fp16 tensor, each op rounds (plms.py:197)
+        if score_corrector is not None:
+            assert getattr(model, "parameterization", "eps") == "eps"
+            e_t = score_corrector.modify_score(model, e_t, x, t, cond, **(corrector_kwargs or {}))
+        return e_t
 
     drops = [0]
 
@@ -568,6 +615,8 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
         sigma_t = torch.tensor(sigmas[index])
         s1m = torch.tensor(sqrt_one_minus_alphas[index])
         pred_x0 = (x - s1m * e_t) / a_t.sqrt()
+        if quantize_x0:
+            pred_x0, _, *_ = model.first_stage_model.quantize(pred_x0)
         dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t
         if float(sigma_t) != 0.0:
             noise = sigma_t * torch.as_tensor(noise_fn(tuple(x.shape)), dtype=torch.float32) * temperature

@@ -219,3 +219,38 @@ def test_sampler_option_noise_dropout():
     # eta changes the dir coefficient too, so compare the two eta = 1 runs with each other
     np.testing.assert_allclose(drop - (full - sig * noise), sig * noise * keep / 0.5, atol=1e-5)
     assert np.abs(full - base).max() > 0
+
+
+def test_sampler_hooks_change_the_trajectory_as_specified():
+    """score_corrector / quantize_x0 (plms.py:199-201, 218-219) in the oracle: an identity corrector and an identity quantizer
+    leave the trajectory unchanged, a grid quantizer puts every pred_x0 on the grid, the corrector sees S + 1 PLMS calls."""
+    cfg = dict(in_channels=4, out_channels=4, model_channels=32, attention_resolutions=[1], num_res_blocks=1, channel_mult=[1],
+               num_head_channels=32, num_heads=-1, use_spatial_transformer=True, use_linear_in_transformer=True,
+               transformer_depth=1, context_dim=32, legacy=False)
+    model = ldm.ModelOracle(ldm.UNetOracle(cfg, ldm.init_params(cfg, seed=4)))
+    rng = np.random.RandomState(0)
+    x_T, c = rng.randn(1, 4, 8, 8).astype(np.float32), rng.randn(1, 3, 32).astype(np.float32)
+    base, _ = ldm.sample(model, 4, 1, (4, 8, 8), c, x_T, "plms")
+
+    class Ident:
+        n = 0
+
+        def modify_score(self, model, e_t, x, t, c, **kw):
+            Ident.n += 1
+            return e_t * kw.get("gain", 1.0)
+
+        def quantize(self, z):
+            return z, None, None
+    model.first_stage_model = Ident()
+    same, _ = ldm.sample(model, 4, 1, (4, 8, 8), c, x_T, "plms", score_corrector=Ident(), quantize_x0=True)
+    assert torch.equal(same, base) and Ident.n == 5
+    diff, _ = ldm.sample(model, 4, 1, (4, 8, 8), c, x_T, "plms", score_corrector=Ident(), corrector_kwargs=dict(gain=0.5))
+    assert not torch.equal(diff, base)
+
+    class Grid:
+        def quantize(self, z):
+            return (z * 2).round() / 2, None, None
+    model.first_stage_model = Grid()
+    _, inter = ldm.sample(model, 4, 1, (4, 8, 8), c, x_T, "ddim", quantize_x0=True, log_every_t=1)
+    for p0 in inter["pred_x0"][1:]:
+        assert float((p0 * 2 - (p0 * 2).round()).abs().max()) == 0.0

@@ -60,6 +60,54 @@ def test_tiny_unet_forward(graph):
         assert torch.equal(got, got2)
 
 
+VARIANTS = {
+    # the UNetModel constructor switches outside the shipped YAMLs (openaimodel.py:283-531), each against the oracle
+    "depth2": dict(transformer_depth=2),
+    "scale_shift": dict(use_scale_shift_norm=True),
+    "updown": dict(resblock_updown=True),
+    "updown_scale_shift_depth2": dict(resblock_updown=True, use_scale_shift_norm=True, transformer_depth=2),
+    "pool_resample": dict(conv_resample=False),
+    "class_cond": dict(num_classes=10),
+    "codebook_ids": dict(n_embed=24),
+    "wukong_style_depth2": None,
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+@pytest.mark.parametrize("graph", [False, True])
+def test_unet_constructor_variants(name, graph):
+    from minddiffusion_amd.configs import SMALL_WUKONG_UNET
+    from minddiffusion_amd._lib import MdxError
+    if name == "wukong_style_depth2":      # conv proj_in / proj_out, 8 heads (head dims 40 / 80: no LayerNorm fold), depth 2
+        cfg = dict(SMALL_WUKONG_UNET, transformer_depth=2)
+    else:
+        cfg = dict(_tiny_cfg(), **VARIANTS[name])
+    ocfg = _oracle_cfg(cfg)
+    params = O.init_params(ocfg, seed=11)
+    net = _build(cfg, params, graph)
+    oracle = O.UNetOracle(ocfg, params)
+    for (B, H, W, T) in ((2, 8, 8, 5), (1, 16, 16, 77)):
+        x, ctx = _inputs(B, H, W, T, cfg["context_dim"], seed=B + H)
+        ts = np.linspace(7.0, 940.0, B).astype(np.float32)
+        kw = {}
+        if cfg.get("num_classes"):
+            kw["y"] = [(3 * b + 1) % cfg["num_classes"] for b in range(B)]
+        ref = oracle(x, torch.tensor(ts), ctx, **kw)
+        dkw = {k: torch.tensor(v, device=DEV) for k, v in kw.items()}
+        got = net(torch.tensor(x, device=DEV), torch.tensor(ts, device=DEV), torch.tensor(ctx, device=DEV), **dkw)
+        assert tuple(got.shape) == tuple(ref.shape)
+        check(f"tiny_unet_variant_{name}_graph{int(graph)}_B{B}_{H}x{W}", got, ref, rel_l2=5e-3, max_abs=5e-2)
+    if cfg.get("num_classes"):
+        x, ctx = _inputs(2, 8, 8, 5, cfg["context_dim"])
+        args = (torch.tensor(x, device=DEV), torch.tensor([1.0, 2.0], device=DEV), torch.tensor(ctx, device=DEV))
+        with pytest.raises(MdxError, match="class-conditional"):
+            net(*args)
+        with pytest.raises(MdxError, match="outside"):
+            net(*args, y=torch.tensor([0, 10]))
+        with pytest.raises(MdxError, match="timestep-only"):
+            net.time_embedding_table([1.0])
+
+
 def test_zero_init_unet_is_exactly_zero():
     """Structural KAT: the reference constructor zero-inits out convs / proj_out (zero_module) => output == 0."""
     cfg = _tiny_cfg()
@@ -429,5 +477,72 @@ def test_sampler_options_vs_oracle(mode):
                                             unconditional_conditioning=dev(uc), noise_dropout=0.3, step_noises=noises, **common)
         assert torch.isfinite(free).all() and not torch.equal(free, got)
     check(f"tiny_sampler_option_{mode}", got, ref, rel_l2=1e-2, max_rel=1e-2)
-    with pytest.raises(NotImplementedError):
-        PLMSSampler(model).sample(4, B, (4, H, W), conditioning=dev(c), x_T=dev(x_T), verbose=False, quantize_x0=True)
+
+
+class _Corrector:
+    """A score corrector in the reference's calling convention (plms.py:201): works on whatever tensor library it is handed."""
+
+    def __init__(self):
+        self.calls = []
+
+    def modify_score(self, model, e_t, x, t, c, gain=1.0):
+        self.calls.append((tuple(e_t.shape), [int(v) for v in t]))
+        return gain * e_t + 0.05 * x
+
+
+class _SoftQuantizer:
+    """Stands in for a VQ first stage in the (z_q, loss, info) calling convention.  A real codebook lookup (or any hard
+    clipping) is not a parity-testable map: on this random-weight UNet the oracle's own fp32 and fp16-emulated runs end 3-12 %
+    apart with `clamp` as the quantizer, because pred_x0 = (x - s e) / sqrt(a_t) divides fp16-level differences in e by
+    sqrt(a_t) ~ 0.07 at the high-noise steps and the clipped trajectory leaves the region where the sampler contracts.  A smooth
+    contraction (z - 0.3 tanh z: moves the samples by ~19 % rel-L2, oracle fp32-vs-fp16 distance 2e-3) exercises the same code."""
+
+    def quantize(self, z):
+        return z - 0.3 * torch.tanh(z), None, (None, None, None)
+
+
+@pytest.mark.parametrize("which", ["plms_corrector", "ddim_corrector_quantize", "plms_quantize"])
+def test_sampler_hooks_vs_oracle(which):
+    """score_corrector / corrector_kwargs and quantize_x0 (plms.py:199-201, 218-219): caller-supplied objects inside the step."""
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from minddiffusion_amd.ldm.models.diffusion.plms import PLMSSampler
+    from minddiffusion_amd.ldm.models.diffusion.ddim import DDIMSampler
+    from minddiffusion_amd._lib import MdxError
+    cfg = _tiny_cfg()
+    params = O.init_params(_oracle_cfg(cfg), seed=21)
+    net = _build(cfg, params, True)
+    model = LatentDiffusion(net, linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    omodel = O.ModelOracle(O.UNetOracle(_oracle_cfg(cfg), params))
+    B, H, W, T, S = 2, 8, 8, 6, 5
+    rng = np.random.RandomState(5)
+    x_T = rng.randn(B, 4, H, W).astype(np.float32)
+    c = rng.randn(B, T, cfg["context_dim"]).astype(np.float32)
+    uc = np.repeat(rng.randn(1, T, cfg["context_dim"]).astype(np.float32), B, 0)
+    dev = lambda a: torch.tensor(a, device=DEV)
+    kind = "plms" if which.startswith("plms") else "ddim"
+    Sampler = PLMSSampler if kind == "plms" else DDIMSampler
+    kw, okw = dict(unconditional_guidance_scale=4.0), {}
+    cor_ref, cor_got = _Corrector(), _Corrector()
+    if "corrector" in which:
+        kw.update(corrector_kwargs=dict(gain=0.9))
+        okw.update(score_corrector=cor_ref)
+    quant = "quantize" in which
+    if quant:
+        with pytest.raises(MdxError, match="quantize"):        # no first stage with .quantize attached
+            Sampler(model).sample(S, B, (4, H, W), conditioning=dev(c), x_T=dev(x_T), verbose=False, quantize_x0=True)
+        model.first_stage_model = omodel.first_stage_model = _SoftQuantizer()
+    ref, ri = O.sample(omodel, S, B, (4, H, W), c, x_T, kind, unconditional_conditioning=uc, quantize_x0=quant,
+                       log_every_t=1, **okw, **kw)
+    got, gi = Sampler(model).sample(S, B, (4, H, W), conditioning=dev(c), x_T=dev(x_T), verbose=False, log_every_t=1,
+                                    unconditional_conditioning=dev(uc), quantize_x0=quant,
+                                    score_corrector=cor_got if "corrector" in which else None, **kw)
+    if "corrector" in which:       # same number of calls (PLMS: S + 1), on the same timesteps, on the un-doubled batch
+        assert cor_got.calls == cor_ref.calls and len(cor_got.calls) == S + (kind == "plms")
+    if quant:
+        assert len(gi["pred_x0"]) == len(ri["pred_x0"]) == S + 1
+        plain, _ = Sampler(model).sample(S, B, (4, H, W), conditioning=dev(c), x_T=dev(x_T), verbose=False,
+                                         unconditional_conditioning=dev(uc),
+                                         score_corrector=_Corrector() if "corrector" in which else None, **kw)
+        assert float((plain - got).norm() / plain.norm()) > 0.05       # the quantizer was in the loop
+        check(f"tiny_sampler_hook_{which}_pred_x0", gi["pred_x0"][-1], ri["pred_x0"][-1], rel_l2=1e-2, max_rel=1e-2)
+    check(f"tiny_sampler_hook_{which}", got, ref, rel_l2=1e-2, max_rel=1e-2)

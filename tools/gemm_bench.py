@@ -36,6 +36,8 @@ SHAPES_B1ROW = [
     ("proj8_1280", 64, 1, 1280, 1280, 1, 0),
     ("ff2_32_2560_640", 1024, 1, 2560, 640, 1, 0),
     ("qk16_1280_2560", 256, 1, 1280, 2560, 1, 0),
+    ("out64_320", 4096, 1, 320, 320, 1, 0),
+    ("kv64_ctx1024_320", 77, 1, 1024, 320, 1, 0),
 ]
 
 
