@@ -107,7 +107,14 @@ typedef struct mdx_gemm_desc {
     int epilogue;         /* MDX_EPI_* */
     int out_mode;         /* MDX_OUT_* */
     int splitk;           /* 0 = auto, >=1 = number of K splits */
-    void* workspace;      /* fp32 split-K slabs (may be NULL when splitk <= 1) */
+    void* workspace;      /* split-K workspace, 16-byte aligned (may be NULL when splitk <= 1).  Row-major launches reduce IN the
+                             kernel: every (tile, split) block parks its fp32 partial in the workspace and takes a ticket on
+                             the tile's arrival counter; the block that completes a tile sums the partials in split order and
+                             runs the epilogue (no reduce launch).  The counters are the first MDX_GEMM_WS_HEAD bytes of the
+                             workspace: they must be ZERO when the workspace is first handed to the library (every launch
+                             leaves them zero again) and nothing else may write them; a workspace may be shared by
+                             launches on ONE stream.  Transposed-output split launches use [split][M][N] slabs + a reduce
+                             launch as before (no counters). */
     size_t workspace_bytes;
     long out_bs;          /* row-major only: element stride between samples (0 = dense); lets a projection write
                              into a token sub-range of a larger [B][tokens][C] buffer (GLIDE text|image keys) */
@@ -132,8 +139,8 @@ typedef struct mdx_gemm_desc {
     /* GroupNorm statistics from the producer (openaimodel.py:136,159: every GroupNorm input is a conv / Dense output): when
      * set, the launch also writes, for every ROW BLOCK of its output and every output column n,
      *   colstats_out[(row_block * N + n) * 2 + {0,1}] = {sum, sum of squares} of the fp16 values stored in that column,
-     * rows per block = the M tile (a HALO conv tile = one 8x16 pixel patch) for a single-pass launch, 64 for a split-K launch
-     * (its fused reduce kernel); mdx_gemm_query reports the number.  Per COLUMN, so that any consumer grouping -- channel
+     * rows per block = the M tile (a HALO conv tile = one 8x16 pixel patch), 64 for a split-K launch that still uses the
+     * separate reduce kernel; mdx_gemm_query reports the number.  Per COLUMN, so that any consumer grouping -- channel
      * concats, groups that are not aligned to the store granule -- can fold them (mdx_groupnorm_colstats_f16).  Plain row-major
      * launches only (no GEGLU / transposed / n_split / LayerNorm fold / out_bs); tokens per sample % rows per block == 0. */
     float* colstats_out;
@@ -146,6 +153,7 @@ typedef struct mdx_gemm_desc {
     int tile_n;           /* 0 = auto; 64 | 128 forces the N tile (same purpose; GEGLU always uses 128) */
 } mdx_gemm_desc;
 
+#define MDX_GEMM_WS_HEAD 16384 /* bytes of arrival counters at the head of mdx_gemm_desc.workspace (zero on first use) */
 #define MDX_EPI_NONE 0
 #define MDX_EPI_GEGLU 1 /* out[m][j] = a * gelu_tanh(g); packed so that each 128-wide N tile = 64 'a' | 64 'gate' cols
                            (attention.py:41-51) */
@@ -160,10 +168,11 @@ size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d);
 /* Host-only validation of a descriptor (no launch): MDX_OK or MDX_E_INVALID with mdx_last_error() set. */
 int mdx_gemm_check(const mdx_gemm_desc* d);
 /* What mdx_gemm_f16 WOULD launch for this descriptor (host only, nothing is launched):
- * out6 = {tile_m, tile_n, splitk, kernel (0 = generic implicit GEMM, 1 = HALO 3x3 conv), 1 if the choice came from the
+ * out7 = {tile_m, tile_n, splitk, kernel (0 = generic implicit GEMM, 1 = HALO 3x3 conv), 1 if the choice came from the
  * measured tile table csrc/gemm_tuned.inc, rows per colstats_out row block (0 = this launch cannot produce column
- * statistics)}.  The parity tests assert with it that the table rows are hit at the benchmarked shapes. */
-int mdx_gemm_query(const mdx_gemm_desc* d, int* out6);
+ * statistics), 1 if a split launch reduces in the kernel (no reduce launch follows)}.  The parity tests assert with it that
+ * the table rows are hit at the benchmarked shapes. */
+int mdx_gemm_query(const mdx_gemm_desc* d, int* out7);
 
 /* GroupNorm fused with the split-K reduce of its producer (the small tensors of the deep UNet levels, where one block
  * normalises a whole (sample, column block) and the conv in front of it is always split): `prod` is the descriptor of a conv /

@@ -40,6 +40,7 @@ struct GemmParams {
     f16* out;
     f16* out2;       // transposed destination of the columns n >= n_split (0 = none): q|k row-major + V^T in ONE launch
     float* ws;
+    unsigned* tickets;       // in-kernel split-K reduce: one arrival counter per output tile (head of the workspace), else null
     int c1, c2, cin;
     int rowbias_ld, residual_ld, out_ld, out2_ld, n_split;
     // LayerNorm folded into the GEMMs around it (mdx.h): the PRODUCER of the token stream writes per-row {sum, sumsq}
@@ -166,12 +167,102 @@ __device__ __forceinline__ void gemm_bias_prefetch(const GemmParams& p, const in
     }
 }
 
+// In-kernel split-K reduce ("last block in finishes the tile").  Every (tile, split) block parks its fp32 accumulators in
+// the workspace IN REGISTER LAYOUT -- [tile][split][register quad][thread] 16-byte pieces, so that the stores and the later
+// loads are 1 KiB-per-wave contiguous -- then takes a ticket on the tile's arrival counter.  The block that draws the last
+// ticket sums all nsplit partials in split order (its own included: the order, and so the fp32 result, does not depend on who
+// arrives last) back into its accumulator registers and falls through to the ordinary epilogue: every epilogue feature
+// (GEGLU, LayerNorm fold, row / column statistics, q|k|v split stores) works unchanged for split launches, and there is no
+// reduce launch.  Hand-off (cdna_hip_programming.md, "In-launch split-K reduction" / Guideline 16, the sc1 form -- a
+// __threadfence() per block measured +47 us on a 400-block launch here): partials are stored WRITE-THROUGH at agent scope
+// (buffer_store ... sc1), every wave drains its stores (s_waitcnt vmcnt(0)), block barrier, ONE lane takes the ticket with a
+// relaxed agent-scope atomic; the last arriver reads the partials with agent-scope (sc1) loads, which cannot hit a stale
+// line of its CU's L1 or its XCD's L2.  No placement assumption: a tile's splits may run on any CUs of any XCDs.
+// The counter is reset by the last arriver, so the ticket area only has to be zero before the FIRST launch on a workspace.
+constexpr int MDX_TICKET_SLOTS = MDX_GEMM_WS_HEAD / 4;      // tiles per launch that can take tickets
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, int NW>
+__device__ __forceinline__ bool splitk_last_block_reduce(const GemmParams& p, f32x16 (&acc)[BM / (16 * NW)][BN / 64], char* smem,
+                                                         const int tile_lin, const int split) {
+    constexpr int NT = NW * 64;
+    constexpr int TM = BM / (16 * NW);
+    constexpr int TN = BN / 64;
+    constexpr int Q = TM * TN * 4;                       // 16-byte pieces per thread per partial
+    constexpr int U = (32 / Q) < 1 ? 1 : (32 / Q);       // partials whose loads are in flight together (<= 128 VGPRs)
+    constexpr unsigned PART = (unsigned)Q * NT * 16u;    // bytes per partial
+    const int tid = threadIdx.x;
+    char* base = reinterpret_cast<char*>(p.ws + MDX_TICKET_SLOTS) + (size_t)tile_lin * p.nsplit * PART;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, (unsigned)p.nsplit * PART);
+    const unsigned toff = (unsigned)tid * 16u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+                v[0] = acc[i][j][4 * g]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                       (unsigned)split * PART + (unsigned)((i * TN + j) * 4 + g) * (NT * 16u) + toff,
+                                                       0, /*sc1*/ 16);
+            }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave: its write-through stores are complete
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.tickets + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old >= (unsigned)p.nsplit) __builtin_trap();     // the caller did not zero the head of the workspace (mdx.h)
+        *flag = old == (unsigned)p.nsplit - 1u;
+    }
+    __syncthreads();
+    const bool last = *flag != 0;
+    __syncthreads();                                     // the epilogue reuses smem
+    if (!last) return false;
+    if (tid == 0) __hip_atomic_store(p.tickets + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto add = [&](const u32x4 (&v)[Q]) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const f32x4 f = __builtin_bit_cast(f32x4, v[q]);
+            f32x16& a = acc[q / (TN * 4)][(q / 4) % TN];
+            const int g = q & 3;
+            a[4 * g] += f[0]; a[4 * g + 1] += f[1]; a[4 * g + 2] += f[2]; a[4 * g + 3] += f[3];
+        }
+    };
+    // U partials' loads in flight per step; added strictly in split order
+    int z = 0;
+    for (; z + U <= p.nsplit; z += U) {
+        u32x4 v[U][Q];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                v[u][q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(z + u) * PART + (unsigned)q * (NT * 16u) + toff, 0, 16);
+#pragma unroll
+        for (int u = 0; u < U; ++u) add(v[u]);
+    }
+    for (; z < p.nsplit; ++z) {
+        u32x4 v[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)z * PART + (unsigned)q * (NT * 16u) + toff, 0, 16);
+        add(v);
+    }
+    return true;
+}
+
 // Fused epilogue shared by the GEMM kernels.  SWAP: accumulators hold C^T (col = lane&31 -> m), staged through LDS
 // and stored row-major with bias / rowbias / residual / GEGLU / GELU; !SWAP: split-K partial slab or transposed store.
 template <int BM, int BN, bool SWAP, int NW, class RowMap>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / (16 * NW)][BN / 64], char* smem,
                                               const RowMap rm, const int n0, const int split, const float (&bpre)[16],
-                                              const int row_block = 0) {
+                                              const int row_block = 0, const int tile_lin = 0) {
     constexpr int NT = NW * 64;           // threads per block
     constexpr int WROWS = BM / (NW / 2);  // rows of the block tile owned by one wave row (waves are (NW/2) x 2)
     constexpr int TM = WROWS / 32;
@@ -239,6 +330,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         // row-major store: C^T layout (col = lane&31 -> m, 4 consecutive n per register group)
         constexpr int SLD = BN + 8;
         f16* stg = reinterpret_cast<f16*>(smem);
+        if (p.tickets) {      // split-K: only the block that completes the tile goes on (block-uniform)
+            if (!splitk_last_block_reduce<BM, BN, NW>(p, acc, smem, tile_lin, split)) return;
+        }
         if (p.ln_stats) {
             // LayerNorm fold: acc holds raw_tokens x (gamma (.) W)^T.  Per row mean / rstd from the producer's partials and
             // S[n] of this tile go through LDS (behind the staging area), then every accumulator becomes
@@ -689,7 +783,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
 
     __syncthreads();  // all waves done with the ring before the epilogue reuses it
     trace_mark(p, 3);
-    gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{m0}, n0, split, bpre, tile_m);
+    gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{m0}, n0, split, bpre, tile_m, tile_id);
     trace_mark(p, 4);
 }
 
@@ -907,9 +1001,10 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     __syncthreads();
     trace_mark(p, 3);
     if constexpr (PW == 16)
-        gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split, bpre, tile_m);
+        gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split, bpre, tile_m,
+                                        tile_id);
     else   // two whole 64-pixel samples: tile rows are consecutive output rows
-        gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{tile_m * BM}, n0, split, bpre, tile_m);
+        gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{tile_m * BM}, n0, split, bpre, tile_m, tile_id);
     trace_mark(p, 4);
 }
 
@@ -1433,12 +1528,39 @@ extern "C" int mdx_probe_gemm_trace(void* buf, size_t bytes) {
     return MDX_OK;
 }
 
+// Split-K launches of at most MDX_GEMM_SPLITK_FIXUP_MAX (default 4) splits reduce in the kernel (splitk_last_block_reduce)
+// when the output is row-major and the tiles fit the ticket area.  The last arriver reads nsplit partials serially at the
+// ~65 GB/s one block can pull, so the in-kernel form only beats the reduce launch it replaces for few splits (measured at UNet
+// batch 2, profiles/r02_l_splitk_fixup.txt: 4 splits -1.7 us, 3 splits -1.4 us, 5 splits 0 ... +1.7 us, 10 splits +7 us,
+// 20 splits +8 us per launch); deeper splits, transposed outputs and deferred reduces keep the [split][M][N] slabs + reduce kernel.
+static bool fixup_eligible(const mdx_gemm_desc* d, const GemmParams& p, int bm, int bn, int ns) {
+    static const int max_ns = getenv("MDX_GEMM_SPLITK_FIXUP_MAX") ? atoi(getenv("MDX_GEMM_SPLITK_FIXUP_MAX")) : 4;
+    if (ns > max_ns) return false;
+    if (p.out_mode != MDX_OUT_ROWMAJOR || d->defer_reduce) return false;
+    const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+    return tiles <= MDX_TICKET_SLOTS;
+}
+
+// bytes of workspace one split of this launch occupies (+ `head` bytes once)
+static size_t split_bytes(const mdx_gemm_desc* d, const GemmParams& p, int bm, int bn, int ns, size_t* head) {
+    if (fixup_eligible(d, p, bm, bn, ns)) {
+        *head = (size_t)MDX_TICKET_SLOTS * sizeof(unsigned);
+        return (size_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * bm * bn * sizeof(float);
+    }
+    *head = (size_t)MDX_TICKET_SLOTS * sizeof(unsigned);     // never used for slabs: other launches keep their tickets there
+    return (size_t)p.M * p.N * sizeof(float);
+}
+
 extern "C" size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d) {
     GemmParams p{};
     if (fill_params(d, p) != MDX_OK) return 0;
     const GemmCfg c = pick_cfg(p);
-    const int ns = choose_tiling(p, c.bn, d->splitk, d->tile_m).ns;
-    return ns > 1 ? (size_t)ns * p.M * p.N * sizeof(float) : 0;
+    const Tiling tl = choose_tiling(p, c.bn, d->splitk, d->tile_m);
+    if (tl.ns <= 1) return 0;
+    size_t head;
+    // (a launch clamped to fewer splits by a small workspace may switch to the in-kernel form: cover both layouts)
+    const size_t per = std::max(split_bytes(d, p, tl.bm, c.bn, tl.ns, &head), split_bytes(d, p, tl.bm, c.bn, 1 << 30, &head));
+    return head + (size_t)tl.ns * per;
 }
 
 extern "C" int mdx_gemm_check(const mdx_gemm_desc* d) {
@@ -1455,6 +1577,7 @@ struct Resolved {
     GemmCfg c;
     int bn, ns;
     bool halo, tuned;
+    bool fixup;      // split-K reduced by the last block of each tile (no reduce launch)
 };
 
 static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
@@ -1469,13 +1592,15 @@ static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
     if (ns > p.ktiles) ns = p.ktiles;
     if (ns > 1) {
         // shrink to what the caller's workspace can hold
-        const size_t slab = (size_t)p.M * p.N * sizeof(float);
-        const size_t cap = d->workspace ? d->workspace_bytes / slab : 0;
+        size_t head;
+        // sized for the tile-padded partials of the in-kernel form, which are never smaller than the [M][N] slabs
+        const size_t slab = std::max(split_bytes(d, p, tl.bm, bn, ns, &head), split_bytes(d, p, tl.bm, bn, 1 << 30, &head));
+        const size_t cap = (d->workspace && d->workspace_bytes > head) ? (d->workspace_bytes - head) / slab : 0;
         if ((size_t)ns > cap) ns = (int)cap;
         if (ns < 1) ns = 1;
         if (d->splitk > 1 && ns != d->splitk) {
             mdx_set_error("mdx_gemm_f16: workspace too small for splitk=%d (need %zu bytes)", d->splitk,
-                          (size_t)d->splitk * slab);
+                          head + (size_t)d->splitk * slab);
             return MDX_E_WORKSPACE;
         }
     }
@@ -1492,6 +1617,9 @@ static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
     }
     p.nsplit = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;  // no empty splits
     r.ns = p.nsplit;
+    r.fixup = r.ns > 1 && fixup_eligible(d, p, r.c.bm, bn, r.ns);
+    p.tickets = r.fixup ? reinterpret_cast<unsigned*>(p.ws) : nullptr;
+    if (r.ns > 1 && !r.fixup) p.ws += MDX_TICKET_SLOTS;     // [split][M][N] slabs of the reduce-kernel path start behind the head
     return MDX_OK;
 }
 
@@ -1500,12 +1628,12 @@ static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
 static int colstats_rows(const GemmParams& p, const Resolved& r) {
     if (p.out_mode != MDX_OUT_ROWMAJOR || p.epilogue != MDX_EPI_NONE || p.n_split || p.ln_stats || p.stats_out || p.out_bs)
         return 0;
-    if (r.ns > 1) return p.HoWo % CS_ROWS == 0 ? CS_ROWS : 0;
+    if (r.ns > 1 && !r.fixup) return p.HoWo % CS_ROWS == 0 ? CS_ROWS : 0;
     if (r.halo) return halo8_eligible(p) && r.c.bm == 128 ? 0 : r.c.bm;
     return p.HoWo % r.c.bm == 0 ? r.c.bm : 0;
 }
 
-// What mdx_gemm_f16 would launch for this descriptor (no launch): out6 = {tile_m, tile_n, splitk, kernel (0 generic implicit
+// What mdx_gemm_f16 would launch for this descriptor (no launch): out7 = {tile_m, tile_n, splitk, kernel (0 generic implicit
 // GEMM, 1 HALO conv), from_tuned_table, colstats rows per block}.  Parity tests use it to assert that the measured tile table
 // (gemm_tuned.inc) is actually hit at the benchmarked shapes; the UNet plan asks it where GroupNorm statistics can come from.
 extern "C" int mdx_gemm_query(const mdx_gemm_desc* d, int* out5) {
@@ -1522,6 +1650,7 @@ extern "C" int mdx_gemm_query(const mdx_gemm_desc* d, int* out5) {
     out5[3] = r.halo ? 1 : 0;
     out5[4] = r.tuned ? 1 : 0;
     out5[5] = colstats_rows(p, r);
+    out5[6] = r.fixup ? 1 : 0;
     return MDX_OK;
 }
 
@@ -1571,6 +1700,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
                     (p.M + rows - 1) / rows, rows);
     }
     MDX_REQUIRE(!d->defer_reduce || ns > 1, "mdx_gemm_f16: defer_reduce set but the launch does not split K");
+    MDX_REQUIRE(!rs.fixup || ((uintptr_t)p.ws % 16 == 0), "mdx_gemm_f16: workspace must be 16-byte aligned");
     p.tiles_m = (p.M + c.bm - 1) / c.bm;
     p.tiles_n = (p.N + bn - 1) / bn;
     const bool fastk = (p.cin % 64 == 0) && (p.c2 == 0 || p.c1 % 64 == 0);
@@ -1590,7 +1720,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         // on the split-K'd small-M layers); otherwise 2 stages keep 2-3 blocks resident per CU.
         cc.ns = (ntiles * ns <= 256) ? 3 : 2;
     }
-    const bool swap = (ns == 1) && (p.out_mode == MDX_OUT_ROWMAJOR);
+    const bool swap = (ns == 1 || rs.fixup) && (p.out_mode == MDX_OUT_ROWMAJOR);
     bool ok;
     if (halo) {
         // 128-pixel patches: the 2-stage weight ring keeps two blocks per CU (measured better than 3 stages at every
@@ -1612,7 +1742,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         ok = (bn == 128) ? launch_bn<128, 128>(cc, p, swap, fastk, grid, st) : launch_bn<128, 64>(cc, p, swap, fastk, grid, st);
     MDX_REQUIRE(ok, "mdx_gemm_f16: unsupported tile configuration bk=%d ns=%d", c.bk, c.ns);
     MDX_LAUNCH_CHECK("mdx_gemm_f16");
-    if (ns > 1 && !d->defer_reduce) {
+    if (ns > 1 && !d->defer_reduce && !rs.fixup) {
         const int ncols = p.epilogue == MDX_EPI_GEGLU ? p.N / 2 : p.N;
         const size_t total = (size_t)p.M * (ncols / 8);
         int blocks = (int)((total + 255) / 256);

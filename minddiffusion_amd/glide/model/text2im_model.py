@@ -308,9 +308,8 @@ class Text2ImUNet:
             pad = 1 if ks == 3 else 0
             m_rows = kw["B"] * ((hs_ + 2 * pad - ks) // st + 1) * ((ws2 + 2 * pad - ks) // st + 1)
             kdim = ks * ks * (kw["c1"] + kw.get("c2", 0))
-            wsb = ops.gemm_workspace_bytes(d)
-            emit(lambda d=d: ops.gemm_run(d), "gemm", 2 * m_rows * kw["N"] * kdim, 2 if wsb else 1,
-                 f"M={m_rows} N={kw['N']} K={kdim} k{ks}")
+            emit(lambda d=d: ops.gemm_run(d), "gemm", 2 * m_rows * kw["N"] * kdim, 1, f"M={m_rows} N={kw['N']} K={kdim} k{ks}")
+            meta[-1]["desc"] = d            # launches / split are filled in by ops.account_gemm_launches below
 
         def gn(x1, x2, g, b, silu, out, scale=None, shift=None):
             Bq, HW, C1 = x1.shape
@@ -506,7 +505,7 @@ class Text2ImUNet:
              bias=w["out2.b"], ksize=3)
 
         need = max([ops.gemm_workspace_bytes(d) for d in descs] + [16])
-        P.gemm_ws = torch.empty(need // 4, dtype=f32, device=dev)
+        P.gemm_ws = ops.new_gemm_workspace(need, dev)
         for d in descs:
             d.workspace = P.gemm_ws.data_ptr()
             d.workspace_bytes = P.gemm_ws.numel() * 4
@@ -515,6 +514,7 @@ class Text2ImUNet:
         import os
         ops.wire_groupnorm_colstats(gn_calls if os.environ.get("MDX_UNET_GN_COLSTATS", "1") != "0" else [], meta, B, dev,
                                     P.colstats)
+        ops.account_gemm_launches(meta)
         P.main, P.meta, P.descs, P.arena = main, meta, descs, A
         P.keep = (t_emb, cat_in, emb, xf_out)
         P.graph, P.graph_failed = None, False

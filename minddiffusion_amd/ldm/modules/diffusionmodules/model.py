@@ -137,7 +137,7 @@ class _PlanBuilder:
     def finish(self):
         P = self.P
         need = max([ops.gemm_workspace_bytes(d) for d in self.descs] + [16])
-        P.gemm_ws = torch.empty(need // 4, dtype=f32, device=self.dev)
+        P.gemm_ws = ops.new_gemm_workspace(need, self.dev)
         for d in self.descs:
             d.workspace, d.workspace_bytes = P.gemm_ws.data_ptr(), P.gemm_ws.numel() * 4
         P.gn_ws = torch.empty(self.gn_need, dtype=f32, device=self.dev)

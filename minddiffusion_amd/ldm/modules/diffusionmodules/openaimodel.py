@@ -429,9 +429,8 @@ class UNetModel:
                 pad = 1 if ks == 3 else 0
                 m_rows = kw["B"] * ((hs_ + 2 * pad - ks) // st + 1) * ((ws2 + 2 * pad - ks) // st + 1)
                 kdim = ks * ks * (kw["c1"] + kw.get("c2", 0))
-                wsb = ops.gemm_workspace_bytes(d)
-                emit(fn, "gemm", 2 * m_rows * kw["N"] * kdim, 2 if wsb else 1,
-                     f"M={m_rows} N={kw['N']} K={kdim} k{ks}s{st}u{up} split={wsb // max(1, m_rows * kw['N'] * 4)}")
+                emit(fn, "gemm", 2 * m_rows * kw["N"] * kdim, 1, f"M={m_rows} N={kw['N']} K={kdim} k{ks}s{st}u{up}")
+                meta[-1]["desc"] = d        # launches / split are filled in by ops.account_gemm_launches below
             else:
                 oplist.append(fn)
 
@@ -710,7 +709,7 @@ class UNetModel:
 
         # shared workspaces (sized for the hungriest op), patched into every descriptor
         need = max([ops.gemm_workspace_bytes(d) for d in descs] + [0])
-        P.gemm_ws = torch.empty(max(need, 16) // 4, dtype=f32, device=dev)
+        P.gemm_ws = ops.new_gemm_workspace(need, dev)
         for d in descs:
             d.workspace = P.gemm_ws.data_ptr()
             d.workspace_bytes = P.gemm_ws.numel() * 4
@@ -747,6 +746,7 @@ class UNetModel:
                 L = cpg // math.gcd(cpg, 8)
                 if L <= 64 and HW * L * 16 <= (64 << 10):
                     meta[c["meta"]]["launches"] = 1
+        ops.account_gemm_launches(meta)     # last: the column-statistics wiring above can change a launch's table row
         P.main, P.ctxops, P.descs, P.meta = main, ctxops, descs, meta
         assert len(main) == len(meta)
         P.arena_bytes = A.total

@@ -141,7 +141,7 @@ class TextEncoder:
         # ln_final = nn.LayerNorm([width]): MindSpore's default epsilon is 1e-7 (:132)
         main.append(lambda: ops.layernorm(x.view(B * T, wd), w["lnf.g"], w["lnf.b"], 1e-7, out=P.out.view(B * T, wd)))
         need = max([ops.gemm_workspace_bytes(d) for d in descs] + [16])
-        P.gemm_ws = torch.empty(need // 4, dtype=f32, device=dev)
+        P.gemm_ws = ops.new_gemm_workspace(need, dev)
         for d in descs:
             d.workspace, d.workspace_bytes = P.gemm_ws.data_ptr(), P.gemm_ws.numel() * 4
         P.main, P.descs, P.arena = main, descs, A

@@ -262,12 +262,30 @@ def gemm_workspace_bytes(desc):
     return int(_lib.load().mdx_gemm_workspace_bytes(ctypes.byref(desc)))
 
 
+def new_gemm_workspace(nbytes, device):
+    """A split-K workspace for mdx_gemm_f16: fp32, ZERO-filled -- its first MDX_GEMM_WS_HEAD bytes are the tiles' arrival
+    counters of the in-kernel split-K reduce, which must start at zero (include/mdx.h, mdx_gemm_desc.workspace)."""
+    return torch.zeros(max(int(nbytes), 16) // 4 + 1, dtype=f32, device=device)
+
+
 def gemm_query(desc):
-    """(tile_m, tile_n, splitk, halo, from_tuned_table, colstats rows per block) mdx_gemm_f16 would use for this
-    descriptor (no launch)."""
-    out = (ctypes.c_int * 6)()
+    """(tile_m, tile_n, splitk, halo, from_tuned_table, colstats rows per block, in-kernel split-K reduce) mdx_gemm_f16
+    would use for this descriptor (no launch)."""
+    out = (ctypes.c_int * 7)()
     _lib.check(_lib.load().mdx_gemm_query(ctypes.byref(desc), out), "mdx_gemm_query")
     return tuple(int(v) for v in out)
+
+
+def account_gemm_launches(meta):
+    """Plan post-pass (after the shared workspace is patched into the descriptors): launches per GEMM op = the kernel
+    plus a split-K reduce launch unless the split is reduced in the kernel; the op's info string gets the real split."""
+    for m in meta:
+        d = m.get("desc")
+        if d is None:
+            continue
+        q = gemm_query(d)
+        m["launches"] = 2 if (q[2] > 1 and not q[6] and not d.defer_reduce) else 1
+        m["info"] = m["info"].split(" split=")[0] + f" split={q[2] if q[2] > 1 else 0}" + ("i" if q[6] else "")
 
 
 def gemm_run(desc):
@@ -299,7 +317,7 @@ def gemm(a, w, N, B, H, W, c1, out=None, **kw):
     if not d.workspace:
         need = gemm_workspace_bytes(d)
         if need:
-            ws = torch.empty(need // 4, dtype=f32, device=a.device)
+            ws = new_gemm_workspace(need, a.device)
             d.workspace = ws.data_ptr()
             d.workspace_bytes = need
     gemm_run(d)

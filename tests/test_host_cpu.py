@@ -383,8 +383,9 @@ def test_unet_plan_folds_layernorm_into_its_gemms(monkeypatch):
 
 
 def test_tuned_table_drives_the_split_choice():
-    """mdx_gemm_workspace_bytes (host only, no launch) must follow csrc/gemm_tuned.inc for the shapes it lists:
-    split-K slabs = splitk x M x N x 4 bytes (0 when the entry says one split)."""
+    """mdx_gemm_workspace_bytes (host only, no launch) must follow csrc/gemm_tuned.inc for the shapes it lists: 0 when the entry
+    says one split, else MDX_GEMM_WS_HEAD bytes of arrival counters + splitk partials of the tile-padded output (which cover the
+    [M][N] slabs of the reduce-kernel form as well)."""
     from minddiffusion_amd import _lib, ops
     lib = _lib.load()
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "minddiffusion_amd", "csrc",
@@ -400,7 +401,10 @@ def test_tuned_table_drives_the_split_choice():
         a = torch.zeros((1,), dtype=torch.float16)      # pointers are never dereferenced on this path
         d = ops.make_gemm_desc(a, a, N, 1, M, 1, K, a, N)
         need = lib.mdx_gemm_workspace_bytes(ctypes.byref(d))
-        assert need == (ns * M * N * 4 if ns > 1 else 0), (M, N, K, ns, need)
+        tm, tn = ops.gemm_query(d)[:2]
+        assert (bm in (0, tm)) and (bn in (0, tn))
+        padded = -(-M // tm) * tm * -(-N // tn) * tn
+        assert need == (16384 + ns * padded * 4 if ns > 1 else 0), (M, N, K, bm, bn, ns, need)
         checked += 1
         if checked >= 12:
             break

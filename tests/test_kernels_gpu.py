@@ -165,9 +165,10 @@ def test_gemm_splitk_workspace_reuse(ops):
     for (a, w, bv, M, N, K, sk, ref) in probs:
         out = torch.empty(M, N, dtype=torch.float16, device=DEV)
         d = ops.make_gemm_desc(a, w, N, M, 1, 1, K, out, N, bias=bv, splitk=sk)
-        need = max(need, sk * M * N * 4)
+        need = max(need, ops.gemm_workspace_bytes(d), sk * M * N * 4)
         descs.append((d, out))
     ws = torch.full((need // 4,), float("nan"), dtype=torch.float32, device=DEV)   # stale garbage must not leak
+    ws[:4096] = 0       # ... except the arrival counters (MDX_GEMM_WS_HEAD bytes), which the caller hands over zeroed
     for d, _ in descs:
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     first = None
@@ -341,7 +342,7 @@ def test_gemm_split_rowmajor_transposed_output(ops, B, T, C, splitk):
                            out2=vt, out2_ld=T, n_split=2 * C)
     keep = d.a, d.w, d.bias
     need = ops.gemm_workspace_bytes(d)
-    ws = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=DEV)
+    ws = ops.new_gemm_workspace(need, DEV)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     # keep the operand tensors alive across the launch
     a_d, w_d, b_d = dev16(a), pack_dense(w), dev32(bv)
@@ -377,7 +378,7 @@ def test_gemm_layernorm_fold(ops, M, C, kind, sp, sc):
 
     def run(desc, keep):
         need = ops.gemm_workspace_bytes(desc)
-        ws = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=DEV)
+        ws = ops.new_gemm_workspace(need, DEV)
         desc.workspace, desc.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         ops.gemm_run(desc)
         torch.cuda.synchronize()
@@ -600,7 +601,7 @@ def test_gemm_colstats_and_groupnorm_from_them(ops, B, H, W, Cin, Cout, ks, spli
     d = _ops.make_gemm_desc(a, wp, Cout, B, H, W, Cin, out, Cout, bias=biasd, ksize=ks, splitk=splitk, rowbias=embd,
                             rowbias_ld=Cout, residual=resd, residual_ld=Cout)
     need = _ops.gemm_workspace_bytes(d)
-    wsb = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=DEV)
+    wsb = _ops.new_gemm_workspace(need, DEV)
     d.workspace, d.workspace_bytes = wsb.data_ptr(), wsb.numel() * 4
     rows = _ops.gemm_query(d)[5]
     assert rows > 0 and (H * W) % rows == 0
@@ -659,7 +660,9 @@ def test_groupnorm_colstats_two_sources(ops):
 ])
 def test_groupnorm_fused_with_splitk_reduce(ops, B, H, W, Cin, Cout, ks, splitk, silu):
     """mdx_gemm_desc.defer_reduce + mdx_groupnorm_from_splitk_f16: the GroupNorm launch sums the producer's split-K slabs
-    itself -- the conv output it stores and the normalised tensor must be BIT-IDENTICAL to reduce-kernel-then-GroupNorm."""
+    itself.  The conv output it stores and the normalised tensor are compared with the ordinary launch (in-kernel split-K
+    reduce, whose epilogue rounds the accumulator to fp16 once before bias / residual are added): same sums in the same
+    order, at most one fp16 rounding apart."""
     from minddiffusion_amd import ops as _ops
     rng = np.random.RandomState(B + H + Cin + Cout)
     x = h16(rng.standard_normal((B, Cin, H, W)))
@@ -678,7 +681,7 @@ def test_groupnorm_fused_with_splitk_reduce(ops, B, H, W, Cin, Cout, ks, splitk,
     da, db = build(out_a), build(out_b)
     need = _ops.gemm_workspace_bytes(da)
     assert need > 0
-    ws = torch.empty(need // 4, dtype=torch.float32, device=DEV)
+    ws = _ops.new_gemm_workspace(need, DEV)
     for d in (da, db):
         d.workspace, d.workspace_bytes = ws.data_ptr(), need
     _ops.gemm_run(da)
@@ -689,8 +692,9 @@ def test_groupnorm_fused_with_splitk_reduce(ops, B, H, W, Cin, Cout, ks, splitk,
     assert float(out_b.abs().max()) == 0.0          # the deferred launch left the output to its consumer
     y_b = torch.empty_like(out_b)
     _ops.groupnorm_from_splitk(db, g, bt, 1e-5, silu, y_b)
-    assert torch.equal(out_a, out_b), "conv output written by the fused GroupNorm differs from the reduce kernel's"
-    assert torch.equal(y_a, y_b), "fused reduce + GroupNorm differs from reduce-then-GroupNorm"
+    ulp = 2.0 ** -10
+    assert float((out_a.float() - out_b.float()).abs().max()) <= 2 * ulp * float(out_a.float().abs().max())
+    assert float((y_a.float() - y_b.float()).abs().max()) <= 8 * ulp * max(1.0, float(y_a.float().abs().max()))
     xr = O.conv2d(torch.tensor(x), torch.tensor(w), bias.cpu(), padding=ks // 2) + emb.cpu()[:, :, None, None] \
         + torch.tensor(from_nhwc(res.float().cpu().numpy(), B, H, W))
     ref = O.group_norm(xr, g.cpu(), bt.cpu(), 1e-5)

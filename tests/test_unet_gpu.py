@@ -127,15 +127,18 @@ def test_context_cache_invalidation():
     xd, td = torch.tensor(x, device=DEV), torch.full((2,), 401.0, device=DEV)
     c1 = torch.tensor(ctx, device=DEV)
     a = net(xd, td, c1)
-    c2 = torch.tensor(ctx[:, ::-1].copy(), device=DEV)   # different tensor, different content
+    # different tensor, different content (a pure permutation of the tokens would not do: cross-attention is invariant to it,
+    # and the two outputs then differ by fp16 rounding noise at best)
+    ctx2 = (0.8 * ctx[:, ::-1] + 0.1).astype(np.float32)
+    c2 = torch.tensor(ctx2, device=DEV)
     b = net(xd, td, c2)
-    ref_b = oracle(x, torch.full((2,), 401.0), ctx[:, ::-1].copy())
+    ref_b = oracle(x, torch.full((2,), 401.0), ctx2)
     check("context_cache_second_context", b, ref_b, rel_l2=5e-3)
     c1.mul_(0.5)                                          # in-place update of the first tensor
     c = net(xd, td, c1)
     ref_c = oracle(x, torch.full((2,), 401.0), ctx * 0.5)
     check("context_cache_inplace_update", c, ref_c, rel_l2=5e-3)
-    assert float((a - b).abs().max()) > 0
+    assert float((a - b).abs().max()) > 1e-3
 
 
 @pytest.mark.parametrize("sampler,S,scale", [("plms", 5, 3.0), ("ddim", 5, 3.0), ("ddim", 4, 1.0), ("plms", 10, 7.5)])

@@ -71,7 +71,7 @@ def main():
                 descs = [ops.make_gemm_desc(a, w, cout, B, H, W, cin, out, ncols, bias=bias, ksize=ks, epilogue=epi,
                                             splitk=sk) for w in ws]
                 need = ops.gemm_workspace_bytes(descs[0])
-                wsp = torch.empty(max(need, 16) // 4, device=dev, dtype=torch.float32)
+                wsp = ops.new_gemm_workspace(need, dev)
                 for d in descs:
                     d.workspace = wsp.data_ptr()
                     d.workspace_bytes = wsp.numel() * 4

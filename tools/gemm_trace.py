@@ -32,7 +32,7 @@ def trace_one(ops, lib, name, B, H, W, cin, cout, ks, sk, reps=3, flush_caches=T
         w = ops.pack_gemm_weight(torch.randn(cout, K, device=dev, dtype=torch.float16) * (K ** -0.5))  # cold weights
         d = ops.make_gemm_desc(a, w, cout, B, H, W, cin, out, cout, bias=bias, ksize=ks, splitk=sk)
         need = ops.gemm_workspace_bytes(d)
-        wsp = torch.empty(max(need, 16) // 4, device=dev, dtype=torch.float32)
+        wsp = ops.new_gemm_workspace(need, dev)
         d.workspace, d.workspace_bytes = wsp.data_ptr(), wsp.numel() * 4
         flush = None
         if flush_caches:

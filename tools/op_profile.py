@@ -74,7 +74,7 @@ def main():
     if args.out:
         with open(args.out, "w") as f:
             json.dump({"B": B, "latent": h, "total_us": total,
-                       "ops": [dict(m, us=t) for t, m in zip(best, P.meta)]}, f)
+                       "ops": [dict({k: v for k, v in m.items() if k != "desc"}, us=t) for t, m in zip(best, P.meta)]}, f)
 
 
 if __name__ == "__main__":

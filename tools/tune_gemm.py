@@ -109,7 +109,7 @@ def main():
                     if key not in pres:
                         pres[key] = list(P.main[max(0, i - args.insitu):i])
                         shapes[key] = dd
-    big_ws = torch.empty((256 << 20) // 4, dtype=torch.float32, device=dev)
+    big_ws = ops.new_gemm_workspace(256 << 20, dev)
     lines, log = [], []
     for (M, N, K, ks, var), d0 in sorted(shapes.items()):
         if (args.only_m and M != args.only_m) or (args.only_ks and ks != args.only_ks):
