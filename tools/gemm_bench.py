@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--out", default=None)
     ap.add_argument("--splits", default="0", help="comma list of split-K values to sweep (0 = auto)")
+    ap.add_argument("--hot", action="store_true", help="ONE weight copy: the stream is served by the Infinity Cache, not HBM")
     args = ap.parse_args()
     from minddiffusion_amd import ops
     dev = torch.device("cuda:0")
@@ -60,7 +61,7 @@ def main():
             M = B * H * W
             a = torch.randn(B, H * W, cin, device=dev, dtype=torch.float16)
             wbytes = cout * K * 2
-            ncopy = max(1, min(16, (400 << 20) // wbytes + 1))
+            ncopy = 1 if args.hot else max(1, min(16, (400 << 20) // wbytes + 1))
             ws = [ops.pack_gemm_weight(torch.randn(cout, K, device=dev, dtype=torch.float16) * (K ** -0.5)) for _ in range(ncopy)]
             bias = torch.randn(cout, device=dev)
             ncols = cout // 2 if epi else cout
