@@ -52,6 +52,7 @@ struct GemmParams {
     const float* ln_s;       // consumer: S[n] = sum_k (gamma (.) W)[n][k], fp32 [N]
     int ln_nt;
     int bn_hint;             // mdx_gemm_desc.tile_n
+    int st_hint;             // mdx_gemm_desc.stages
     int spread;              // gemm_kernel: 1-D grid of (tile, split) items dealt round-robin to the XCDs
     float ln_eps;
     long out_bs;   // element stride between samples of a row-major output (0 = dense [M][out_ld])
@@ -1210,6 +1211,7 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     p.ln_nt = d->ln_nt;
     p.ln_eps = d->ln_eps;
     p.bn_hint = d->tile_n;
+    p.st_hint = d->stages;
     p.out2_ld = d->out2_ld;
     p.n_split = d->n_split;
     p.ws = (float*)d->workspace;
@@ -1296,10 +1298,11 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
 struct TunedEntry {
     int M, N, K, ksize, bm, bn, ns;   // bn 0 = pick_bn's default
     int var1;
+    int st;                           // LDS ring depth (0 = the occupancy rule in mdx_gemm_f16)
 };
 static const TunedEntry g_tuned[] = {
 #include "gemm_tuned.inc"
-    {0, 0, 0, 0, 0, 0, 0, 0}};
+    {0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
 // Launch variant of a descriptor (tools/tune_gemm.py computes the same number from the mdx_gemm_desc fields).
 int tuned_variant(const GemmParams& p) {
@@ -1313,7 +1316,7 @@ bool halo_eligible(const GemmParams& p, int bm);
 const TunedEntry* lookup_tuned(const GemmParams& p) {
     static const bool use_table = !(getenv("MDX_GEMM_TUNED") && atoi(getenv("MDX_GEMM_TUNED")) == 0) &&
                                   !getenv("MDX_GEMM_BM") && !getenv("MDX_GEMM_BN");
-    if (!use_table || p.bn_hint || p.stride != 1 || p.upsample) return nullptr;
+    if (!use_table || p.bn_hint || p.st_hint || p.stride != 1 || p.upsample) return nullptr;
     const int var1 = tuned_variant(p) + 1;
     const TunedEntry* any = nullptr;
     for (const TunedEntry* e = g_tuned; e->M; ++e)
@@ -1576,6 +1579,7 @@ extern "C" int mdx_gemm_check(const mdx_gemm_desc* d) {
 struct Resolved {
     GemmCfg c;
     int bn, ns;
+    int stages;      // LDS ring depth forced by the descriptor or the tile table (0 = the occupancy rule)
     bool halo, tuned;
     bool fixup;      // split-K reduced by the last block of each tile (no reduce launch)
 };
@@ -1586,6 +1590,8 @@ static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
     p.bk = r.c.bk;
     p.ktiles = (p.K + r.c.bk - 1) / r.c.bk;
     r.tuned = d->splitk <= 0 && d->tile_m <= 0 && lookup_tuned(p) != nullptr;
+    r.stages = p.st_hint;
+    if (r.tuned) r.stages = lookup_tuned(p)->st;
     const Tiling tl = choose_tiling(p, bn, d->splitk, d->tile_m);
     r.c.bm = tl.bm;
     int ns = tl.ns;
@@ -1716,16 +1722,20 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     p.trace = (g_gemm_trace && (size_t)grid.x * grid.y <= g_gemm_trace_slots) ? g_gemm_trace : nullptr;
     GemmCfg cc = c;
     if (!getenv("MDX_GEMM_CFG")) {
-        // <= 1 block per CU: LDS is not what limits residency, so spend it on a deeper DMA ring (measured +15-20 %
-        // on the split-K'd small-M layers); otherwise 2 stages keep 2-3 blocks resident per CU.
-        cc.ns = (ntiles * ns <= 256) ? 3 : 2;
+        // ring depth: three stages wherever they still leave two blocks per CU (every tile but 128 x 128: 3 x 24 KB), and for
+        // 128 x 128 tiles when the grid has at most one block per CU anyway; otherwise two.  tools/tune_gemm.py measures both
+        // depths per shape (round 2: 143 of 153 retuned rows chose three) and the table overrides this rule.
+        cc.ns = (ntiles * ns <= 256 || c.bm + bn <= 192) ? 3 : 2;
+        if (rs.stages == 2 || rs.stages == 3) cc.ns = rs.stages;
     }
     const bool swap = (ns == 1 || rs.fixup) && (p.out_mode == MDX_OUT_ROWMAJOR);
     bool ok;
     if (halo) {
-        // 128-pixel patches: the 2-stage weight ring keeps two blocks per CU (measured better than 3 stages at every
-        // UNet shape); 256-pixel patches own the CU, so the LDS left over goes to a third stage
-        int nsb = c.bm == 256 ? 3 : 2;
+        // weight ring depth: three stages where two blocks per CU still fit (64-column tiles: 46 KB halos + 3 x 8 KB; measured
+        // -5...-25 % against two stages at the UNet shapes, batch 2 and 16) and for 256-pixel patches, which own the CU; 128 x 128
+        // tiles keep two (a third stage would evict the second block)
+        int nsb = (c.bm == 256 || bn == 64) ? 3 : 2;
+        if (rs.stages == 2 || rs.stages == 3) nsb = rs.stages;
         static const char* envn = getenv("MDX_HALO_NSB");
         if (envn && atoi(envn) >= 2 && atoi(envn) <= 3) nsb = atoi(envn);
         if (c.bm == 256) {

@@ -34,7 +34,7 @@ def _threads():
 def _tuned_table():
     rows = {}
     for ln in open(os.path.join(ROOT, "minddiffusion_amd", "csrc", "gemm_tuned.inc")):
-        m = re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?\}", ln)
+        m = re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, \d+)?\}", ln)
         if m:
             v = [int(g or 0) for g in m.groups()]
             rows.setdefault(tuple(v[:4]), []).append(tuple(v[4:]))

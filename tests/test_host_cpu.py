@@ -345,7 +345,7 @@ def test_tuned_tile_table_is_well_formed():
     for ln in open(path):
         if ln.lstrip().startswith("//") or not ln.strip():
             continue
-        m = re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?\},", ln)
+        m = re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, \d+)?\},", ln)
         assert m, ln
         M, N, K, ks, bm, bn, ns = map(int, m.groups()[:7])
         var1 = int(m.group(8) or 0)
@@ -391,7 +391,7 @@ def test_tuned_table_drives_the_split_choice():
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "minddiffusion_amd", "csrc",
                         "gemm_tuned.inc")
     rows = [tuple(int(g or 0) for g in m.groups()) for m in
-            (re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?\},", ln) for ln in open(path)) if m]
+            (re.match(r"\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, \d+)?\},", ln) for ln in open(path)) if m]
     plain = {r[:4] for r in rows if r[7] in (0, 1)}
     checked = 0
     for M, N, K, ks, bm, bn, ns, var1 in rows:
