@@ -35,8 +35,13 @@ PY
       rm -rf gpurun_out/prof_bench; head -30 $OUT/bench_kernel_stats.md ;;
     pmc)
       for c in FETCH_SIZE WRITE_SIZE; do
-        timeout 400 rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc/$c -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $OUT/pmc_$c.log 2>&1
-        tail -2 $OUT/pmc_$c.log
+        for attempt in 1 2 3; do     # rocprofv3 --pmc occasionally dies with SIGSEGV inside the profiled process (ROCm 7.2): retry
+          rm -rf gpurun_out/pmc/$c
+          timeout 400 rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc/$c -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $OUT/pmc_$c.log 2>&1
+          [ -n "$(find gpurun_out/pmc/$c -name '*_results.db' 2>/dev/null | head -1)" ] && break
+          echo "pmc $c attempt $attempt failed"
+        done
+        tail -2 $OUT/pmc_$c.log | cut -c1-200
       done
       python tools/pmc_traffic.py gpurun_out/pmc "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph (the timed configuration launched eagerly: rocprofv3 --pmc segfaults on hipGraph replay; same kernels, same launch mix)" > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err; rm -rf gpurun_out/pmc; cat $OUT/pmc_traffic.json | head -60; cat $OUT/pmc_traffic.err | tail -3 ;;
     opprof)
