@@ -1399,7 +1399,7 @@ Tiling choose_tiling(const GemmParams& p, int bn, int forced_ns, int forced_bm) 
         // 256-row tiles exist for the HALO kernel only and are opt-in (MDX_GEMM_BM=256): measured on MI355X they move
         // 45 % fewer DMA bytes per MAC yet run no faster than two co-resident 128-row blocks (profiles/
         // r01_halo256_ab.txt) -- the K-step's barrier/issue structure, not the DMA rate, is what bounds this kernel
-        if (bm == 256 && (!halo || !envbm)) continue;
+        if (bm == 256 && (!halo || !(envbm || forced_bm == 256))) continue;
         if (bm == 64 && halo_eligible(p, 128) && !envbm && forced_bm <= 0) continue;  // HALO beats the generic kernel on every conv
         const int tiles = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
         // us per K-tile step of one block running alone on its CU (tools/gemm_trace.py): fewer DMA instructions and
@@ -1466,7 +1466,15 @@ void launch_cfg(const GemmParams& p, bool swap, bool fastk, dim3 grid, hipStream
 }
 
 template <int BM, int BN>
-bool launch_bn(const GemmCfg& c, const GemmParams& p, bool swap, bool fastk, dim3 grid, hipStream_t st) {
+bool launch_bn(const GemmCfg& c, const GemmParams& p, bool swap, bool fastk, dim3 grid, hipStream_t st, bool nw8 = false) {
+    if constexpr (BM == 128) {
+        // eight waves (4 x 2) on the same 128-row tile: each wave owns half the rows of the 4-wave form, so a block that has a
+        // CU to itself keeps two waves per SIMD busy (tile-table choice, mdx_gemm_desc.stages 10 | 11)
+        if (nw8 && c.bk == 64 && (c.ns == 2 || c.ns == 3)) {
+            if (c.ns == 2) launch_cfg<128, BN, 64, 2, 8>(p, swap, fastk, grid, st); else launch_cfg<128, BN, 64, 3, 8>(p, swap, fastk, grid, st);
+            return true;
+        }
+    }
     if (c.bk == 64 && c.ns == 2) launch_cfg<BM, BN, 64, 2, 4>(p, swap, fastk, grid, st);
     else if (c.bk == 64 && c.ns == 3) launch_cfg<BM, BN, 64, 3, 4>(p, swap, fastk, grid, st);
     else if (BM == 128 && c.bk == 64 && c.ns == 4) launch_cfg<128, BN, 64, 4, 4>(p, swap, fastk, grid, st);
@@ -1721,12 +1729,14 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     if (p.spread) grid = dim3(ntiles * ns, 1);
     p.trace = (g_gemm_trace && (size_t)grid.x * grid.y <= g_gemm_trace_slots) ? g_gemm_trace : nullptr;
     GemmCfg cc = c;
+    const bool nw8 = rs.stages >= 10;                      // eight waves per block (generic kernel, 128-row tiles)
+    const int st_req = nw8 ? rs.stages - 8 : rs.stages;    // requested ring depth (0 = the rule below)
     if (!getenv("MDX_GEMM_CFG")) {
         // ring depth: three stages wherever they still leave two blocks per CU (every tile but 128 x 128: 3 x 24 KB), and for
         // 128 x 128 tiles when the grid has at most one block per CU anyway; otherwise two.  tools/tune_gemm.py measures both
         // depths per shape (round 2: 143 of 153 retuned rows chose three) and the table overrides this rule.
         cc.ns = (ntiles * ns <= 256 || c.bm + bn <= 192) ? 3 : 2;
-        if (rs.stages == 2 || rs.stages == 3) cc.ns = rs.stages;
+        if (st_req == 2 || st_req == 3) cc.ns = st_req;
     }
     const bool swap = (ns == 1 || rs.fixup) && (p.out_mode == MDX_OUT_ROWMAJOR);
     bool ok;
@@ -1735,7 +1745,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         // -5...-25 % against two stages at the UNet shapes, batch 2 and 16) and for 256-pixel patches, which own the CU; 128 x 128
         // tiles keep two (a third stage would evict the second block)
         int nsb = (c.bm == 256 || bn == 64) ? 3 : 2;
-        if (rs.stages == 2 || rs.stages == 3) nsb = rs.stages;
+        if (st_req == 2 || st_req == 3) nsb = st_req;
         static const char* envn = getenv("MDX_HALO_NSB");
         if (envn && atoi(envn) >= 2 && atoi(envn) <= 3) nsb = atoi(envn);
         if (c.bm == 256) {
@@ -1749,7 +1759,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     } else if (cc.bm == 64)
         ok = (bn == 128) ? launch_bn<64, 128>(cc, p, swap, fastk, grid, st) : launch_bn<64, 64>(cc, p, swap, fastk, grid, st);
     else
-        ok = (bn == 128) ? launch_bn<128, 128>(cc, p, swap, fastk, grid, st) : launch_bn<128, 64>(cc, p, swap, fastk, grid, st);
+        ok = (bn == 128) ? launch_bn<128, 128>(cc, p, swap, fastk, grid, st, nw8) : launch_bn<128, 64>(cc, p, swap, fastk, grid, st, nw8);
     MDX_REQUIRE(ok, "mdx_gemm_f16: unsupported tile configuration bk=%d ns=%d", c.bk, c.ns);
     MDX_LAUNCH_CHECK("mdx_gemm_f16");
     if (ns > 1 && !d->defer_reduce && !rs.fixup) {

@@ -212,7 +212,7 @@ def pack_conv_weight(w4d, cin_pad=None, cout_pad=None):
 def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, rowbias=None, rowbias_ld=0,
                    residual=None, residual_ld=0, ksize=1, stride=1, upsample=0, epilogue=EPI_NONE,
                    out_mode=OUT_ROWMAJOR, splitk=0, workspace=None, out_bs=0, out2=None, out2_ld=0, n_split=0, asym_pad=0,
-                   stats_out=None, ln_stats=None, ln_s=None, ln_eps=1e-5, tile_m=0, tile_n=0, colstats_out=None):
+                   stats_out=None, ln_stats=None, ln_s=None, ln_eps=1e-5, tile_m=0, tile_n=0, colstats_out=None, stages=0):
     d = GemmDesc()
     d.a = a.data_ptr()
     d.a2 = 0 if a2 is None else a2.data_ptr()
@@ -239,7 +239,7 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
     d.ln_s = 0 if ln_s is None else ln_s.data_ptr()
     d.ln_nt = 0 if ln_stats is None else (int(c1) + int(c2)) // 64
     d.ln_eps = float(ln_eps)
-    d.tile_m, d.tile_n = int(tile_m), int(tile_n)
+    d.tile_m, d.tile_n, d.stages = int(tile_m), int(tile_n), int(stages)
     d.colstats_out = 0 if colstats_out is None else colstats_out.data_ptr()
     d.colstats_cap = 0 if colstats_out is None else int(colstats_out.shape[0])
     return d

@@ -149,6 +149,41 @@ def test_gemm_dense(ops, M, N, K, bias, res, splitk):
     check(f"gemm_dense_M{M}_N{N}_K{K}_b{int(bias)}_r{int(res)}_s{splitk}", out, ref, rel_l2=1e-3)
 
 
+@pytest.mark.parametrize("M,N,K,tile_n,splitk,epi", [
+    (384, 640, 1280, 128, 1, "none"),       # ragged M tail, 128 x 128 tiles
+    (512, 320, 640, 64, 1, "none"),         # 128 x 64 tiles
+    (256, 1280, 2560, 128, 3, "none"),      # split-K, reduced by the last arriver
+    (256, 1280, 5120, 64, 8, "none"),       # split-K through the reduce kernel
+    (256, 2560, 320, 128, 1, "geglu"),
+])
+def test_gemm_launch_forms_are_bit_identical(ops, M, N, K, tile_n, splitk, epi):
+    """mdx_gemm_desc.stages: ring depth 2 | 3 with four waves per block, 10 | 11 with eight (128-row tiles).  The launch form
+    changes which wave computes an output and how far ahead the DMAs run, never the order in which an output's products are
+    added: all four must agree bit for bit, and with the fp32 reference to fp16 accuracy."""
+    rng = np.random.RandomState(M + N + K + splitk)
+    a = h16(rng.standard_normal((M, K)))
+    w = h16(rng.standard_normal((N, K)) / math.sqrt(K))
+    bv = rng.standard_normal(N).astype(np.float32)
+    if epi == "geglu":
+        full = torch.tensor(a).float() @ torch.tensor(w).float().T + torch.tensor(bv)
+        ref = full[:, :N // 2] * O.gelu_tanh(full[:, N // 2:])
+        half = N // 2
+        nt = half // 64
+        wp = np.stack([w[:half].reshape(nt, 64, K), w[half:].reshape(nt, 64, K)], 1).reshape(N, K)
+        bp = np.stack([bv[:half].reshape(nt, 64), bv[half:].reshape(nt, 64)], 1).reshape(-1)
+        kw = dict(epilogue=ops.EPI_GEGLU)
+    else:
+        ref = torch.tensor(a).float() @ torch.tensor(w).float().T + torch.tensor(bv)
+        wp, bp, kw = w, bv, {}
+    ad, wd, bd = dev16(a), pack_dense(wp), dev32(np.ascontiguousarray(bp))
+    outs = {}
+    for st in (2, 3, 10, 11):
+        outs[st] = ops.gemm(ad, wd, N, 1, M, 1, K, bias=bd, splitk=splitk, tile_m=128, tile_n=tile_n, stages=st, **kw).clone()
+    for st in (3, 10, 11):
+        assert torch.equal(outs[2], outs[st]), f"stages={st} differs from stages=2"
+    check(f"gemm_launch_forms_M{M}_N{N}_K{K}_s{splitk}_{epi}", outs[11], ref, rel_l2=1e-3)
+
+
 def test_gemm_splitk_workspace_reuse(ops):
     """ONE split-K workspace serves different problems launched back to back and repeatedly (the planned executor and
     hipGraph replay rely on this), and the slab reduction order is fixed, so results are bit-identical run to run."""

@@ -132,14 +132,16 @@ def main():
         t_auto = time_desc(ops, auto, flush, args.reps, pre)
         best = (t_auto, 0, 0, 0, 0)
         bns = [128] if d0.epilogue == ops.EPI_GEGLU else ([64] if N < 128 else [128, 64])
-        for bm in ([128] if halo else [128, 64]):
+        halo256 = halo and d0.H % 16 == 0
+        for bm in (([128, 256] if halo256 else [128]) if halo else [128, 64]):
             for bn in bns:
                 for ns in NS_CANDIDATES:
                     if ns > 1 and (kt // ns < 2 or ns * M * N * 4 > big_ws.numel() * 4):
                         continue
                     if (halo or (halo8 and bm == 128)) and ns > (d0.c1 // 64):
                         continue
-                    for st in (2, 3):       # depth of the LDS ring (the library's rule: 3 when the grid leaves CUs half empty)
+                    # depth of the LDS ring; 10 | 11 = the same depths with eight waves per block (generic 128-row tiles)
+                    for st in ((2, 3, 10, 11) if (bm == 128 and not halo and not halo8) else (2, 3)):
                         try:
                             t = time_desc(ops, cand(bm, ns, bn, st), flush, args.reps, pre)
                         except Exception as e:      # unsupported combination
