@@ -283,6 +283,8 @@ def main():
     rank, world, local_rank = D.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if os.environ.get("MDX_BENCH_SHARE_GPU") == "1":     # tests only: every rank on device 0 (with MDX_DIST_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     batch = cfg["batch"]

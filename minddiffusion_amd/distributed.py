@@ -30,7 +30,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MDX_DIST_BACKEND=gloo: tests that put several ranks on ONE GPU (RCCL refuses that); payloads are then staged
+            # through the host by _broadcast / gather_latents
+            backend = os.environ.get("MDX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank))

@@ -142,3 +142,26 @@ def test_two_ranks_on_one_gpu_real_samplers_equal_single_process(tmp_path):
         got = torch.load(os.path.join(out_dir, f"glide_{rank}.pt"))
         assert torch.isfinite(got).all() and tuple(got.shape) == (per, 3, 32, 32)
         assert torch.equal(got, ref), f"GLIDE rank {rank}: sharded run differs from the single-process shard"
+
+
+def test_bench_two_ranks_contract():
+    """bench.py's own N > 1 path (the driver launches it through torch.distributed.run on an 8-GPU node, which this box does
+    not have): two ranks share the one GPU over gloo (MDX_DIST_BACKEND / MDX_BENCH_SHARE_GPU are test-only switches) and run
+    the headline config for one timed trajectory each.  Checked: rank 0 prints exactly one JSON line, n_gpus = 2, the value is
+    the whole-job rate (global batch 2 per step over the max-over-ranks time), weak scaling, no CPU baseline at N > 1."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDX_DIST_BACKEND="gloo", MDX_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"]
+    assert d["config"]["global_batch"] == 2 and d["config"]["parallelism"].endswith("x2")
+    assert abs(d["value"] - 2 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+    assert d["cpu_baseline"] is None and d["roofline"]["frac"] > 0
