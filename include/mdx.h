@@ -151,8 +151,9 @@ typedef struct mdx_gemm_desc {
     int tile_m;           /* 0 = auto (tuned table, then the cost model); 64 | 128 forces the M tile.  For tools/tune_gemm.py,
                              which measures the (tile_m, splitk) candidates of every UNet shape on the device. */
     int tile_n;           /* 0 = auto; 64 | 128 forces the N tile (same purpose; GEGLU always uses 128) */
-    int stages;           /* 0 = auto; 2 | 3 forces the depth of the LDS ring the K tiles are DMA'd through (same purpose);
-                             10 | 11 = the same depths with EIGHT waves per block (generic kernel, tile_m = 128 only) */
+    int stages;           /* 0 = auto; 2 .. 6 forces the depth of the LDS ring the K tiles are DMA'd through (same purpose; 64-row
+                             tiles up to 6, 128-row tiles up to 5, HALO weight ring 2 | 3); 10 | 11 = depth 2 | 3 with EIGHT
+                             waves per block (generic kernel, tile_m = 128 only) */
 } mdx_gemm_desc;
 
 #define MDX_GEMM_WS_HEAD 16384 /* bytes of arrival counters at the head of mdx_gemm_desc.workspace (zero on first use) */

@@ -741,7 +741,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
     for (int t = 0; t < nt; ++t) {
         // tiles t .. min(t+NS-2, nt-1) are outstanding; allow all but the oldest to stay in flight
         const int ahead = min(NS - 2, nt - 1 - t);
-        if (NS >= 5 && ahead >= 3)
+        if (NS >= 6 && ahead >= 4)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT) : "memory");
+        else if (NS >= 5 && ahead == 3)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
         else if (NS >= 4 && ahead == 2)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
@@ -1479,6 +1481,11 @@ bool launch_bn(const GemmCfg& c, const GemmParams& p, bool swap, bool fastk, dim
     else if (c.bk == 64 && c.ns == 3) launch_cfg<BM, BN, 64, 3, 4>(p, swap, fastk, grid, st);
     else if (BM == 128 && c.bk == 64 && c.ns == 4) launch_cfg<128, BN, 64, 4, 4>(p, swap, fastk, grid, st);
     else if (BM == 128 && c.bk == 64 && c.ns == 5) launch_cfg<128, BN, 64, 5, 4>(p, swap, fastk, grid, st);
+    // 64-row tiles stage only 16 / 24 KB per K tile: deeper rings are cheap, and a launch with one or two blocks per CU is
+    // bound by how many tiles it keeps in flight (tile-table choice)
+    else if (BM == 64 && c.bk == 64 && c.ns == 4) launch_cfg<64, BN, 64, 4, 4>(p, swap, fastk, grid, st);
+    else if (BM == 64 && c.bk == 64 && c.ns == 5) launch_cfg<64, BN, 64, 5, 4>(p, swap, fastk, grid, st);
+    else if (BM == 64 && c.bk == 64 && c.ns == 6) launch_cfg<64, BN, 64, 6, 4>(p, swap, fastk, grid, st);
     else return false;
     return true;
 }
@@ -1736,7 +1743,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         // 128 x 128 tiles when the grid has at most one block per CU anyway; otherwise two.  tools/tune_gemm.py measures both
         // depths per shape (round 2: 143 of 153 retuned rows chose three) and the table overrides this rule.
         cc.ns = (ntiles * ns <= 256 || c.bm + bn <= 192) ? 3 : 2;
-        if (st_req == 2 || st_req == 3) cc.ns = st_req;
+        if (st_req >= 2 && st_req <= 6) cc.ns = st_req;
     }
     const bool swap = (ns == 1 || rs.fixup) && (p.out_mode == MDX_OUT_ROWMAJOR);
     bool ok;

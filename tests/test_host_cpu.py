@@ -339,7 +339,7 @@ def test_layernorm_fold_host_algebra():
 def test_tuned_tile_table_is_well_formed():
     """csrc/gemm_tuned.inc (tools/tune_gemm.py): one {M, N, K, ksize, tile_m, tile_n, splitk[, variant + 1[, stages]]} row per
     shape and launch variant (rows without the 8th field predate the variant key and match any variant; stages = LDS ring depth
-    2 | 3, +8 for the eight-wave form of the generic kernel, 0 / absent = the library's rule).  256-row tiles exist for 3x3 convs
+    2 .. 6, 10 | 11 = depth 2 | 3 in the eight-wave form of the generic kernel, 0 / absent = the library's rule).  256-row tiles exist for 3x3 convs
     only (HALO kernel), the eight-wave form for 128-row tiles only."""
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "minddiffusion_amd", "csrc",
                         "gemm_tuned.inc")
@@ -352,7 +352,7 @@ def test_tuned_tile_table_is_well_formed():
         M, N, K, ks, bm, bn, ns = map(int, m.groups()[:7])
         var1, st = int(m.group(8) or 0), int(m.group(9) or 0)
         assert M > 0 and N % 8 == 0 and K > 0 and ks in (1, 3) and bm in (64, 128, 256) and bn in (0, 64, 128) and 1 <= ns <= 32
-        assert st in (0, 2, 3, 10, 11) and (bm != 256 or ks == 3) and (st < 10 or bm == 128)
+        assert st in (0, 2, 3, 4, 5, 6, 10, 11) and (bm != 256 or ks == 3) and (st < 10 or bm == 128) and (st < 5 or st >= 10 or bm < 256)
         assert 0 <= var1 <= 1024
         assert (M, N, K, ks, var1) not in seen, f"duplicate shape {ln}"
         seen.add((M, N, K, ks, var1))

@@ -157,9 +157,10 @@ def test_gemm_dense(ops, M, N, K, bias, res, splitk):
     (256, 2560, 320, 128, 1, "geglu"),
 ])
 def test_gemm_launch_forms_are_bit_identical(ops, M, N, K, tile_n, splitk, epi):
-    """mdx_gemm_desc.stages: ring depth 2 | 3 with four waves per block, 10 | 11 with eight (128-row tiles).  The launch form
-    changes which wave computes an output and how far ahead the DMAs run, never the order in which an output's products are
-    added: all four must agree bit for bit, and with the fp32 reference to fp16 accuracy."""
+    """mdx_gemm_desc.stages: ring depth 2 .. 4 with four waves per block and 10 | 11 = depth 2 | 3 with eight (128-row tiles),
+    depth 2 .. 6 on 64-row tiles.  The launch form changes which wave computes an output and how far ahead the DMAs run, never
+    the order in which an output's products are added: all must agree bit for bit, and with the fp32 reference to fp16
+    accuracy."""
     rng = np.random.RandomState(M + N + K + splitk)
     a = h16(rng.standard_normal((M, K)))
     w = h16(rng.standard_normal((N, K)) / math.sqrt(K))
@@ -177,11 +178,12 @@ def test_gemm_launch_forms_are_bit_identical(ops, M, N, K, tile_n, splitk, epi):
         wp, bp, kw = w, bv, {}
     ad, wd, bd = dev16(a), pack_dense(wp), dev32(np.ascontiguousarray(bp))
     outs = {}
-    for st in (2, 3, 10, 11):
-        outs[st] = ops.gemm(ad, wd, N, 1, M, 1, K, bias=bd, splitk=splitk, tile_m=128, tile_n=tile_n, stages=st, **kw).clone()
-    for st in (3, 10, 11):
-        assert torch.equal(outs[2], outs[st]), f"stages={st} differs from stages=2"
-    check(f"gemm_launch_forms_M{M}_N{N}_K{K}_s{splitk}_{epi}", outs[11], ref, rel_l2=1e-3)
+    forms = [(128, st) for st in (2, 3, 4, 10, 11)] + [(64, st) for st in (2, 3, 4, 5, 6)]
+    for tm, st in forms:
+        outs[(tm, st)] = ops.gemm(ad, wd, N, 1, M, 1, K, bias=bd, splitk=splitk, tile_m=tm, tile_n=tile_n, stages=st, **kw).clone()
+    for f in forms[1:]:
+        assert torch.equal(outs[forms[0]], outs[f]), f"tile_m, stages = {f} differs from {forms[0]}"
+    check(f"gemm_launch_forms_M{M}_N{N}_K{K}_s{splitk}_{epi}", outs[(64, 6)], ref, rel_l2=1e-3)
 
 
 def test_gemm_splitk_workspace_reuse(ops):

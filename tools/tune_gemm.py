@@ -141,7 +141,8 @@ def main():
                     if (halo or (halo8 and bm == 128)) and ns > (d0.c1 // 64):
                         continue
                     # depth of the LDS ring; 10 | 11 = the same depths with eight waves per block (generic 128-row tiles)
-                    for st in ((2, 3, 10, 11) if (bm == 128 and not halo and not halo8) else (2, 3)):
+                    generic = not halo and not (halo8 and bm == 128)
+                    for st in (((2, 3, 4, 10, 11) if bm == 128 else (2, 3, 4, 5, 6)) if generic else (2, 3)):
                         try:
                             t = time_desc(ops, cand(bm, ns, bn, st), flush, args.reps, pre)
                         except Exception as e:      # unsupported combination
