@@ -1655,23 +1655,23 @@ static int colstats_rows(const GemmParams& p, const Resolved& r) {
 }
 
 // What mdx_gemm_f16 would launch for this descriptor (no launch): out7 = {tile_m, tile_n, splitk, kernel (0 generic implicit
-// GEMM, 1 HALO conv), from_tuned_table, colstats rows per block}.  Parity tests use it to assert that the measured tile table
+// GEMM, 1 HALO conv), from_tuned_table, colstats rows per block, in-kernel split-K reduce}.  Parity tests use it to assert that the measured tile table
 // (gemm_tuned.inc) is actually hit at the benchmarked shapes; the UNet plan asks it where GroupNorm statistics can come from.
-extern "C" int mdx_gemm_query(const mdx_gemm_desc* d, int* out5) {
+extern "C" int mdx_gemm_query(const mdx_gemm_desc* d, int* out7) {
     GemmParams p{};
     int rc = fill_params(d, p);
     if (rc != MDX_OK) return rc;
-    MDX_REQUIRE(out5, "mdx_gemm_query: null output");
+    MDX_REQUIRE(out7, "mdx_gemm_query: null output");
     Resolved r;
     rc = resolve_launch(d, p, r);
     if (rc != MDX_OK) return rc;
-    out5[0] = r.c.bm;
-    out5[1] = r.bn;
-    out5[2] = r.ns;
-    out5[3] = r.halo ? 1 : 0;
-    out5[4] = r.tuned ? 1 : 0;
-    out5[5] = colstats_rows(p, r);
-    out5[6] = r.fixup ? 1 : 0;
+    out7[0] = r.c.bm;
+    out7[1] = r.bn;
+    out7[2] = r.ns;
+    out7[3] = r.halo ? 1 : 0;
+    out7[4] = r.tuned ? 1 : 0;
+    out7[5] = colstats_rows(p, r);
+    out7[6] = r.fixup ? 1 : 0;
     return MDX_OK;
 }
 
