@@ -1,5 +1,6 @@
 #!/bin/bash
-# non-temporal weight DMA for launches whose weight tiles are read by exactly one block (one row of M tiles)
+# non-temporal weight DMA for launches whose weight tiles are read by exactly one block (one row of M tiles).  Record of a finished
+# experiment: the MDX_GEMM_W_NT knob was removed again (slower, profiles/r02_o_weight_stream.txt)
 export PYTHONPATH=.
 mkdir -p gpurun_out/r02p
 MDX_GEMM_W_NT=1 timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm or conv or split" 2>&1 | grep -v amdgpu.ids | tail -2

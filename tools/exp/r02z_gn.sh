@@ -1,5 +1,6 @@
 #!/bin/bash
-# blocks per column-statistics GroupNorm launch (each block re-folds its channels' row-block partials)
+# blocks per column-statistics GroupNorm launch (each block re-folds its channels' row-block partials).  Record of a finished experiment:
+# the MDX_GN_CS_BLOCKS knob it drove was removed again (no setting beat 1024)
 export PYTHONPATH=.
 mkdir -p gpurun_out/r02z
 for t in 1024 256 512 2048 1024; do
