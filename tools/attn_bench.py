@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Micro-benchmark of mdx_attention_f16 at the UNet's self-attention shapes.
+
+    python tools/attn_bench.py [--shapes B,heads,N,D;...] [--iters 10]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="8,5,9216,64;2,5,4096,64;16,8,4096,40;16,10,1024,64")
+    ap.add_argument("--iters", type=int, default=10)
+    args = ap.parse_args()
+    from minddiffusion_amd import ops
+    dev = torch.device("cuda:0")
+    for spec in args.shapes.split(";"):
+        B, h, N, D = (int(v) for v in spec.split(","))
+        inner = h * D
+        qk = torch.randn(B, N, 2 * inner, device=dev, dtype=torch.float16)        # [q | k] as the merged projection writes them
+        vt = torch.randn(B, inner, N, device=dev, dtype=torch.float16)            # V^T
+        o = torch.empty(B, N, inner, device=dev, dtype=torch.float16)
+
+        def run():
+            ops.attention(qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, h, D, N, N, D ** -0.5,
+                          N * 2 * inner, 2 * inner, N * 2 * inner, 2 * inner, inner * N, N, N * inner, inner)
+        run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        print(f"self-attention B={B} heads={h} N={N} D={D}: {us:9.1f} us  {4.0 * B * h * N * N * D / us / 1e6:7.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
