@@ -170,9 +170,23 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
-        const float m_new = fmaxf(m_run, mx);           // finite: tile 0 always has a visible key (key 0), so m_run is
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);  // first tile: exp2(-inf) = 0
-        const float mb = m_new * p.scale_log2;
+        // Reference maximum: move it only when some query of this wave outgrew the current one by more than 2^8 (in the log2
+        // domain the exponentials are taken in).  The softmax is invariant to the reference; a stale one just means weights
+        // up to 2^8 instead of <= 1 -- nowhere near the fp16 range of the P fragments or the fp32 range of l and O -- and it
+        // saves the alpha exponential and the 16 * DT accumulator multiplies on almost every tile (with the exact rule
+        // "any of the wave's 32 queries saw a new maximum" 55-85 % of the tiles still rescaled: new maxima keep arriving at
+        // rate ~32 / t).  Tile 0: m_run = -inf, the difference is +inf, the branch is taken and alpha = exp2(-inf) = 0.
+        const float m_cand = fmaxf(m_run, mx);          // finite: tile 0 always has a visible key (key 0)
+        if (__builtin_amdgcn_ballot_w64((m_cand - m_run) * p.scale_log2 > 8.0f)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) * p.scale_log2);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+            m_run = m_cand;
+        }
+        const float mb = m_run * p.scale_log2;
         // two scores per instruction where the ISA has packed fp32 (v_pk_fma_f32 for x * scale - m, v_pk_add_f32 for the
         // row sum): the softmax VALU work, not the MFMAs, bounds this kernel at D = 64
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -190,16 +204,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
                 pf[kt * 2 + (r >> 3)][r & 7] = (f16)pv2.x;
                 pf[kt * 2 + (r >> 3)][(r & 7) + 1] = (f16)pv2.y;
             }
-        const float psum = psum2.x + psum2.y;
-        l_run = l_run * alpha + psum;
-        // rescale O only when some query of this wave saw a new maximum (alpha == 1 everywhere otherwise)
-        if (__builtin_amdgcn_ballot_w64(m_new != m_run)) {
-#pragma unroll
-            for (int d = 0; d < DT; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
-        }
-        m_run = m_new;
+        l_run += psum2.x + psum2.y;
 
         // ---- O^T += V^T P^T
 #pragma unroll
