@@ -1576,8 +1576,9 @@ extern "C" size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d) {
     const Tiling tl = choose_tiling(p, c.bn, d->splitk, d->tile_m);
     if (tl.ns <= 1) return 0;
     size_t head;
-    // (a launch clamped to fewer splits by a small workspace may switch to the in-kernel form: cover both layouts)
-    const size_t per = std::max(split_bytes(d, p, tl.bm, c.bn, tl.ns, &head), split_bytes(d, p, tl.bm, c.bn, 1 << 30, &head));
+    // sized for the larger of the two layouts (tile-padded partials of the in-kernel form >= [M][N] slabs): a launch that a
+    // small workspace clamps to fewer splits may switch form
+    const size_t per = std::max(split_bytes(d, p, tl.bm, c.bn, 2, &head), split_bytes(d, p, tl.bm, c.bn, 1 << 30, &head));
     return head + (size_t)tl.ns * per;
 }
 
@@ -1614,8 +1615,9 @@ static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
     if (ns > 1) {
         // shrink to what the caller's workspace can hold
         size_t head;
-        // sized for the tile-padded partials of the in-kernel form, which are never smaller than the [M][N] slabs
-        const size_t slab = std::max(split_bytes(d, p, tl.bm, bn, ns, &head), split_bytes(d, p, tl.bm, bn, 1 << 30, &head));
+        // counted in the larger of the two layouts (tile-padded partials of the in-kernel form >= [M][N] slabs): clamping can
+        // move a launch from one form to the other, and the split count that fits must fit the form it ends up in
+        const size_t slab = std::max(split_bytes(d, p, tl.bm, bn, 2, &head), split_bytes(d, p, tl.bm, bn, 1 << 30, &head));
         const size_t cap = (d->workspace && d->workspace_bytes > head) ? (d->workspace_bytes - head) / slab : 0;
         if ((size_t)ns > cap) ns = (int)cap;
         if (ns < 1) ns = 1;

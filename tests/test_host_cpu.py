@@ -414,6 +414,39 @@ def test_tuned_table_drives_the_split_choice():
     assert checked >= 6
 
 
+def test_split_k_form_is_decided_on_the_host():
+    """mdx_gemm_query (host only): a split launch of at most 4 splits with a row-major output reduces in the kernel (7th output),
+    deeper splits, transposed outputs and deferred reduces keep the [split][M][N] slabs + reduce kernel; the workspace the
+    library asks for covers the counters (MDX_GEMM_WS_HEAD) and the tile-padded partials; a workspace that is too small for a
+    forced split is an error, not a silent fallback."""
+    from minddiffusion_amd import _lib, ops
+    lib = _lib.load()
+    a = torch.zeros((1,), dtype=torch.float16)      # pointers are never dereferenced on this path
+    M, N, K = 304, 200, 4096
+
+    def desc(splitk, **kw):
+        d = ops.make_gemm_desc(a, a, N, 1, M, 1, K, a, kw.pop("out_ld", N), splitk=splitk, tile_m=128, tile_n=128, **kw)
+        d.workspace, d.workspace_bytes = 4096, 1 << 30
+        return d
+    for splitk, inkernel in ((1, 0), (2, 1), (4, 1), (5, 0), (16, 0)):
+        q = ops.gemm_query(desc(splitk))
+        assert q[:3] == (128, 128, splitk) and q[6] == inkernel, (splitk, q)
+        need = lib.mdx_gemm_workspace_bytes(ctypes.byref(desc(splitk)))
+        per = 3 * 128 * 2 * 128       # tile-padded partials (304 x 200 in 128 x 128 tiles): they cover the [M][N] slabs too
+        assert need == (0 if splitk == 1 else 16384 + splitk * per * 4)
+    assert ops.gemm_query(desc(3, out_mode=ops.OUT_TRANSPOSED, out_ld=M))[6] == 0
+    d = desc(3)
+    d.defer_reduce = 1
+    assert ops.gemm_query(d)[6] == 0
+    small = desc(4)
+    small.workspace_bytes = 16384 + 2 * 3 * 128 * 2 * 128 * 4     # room for two partials only
+    with pytest.raises(_lib.MdxError, match="workspace too small"):
+        ops.gemm_query(small)
+    auto = desc(0)
+    auto.workspace_bytes = 16384 + 2 * 3 * 128 * 2 * 128 * 4     # the auto choice is clamped to what fits instead
+    assert 1 <= ops.gemm_query(auto)[2] <= 2
+
+
 def test_checkpoints_with_reference_prefixes_load_all_models(tmp_path):
     """MindSpore .ckpt files keyed the way the reference's CLIs find them load into the mirrors --
     `model.diffusion_model.` / `first_stage_model.` / `cond_stage_model.` for LatentDiffusion (ddpm.py:75,350), and the
