@@ -107,6 +107,39 @@ def test_unet_constructor_variants_match_oracle_structure(name):
             O.UNetOracle(ocfg, p)(x, [3, 900], ctx)
 
 
+@pytest.mark.parametrize("name", sorted(UNET_VARIANTS))
+def test_unet_constructor_variants_plan_on_the_host(name):
+    """The planner is host code: for every constructor variant the op list is built (no launch) from the reference's block
+    structure, every GEMM op carries its descriptor and a resolved launch count, and the variant's own ops are present."""
+    from minddiffusion_amd.configs import TINY_UNET
+    from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from minddiffusion_amd.weights import synthetic_unet_params_numpy
+    cfg = dict(TINY_UNET, **UNET_VARIANTS[name])
+    net = UNetModel(device="cpu", **cfg)
+    net.load_state_dict(synthetic_unet_params_numpy(net.parameter_shapes(), 0))
+    base = UNetModel(device="cpu", **TINY_UNET)
+    base.load_state_dict(synthetic_unet_params_numpy(base.parameter_shapes(), 0))
+    P, P0 = net._plan(2, 8, 8), base._plan(2, 8, 8)
+    assert len(P.main) == len(P.meta) and all(m["launches"] in (1, 2) for m in P.meta)
+    gemms = [m for m in P.meta if m["kind"] == "gemm"]
+    assert gemms and all("desc" in m and " split=" in m["info"] for m in gemms)
+    blocks = sum(1 for k in base.w if k.endswith("attn2.q.w"))
+    n = lambda Pl, kind: sum(m["kind"] == kind for m in Pl.meta)
+    if name == "depth2":                # a second BasicTransformerBlock per SpatialTransformer: 2 attentions and 6 GEMMs each
+        assert n(P, "attention") == n(P0, "attention") + 2 * blocks and n(P, "gemm") == n(P0, "gemm") + 6 * blocks   # (+ 2 context GEMMs outside the op list)
+        assert len(P.ctxops) == len(P0.ctxops) + 2 * blocks
+    elif name == "pool_resample":       # the resampling convs become parameter-free pooling / nearest ops
+        assert n(P, "gemm") == n(P0, "gemm") - 2 and n(P, "small") == n(P0, "small") + 2
+    elif name.startswith("updown"):     # ResBlocks replace the Downsample / Upsample convs: + 2 GroupNorms each, pooled skip inputs
+        assert n(P, "groupnorm") == n(P0, "groupnorm") + 4
+    elif name == "class_cond":          # emb + label_emb(y): one more op in front of the emb_layers projection
+        assert P.temb_ops == P0.temb_ops + 1 and hasattr(P, "y_static")
+    elif name == "codebook_ids":        # the head is a 1x1 conv to n_embed channels
+        assert tuple(P.eps_nhwc.shape) == (2, 64, 24) and P.descs[-1 - 2 * blocks].ksize == 1
+    if name == "scale_shift":           # emb_layers project to (scale, shift): twice the rows
+        assert net._emb_total == 2 * base._emb_total
+
+
 def test_unet_unsupported_constructor_arguments_raise():
     from minddiffusion_amd.configs import TINY_UNET
     from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
