@@ -200,6 +200,48 @@ int mdx_attention_f16(const void* q, long q_bs, int q_ld, const void* k, long k_
                       long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads, int D, int Nq, int Nk,
                       float scale, mdx_stream_t s);
 
+/* ---- Row-local fused tail of a SpatialTransformer block: everything BasicTransformerBlock.construct does after the
+ *      self-attention core, plus SpatialTransformer's proj_out, as ONE launch (attention.py:151-152 to_out, :177 norm2,
+ *      :108 to_q, :138-150 cross-attention over the cached context keys, :183, :178 norm3, :41-70 GEGLU feed-forward, :184,
+ *      :231 proj_out, :256 residual):
+ *        t1 = attn_out Wo1^T + bo1 + tok;   q2 = LN2(t1) Wq2^T;   o2 = softmax(q2 K_ctx^T scale) V_ctx;
+ *        t2 = o2 Wo2^T + bo2 + t1;   h = GEGLU(LN3(t2) W1^T + b1);   t3 = h W2^T + b2 + t2;   out = t3 Wpo^T + bpo + x_in
+ *      A block owns `tile_rows` token rows for the whole chain (A operands resident in LDS, weights streamed HBM/L2 -> registers
+ *      in MFMA fragment order); none of q2, o2, t1, t2, the [M][4C] GEGLU intermediate or t3 goes through HBM.
+ * attn_out / tok / x_in / out: fp16 [B * tokens][C] dense.  ctx_k: fp16 [B][ctx_cap][C] = to_k(context), rows >= ctx_len
+ * finite; ctx_vt: fp16 [B][C][ctx_cap] = to_v(context) transposed (what the cached-context GEMMs of the unfused path write).
+ * wstream: the six weight matrices packed by minddiffusion_amd/ops.py: pack_st_tail (per wave w of the C / 32 waves, ONE
+ *   contiguous stream of 1 KiB pieces in consumption order; piece (matrix, column tile ct, k-step s)[lane][8] =
+ *   W[32 ct + lane % 32][16 s + 8 (lane / 32) + 0..7]); mdx_st_tail_stream_bytes(C) bytes.
+ * vec: fp32 [16 C] = [bo1 | gamma2 | beta2 | bo2 | gamma3 | beta3 | b1 (8C: a | gate, reference order) | b2 | bpo].
+ * colstats_out: optional [B * tokens / tile_rows][C][2] fp32 = per row block and column {sum, sum of squares} of the fp16
+ *   values stored to `out` (the layout of mdx_gemm_desc.colstats_out, rows per block = tile_rows), for the next GroupNorm.
+ * debug_out (tests only): when non-NULL the launch stops after stage `debug_stage` and writes that stage's [M][C] fp16 rows
+ *   there instead of finishing (1 t1, 2 LN2(t1), 3 q2, 4 o2, 5 t2, 6 LN3(t2), 7 t3). */
+typedef struct mdx_st_tail_desc {
+    const void* attn_out;
+    const void* tok;
+    const void* x_in;
+    void* out;
+    const void* ctx_k;
+    const void* ctx_vt;
+    const void* wstream;
+    const float* vec;
+    float* colstats_out;
+    void* debug_out;
+    int debug_stage;
+    int B, tokens;        /* M = B * tokens rows; tokens % tile_rows == 0 */
+    int C, heads, dim_head;
+    int ctx_len, ctx_cap; /* keys used / row capacity of ctx_k (ctx_vt row length); ctx_cap % 8 == 0, <= 96 */
+    float scale;          /* dim_head ** -0.5 */
+    float ln_eps;
+    int tile_rows;        /* 32 | 64 */
+} mdx_st_tail_desc;
+int mdx_st_tail_f16(const mdx_st_tail_desc* d, mdx_stream_t s);
+/* 1 if mdx_st_tail_f16 has a kernel for this shape (host only): C = 320 with 5 x 64 or 8 x 40 heads today. */
+int mdx_st_tail_supported(int C, int heads, int dim_head, int tokens_per_sample, int tile_rows);
+size_t mdx_st_tail_stream_bytes(int C);
+
 /* ---- timestep_embedding (util.py:111-131): t [M] fp32 -> out [M][dim] fp32 = [cos | sin]. */
 int mdx_timestep_embedding_f32(const float* t, float* out, int M, int dim, float max_period, mdx_stream_t s);
 
@@ -277,6 +319,11 @@ int mdx_probe_mfma_32x32x16_f16(const void* a, const void* b, float* c, mdx_stre
 /* streaming-bandwidth probe of the HBM/L2 -> LDS DMA path (mode 0) vs plain vector loads (mode 1) */
 int mdx_probe_dma_stream(const void* src, size_t bytes_per_block, int nblocks, int waves, int per, int ns, int mode,
                          int stride_tiles, float* sink, mdx_stream_t s);
+
+/* streaming probe of the L2 -> VGPR path the fused-chain kernels use for their weights: each wave reads its own contiguous
+ * bytes_per_wave region in 1 KiB pieces, pf in flight; shared = 1: every block reads the same regions (tools/l2_probe.py) */
+int mdx_probe_l2_stream(const void* src, size_t total_bytes, unsigned bytes_per_wave, int nblocks, int waves, int pf,
+                        int shared, float* sink, mdx_stream_t s);
 
 /* diagnostics: register a device buffer (bytes >= 64 x blocks) that the blocks of subsequent mdx_gemm_f16 launches
  * fill with phase timestamps (8 x u64 per block, 100 MHz realtime counter); NULL unregisters.  tools/gemm_trace.py */

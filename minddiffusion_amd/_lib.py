@@ -37,6 +37,17 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class StTailDesc(ctypes.Structure):
+    """struct mdx_st_tail_desc (include/mdx.h)."""
+    _fields_ = [
+        ("attn_out", c_void_p), ("tok", c_void_p), ("x_in", c_void_p), ("out", c_void_p),
+        ("ctx_k", c_void_p), ("ctx_vt", c_void_p), ("wstream", c_void_p), ("vec", c_void_p),
+        ("colstats_out", c_void_p), ("debug_out", c_void_p), ("debug_stage", c_int),
+        ("B", c_int), ("tokens", c_int), ("C", c_int), ("heads", c_int), ("dim_head", c_int),
+        ("ctx_len", c_int), ("ctx_cap", c_int), ("scale", c_float), ("ln_eps", c_float), ("tile_rows", c_int),
+    ]
+
+
 EPI_NONE, EPI_GEGLU, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3
 OUT_ROWMAJOR, OUT_TRANSPOSED = 0, 1
 
@@ -66,6 +77,9 @@ SIGNATURES = {
                                   c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "mdx_attention_causal_f16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,
                                   c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "mdx_st_tail_f16": (c_int, [ctypes.POINTER(StTailDesc), c_void_p]),
+    "mdx_st_tail_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "mdx_st_tail_stream_bytes": (c_size_t, [c_int]),
     "mdx_timestep_embedding_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "mdx_dense_small_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_int, c_int, c_void_p]),
@@ -84,6 +98,7 @@ SIGNATURES = {
     "mdx_softmax_rows_f16": (c_int, [c_void_p, c_long, c_int, c_int, c_float, c_void_p]),
     "mdx_probe_mfma_32x32x16_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdx_probe_gemm_trace": (c_int, [c_void_p, c_size_t]),
+    "mdx_probe_l2_stream": (c_int, [c_void_p, c_size_t, ctypes.c_uint, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mdx_probe_dma_stream": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 

@@ -330,3 +330,48 @@ extern "C" int mdx_probe_dma_stream(const void* src, size_t bytes_per_block, int
     MDX_LAUNCH_CHECK("mdx_probe_dma_stream");
     return MDX_OK;
 }
+
+// ------------------------------------------------------------------ L2 -> VGPR streaming probe (tools/l2_probe.py)
+// What the fused-chain kernels (stchain.hip) do with their weights: every wave streams its own contiguous region with one
+// coalesced 1 KiB buffer_load_dwordx4 per piece, PF pieces in flight (schedule pinned), optionally the SAME region in every
+// block (shared = 1: all CUs hit the same L2 lines, as all row blocks of a fused launch read the same weights).
+namespace {
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+template <int PFD>
+__global__ __launch_bounds__(1024) void l2_probe_kernel(const char* src, unsigned bytes_per_wave, int shared, unsigned total_bytes,
+                                                        float* sink) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, total_bytes);
+    const unsigned base = ((shared ? 0u : (unsigned)blockIdx.x * nw) + wave) * bytes_per_wave;
+    const unsigned voff = lane * 16u;
+    const int pieces = bytes_per_wave / 1024;
+    pu32x4 ring[PFD];
+#pragma unroll
+    for (int j = 0; j < PFD; ++j) ring[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + j * 1024u, 0);
+    unsigned acc = 0;
+    for (int p0 = 0; p0 < pieces; p0 += PFD) {
+#pragma unroll
+        for (int j = 0; j < PFD; ++j) {
+            acc ^= ring[j][0] ^ ring[j][3];
+            ring[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + (unsigned)(p0 + j + PFD) * 1024u, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = 1.f;
+}
+}  // namespace
+
+extern "C" int mdx_probe_l2_stream(const void* src, size_t total_bytes, unsigned bytes_per_wave, int nblocks, int waves, int pf,
+                                   int shared, float* sink, mdx_stream_t s) {
+    MDX_REQUIRE(src && sink && nblocks > 0 && waves >= 1 && waves <= 16 && bytes_per_wave % (32 * 1024) == 0 &&
+                    total_bytes <= 0xffffffffull, "mdx_probe_l2_stream: bad arguments");
+    hipStream_t st = (hipStream_t)s;
+    if (pf == 8) hipLaunchKernelGGL(l2_probe_kernel<8>, dim3(nblocks), dim3(waves * 64), 0, st, (const char*)src, bytes_per_wave, shared, (unsigned)total_bytes, sink);
+    else if (pf == 16) hipLaunchKernelGGL(l2_probe_kernel<16>, dim3(nblocks), dim3(waves * 64), 0, st, (const char*)src, bytes_per_wave, shared, (unsigned)total_bytes, sink);
+    else if (pf == 32) hipLaunchKernelGGL(l2_probe_kernel<32>, dim3(nblocks), dim3(waves * 64), 0, st, (const char*)src, bytes_per_wave, shared, (unsigned)total_bytes, sink);
+    else MDX_REQUIRE(false, "mdx_probe_l2_stream: pf must be 8, 16 or 32");
+    MDX_LAUNCH_CHECK("mdx_probe_l2_stream");
+    return MDX_OK;
+}

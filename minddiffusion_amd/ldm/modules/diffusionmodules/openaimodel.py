@@ -349,6 +349,17 @@ class UNetModel:
                         .reshape(2 * half, inner), "norm3", w[t + "ff1.b"])
                     w[t + "ff2.w"] = self._pack_dense(P[t + "ff.net.2.weight"])
                     w[t + "ff2.b"] = self._dev(P[t + "ff.net.2.bias"], f32)
+                    # row-local fused tail (mdx_st_tail_f16): to_out1 .. proj_out as one launch where a level has enough
+                    # token rows to fill the chip; its own packing (MFMA-fragment-major per-wave streams, unfolded LayerNorms)
+                    if (self.transformer_depth == 1 and inner == layer[1]
+                            and ops.st_tail_supported(inner, layer[2], layer[3], 64, 64)):
+                        po = self._dev(P[pre + "proj_out.weight"], f16)
+                        w[t + "tail.stream"], w[t + "tail.vec"] = ops.pack_st_tail(
+                            self._dev(P[t + "attn1.to_out.0.weight"], f16), self._dev(P[t + "attn2.to_q.weight"], f16),
+                            self._dev(P[t + "attn2.to_out.0.weight"], f16), gw, self._dev(P[t + "ff.net.2.weight"], f16),
+                            po.reshape(po.shape[0], po.shape[1]),
+                            w[t + "attn1.o.b"], w[t + "norm2.g"], w[t + "norm2.b"], w[t + "attn2.o.b"], w[t + "norm3.g"],
+                            w[t + "norm3.b"], gb, w[t + "ff2.b"], w[pre + "proj_out.b"])
             elif kind == "down" and self.conv_resample:
                 w[pre + "w"] = self._pack_conv(P[pre + "op.conv.weight"])
                 w[pre + "b"] = self._dev(P[pre + "op.conv.bias"], f32)
@@ -503,6 +514,24 @@ class UNetModel:
             return out
 
         ln_stats = {}
+        tails = []
+
+        def tail_rows(t, n, heads, dh):
+            """Rows per block of the fused SpatialTransformer tail for this block, or 0 = unfused launches.  The fused launch
+            needs enough row blocks to fill the chip: 32-row blocks from 192 blocks up (UNet batch 2 at a 64 x 64 latent = 256),
+            64-row blocks (half the weight traffic through L2) once those alone give >= 2 blocks per CU.
+            ops.set_option("unet_st_tail", 0 | 32 | 64) forces a choice (0 = never)."""
+            if (t + "tail.stream") not in w or self.transformer_depth != 1:
+                return 0
+            forced = ops.get_option("unet_st_tail")
+            cands = [forced] if forced in (32, 64) else ([] if forced == 0 else [64, 32])
+            for r in cands:
+                if not ops.st_tail_supported(heads * dh, heads, dh, n, r):
+                    continue
+                blocks = B * n // r
+                if forced in (32, 64) or (r == 64 and blocks >= 512) or (r == 32 and blocks >= 192):
+                    return r
+            return 0
 
         def stats_buf(rows, width):
             """{sum, sumsq} per 64-column slice of a token row: written by the GEMM that produces the rows, read by the
@@ -598,6 +627,26 @@ class UNetModel:
                     qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
                     n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner),
                     "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
+                rows_t = tail_rows(t, n, heads, dh)
+                if rows_t:
+                    # everything after the self-attention core of this block + proj_out + the residual: ONE row-local launch
+                    kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
+                    vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
+                    ctx_kv[t] = (kc, vtc)
+                    out = A.get((B, n, ch))
+                    td = ops.make_st_tail_desc(o, tok, x, out, kc, vtc, w[t + "tail.stream"], w[t + "tail.vec"], B, n, ch, heads,
+                                               dh, 1, TC, tile_rows=rows_t)
+                    tails.append(td)
+                    td._bufs = (o, tok, x, out, kc, vtc)      # keeps the views alive; tools / tests read them
+                    producer[out.data_ptr()] = td
+
+                    def run_tail(td=td):
+                        td.ctx_len = P.ctx_len      # read at call time like the attention ops; a captured graph bakes it in
+                        ops.st_tail_run(td)
+                    emit(run_tail, "gemm", 2 * B * n * 16 * inner * inner + 4 * B * heads * n * 77 * dh, 1,
+                         f"st_tail M={B * n} C={inner} rows={rows_t} (to_out1..proj_out fused)")
+                    A.release(qk); A.release(vt); A.release(tok); A.release(ln)
+                    return out
                 tok2 = dense(main, o, B, n, inner, inner, w[t + "attn1.o.w"], bias=w[t + "attn1.o.b"], residual=tok,
                              stats_out=st)
                 A.release(qk); A.release(vt); A.release(tok)
@@ -730,7 +779,8 @@ class UNetModel:
                 cpg = C1 // 32
                 L = cpg // math.gcd(cpg, 8)
                 d = c["prod"][0]
-                if (c["x2"] is None and not c["film"] and L <= 64 and HW * L * 16 <= (64 << 10) and d is not None and d.N == C1
+                if (c["x2"] is None and not c["film"] and L <= 64 and HW * L * 16 <= (64 << 10) and isinstance(d, ops.GemmDesc)
+                        and d.N == C1
                         and d.out_ld == C1 and op_index.get(ctypes.addressof(d)) == c["meta"] - 1
                         and ops.gemm_query(d)[2] > 1 and ops.groupnorm_from_splitk_ok(d)):
                     d.defer_reduce = 1
@@ -752,6 +802,8 @@ class UNetModel:
         P.arena_bytes = A.total
         P.ln_stats = ln_stats
         P.arena = A   # owns the activation buffers (descriptors only hold raw device pointers)
+        P.tails = tails
+        P.ctx_kv = ctx_kv     # the cached context K / V^T buffers: descriptors hold raw pointers only
         P.graph = None
         P.graph_failed = False
         self._plans[key] = P

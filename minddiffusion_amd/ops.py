@@ -1,6 +1,7 @@
 """Thin torch-tensor wrappers over the C-ABI (include/mdx.h).  torch supplies device memory and
 the current HIP stream; all arithmetic happens in libmdx.so.  No CPU fallbacks."""
 import ctypes
+import os
 
 import torch
 
@@ -9,6 +10,22 @@ from ._lib import GemmDesc, EPI_NONE, EPI_GEGLU, EPI_GELU, EPI_QUICKGELU, OUT_RO
 
 f16 = torch.float16
 f32 = torch.float32
+
+
+# Library-level options (experiment / tuning switches that used to be environment variables read inside the library):
+# one explicit table instead of getenv() calls scattered through the code.
+# -1 auto | 0 never | 32 | 64 rows per block of the fused SpatialTransformer tail (MDX_UNET_ST_TAIL presets it for A/B runs)
+_OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1"))}
+
+
+def set_option(name, value):
+    if name not in _OPTIONS:
+        raise _lib.MdxError(f"unknown option {name!r} (known: {sorted(_OPTIONS)})")
+    _OPTIONS[name] = int(value)
+
+
+def get_option(name):
+    return _OPTIONS[name]
 
 
 def _stream():
@@ -422,6 +439,16 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
             continue
 
         def stats_of(d, cx):
+            if isinstance(d, _lib.StTailDesc):      # fused SpatialTransformer tail: per-row-block column sums of its output
+                key = ctypes.addressof(d)
+                if key not in table:
+                    rows = d.tile_rows
+                    if d.C != cx or HW % rows or HW // rows > 128:
+                        return None
+                    buf = torch.zeros((batch * (HW // rows), cx, 2), dtype=f32, device=device)
+                    d.colstats_out = buf.data_ptr()
+                    table[key] = (buf, HW // rows)
+                return table[key]
             if d is None or d.N != cx or d.out_ld != cx or d.defer_reduce:
                 return None
             key = ctypes.addressof(d)
@@ -446,3 +473,63 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
             continue
         c["cs"] = (s1[0], s1[1], s2[0], s2[1])
         meta[c["meta"]]["launches"] = 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Row-local fused SpatialTransformer tail (include/mdx.h: mdx_st_tail_f16, csrc/stchain.hip)
+def pack_frag_weight(w2d):
+    """[N, K] nn.Dense weight -> MFMA-fragment-major pieces [N/32 column tiles][K/16 k-steps][64 lanes * 8 halves]:
+    piece (ct, s)[lane] = W[32 ct + lane % 32][16 s + 8 (lane // 32) + 0..7] -- the first operand of
+    v_mfma_f32_32x32x16_f16 exactly as a lane holds it, so a wave loads one piece with ONE coalesced 1 KiB instruction."""
+    N, K = w2d.shape
+    assert N % 32 == 0 and K % 16 == 0
+    t = w2d.to(f16).reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4)     # [ct, s, hi, l31, 8]
+    return t.reshape(N // 32, K // 16, 512).contiguous()
+
+
+def pack_st_tail(wo1, wq2, wo2, w1, w2, wpo, bo1, g2, be2, bo2, g3, be3, b1, b2, bpo):
+    """Weights / vectors of one SpatialTransformer block (depth 1) in the layout mdx_st_tail_f16 streams:
+    wave w of the C/32 waves owns output columns [32w, 32w+32) of every GEMM of the chain; its pieces are stored in
+    consumption order -- to_out1, to_q2, to_out2, 4 x (ff1 chunk: 'a' and 'gate' pieces interleaved per k-step, then the ff2
+    K-chunk), proj_out -- as ONE contiguous stream.  w1: [8C, C] (reference order: a rows then gate rows), w2: [C, 4C].
+    Returns (stream fp16 [C/32, 16 C/16, 512], vec fp32 [16 C])."""
+    C = wo1.shape[0]
+    NW, KS = C // 32, C // 16
+    f = pack_frag_weight
+    fo1, fq2, fo2, fpo = f(wo1), f(wq2), f(wo2), f(wpo)        # [NW, KS, 512]
+    f1 = f(w1)                                                  # [8C/32, KS, 512]: tiles [0, 4C/32) = a, then gate
+    f2 = f(w2)                                                  # [NW, 4C/16, 512]
+    parts = [fo1, fq2, fo2]
+    for c in range(4):
+        a = f1[c * NW:(c + 1) * NW]
+        g = f1[4 * C // 32 + c * NW:4 * C // 32 + (c + 1) * NW]
+        parts.append(torch.stack([a, g], 2).reshape(NW, 2 * KS, 512))
+        parts.append(f2[:, c * KS:(c + 1) * KS])
+    parts.append(fpo)
+    stream = torch.cat(parts, 1).contiguous()
+    assert stream.shape == (NW, 16 * KS, 512)
+    vec = torch.cat([v.to(f32).reshape(-1) for v in (bo1, g2, be2, bo2, g3, be3, b1, b2, bpo)]).contiguous()
+    assert vec.numel() == 16 * C
+    return stream, vec
+
+
+def st_tail_supported(C, heads, dim_head, tokens, tile_rows):
+    return bool(_lib.load().mdx_st_tail_supported(int(C), int(heads), int(dim_head), int(tokens), int(tile_rows)))
+
+
+def make_st_tail_desc(attn_out, tok, x_in, out, ctx_k, ctx_vt, stream, vec, B, tokens, C, heads, dim_head, ctx_len, ctx_cap,
+                      tile_rows=64, ln_eps=1e-5, colstats_out=None, debug_out=None, debug_stage=0):
+    d = _lib.StTailDesc()
+    d.attn_out, d.tok, d.x_in, d.out = attn_out.data_ptr(), tok.data_ptr(), x_in.data_ptr(), out.data_ptr()
+    d.ctx_k, d.ctx_vt, d.wstream, d.vec = ctx_k.data_ptr(), ctx_vt.data_ptr(), stream.data_ptr(), vec.data_ptr()
+    d.colstats_out = 0 if colstats_out is None else colstats_out.data_ptr()
+    d.debug_out = 0 if debug_out is None else debug_out.data_ptr()
+    d.debug_stage = int(debug_stage)
+    d.B, d.tokens, d.C, d.heads, d.dim_head = int(B), int(tokens), int(C), int(heads), int(dim_head)
+    d.ctx_len, d.ctx_cap = int(ctx_len), int(ctx_cap)
+    d.scale, d.ln_eps, d.tile_rows = float(dim_head) ** -0.5, float(ln_eps), int(tile_rows)
+    return d
+
+
+def st_tail_run(desc):
+    _lib.check(_lib.load().mdx_st_tail_f16(ctypes.byref(desc), _stream()), "mdx_st_tail_f16")

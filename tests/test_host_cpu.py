@@ -557,3 +557,130 @@ def test_checkpoints_with_reference_prefixes_load_all_models(tmp_path):
     assert list(C.load_checkpoint(p3, strip_prefix=C.UNET_PREFIX)) == ["a"]
     with pytest.raises(ValueError):
         C.load_checkpoint(p3)
+
+
+def _checkpoint_proto_classes(packed_dims):
+    """The published MindSpore schema (mindspore/ccsrc/utils/checkpoint.proto) as a protobuf descriptor built at test time:
+    an INDEPENDENT serializer (google.protobuf's own encoder) for the files ms_checkpoint.load_checkpoint must read."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto()
+    fd.name = f"mdx_test_checkpoint_{int(packed_dims)}.proto"
+    fd.package = f"mdx_test_ckpt{int(packed_dims)}"
+    fd.syntax = "proto2"
+    ck = fd.message_type.add()
+    ck.name = "Checkpoint"
+    val = ck.nested_type.add()
+    val.name = "Value"
+    tp = fd.message_type.add()
+    tp.name = "TensorProto"
+    for name, num, label, typ in (("dims", 1, F.LABEL_REPEATED, F.TYPE_INT64), ("tensor_type", 2, F.LABEL_REQUIRED, F.TYPE_STRING),
+                                  ("tensor_content", 3, F.LABEL_REQUIRED, F.TYPE_BYTES)):
+        f = tp.field.add()
+        f.name, f.number, f.label, f.type = name, num, label, typ
+        if name == "dims" and packed_dims:
+            f.options.packed = True
+    f = val.field.add()
+    f.name, f.number, f.label, f.type = "tag", 1, F.LABEL_REQUIRED, F.TYPE_STRING
+    f = val.field.add()
+    f.name, f.number, f.label, f.type, f.type_name = "tensor", 2, F.LABEL_REQUIRED, F.TYPE_MESSAGE, f".{fd.package}.TensorProto"
+    f = ck.field.add()
+    f.name, f.number, f.label, f.type, f.type_name = "value", 1, F.LABEL_REPEATED, F.TYPE_MESSAGE, f".{fd.package}.Checkpoint.Value"
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    return message_factory.GetMessageClass(pool.FindMessageTypeByName(f"{fd.package}.Checkpoint"))
+
+
+def _write_like_mindspore(Checkpoint, params, path, slice_elems=None, types=None):
+    """What mindspore.train.serialization._exec_save does (restated from its published source): one serialized Checkpoint
+    message per parameter -- per SLICE of a parameter larger than the slice size, every slice under the same tag with the full
+    dims -- written back to back.  `types` overrides tensor_type per name (BFloat16 payloads are raw uint16)."""
+    ms_name = {"float32": "Float32", "float16": "Float16", "float64": "Float64", "int64": "Int64", "int32": "Int32",
+               "uint8": "UInt8", "bool": "Bool"}
+    with open(path, "wb") as f:
+        for name, arr in params.items():
+            arr = np.asarray(arr)
+            ttype = (types or {}).get(name, ms_name.get(arr.dtype.name))
+            flat = arr.reshape(-1)
+            step = slice_elems or max(flat.size, 1)
+            for off in range(0, max(flat.size, 1), step):
+                msg = Checkpoint()
+                v = msg.value.add()
+                v.tag = name
+                v.tensor.dims.extend(int(d) for d in arr.shape)
+                v.tensor.tensor_type = ttype
+                v.tensor.tensor_content = flat[off:off + step].tobytes()
+                f.write(msg.SerializeToString())
+
+
+@pytest.mark.parametrize("packed_dims", [False, True])
+def test_checkpoint_reader_against_independent_protobuf_writer(tmp_path, packed_dims):
+    """a checkpoint whose bytes never passed through ms_checkpoint.save_checkpoint.  The file is produced
+    by google.protobuf from the published checkpoint.proto schema the way MindSpore's save_checkpoint lays messages out
+    (stablediffusionv2/txt2img.py:52-63 and Taichu-GLIDE/src/txt2img.py:34-57 read such files with ms.load_checkpoint): sliced
+    parameters, Float16 / BFloat16 / Int64 payloads, scalar (dims-less) entries, proto2 unpacked AND packed `dims`.  It is
+    loaded through load_checkpoint, load_latent_diffusion -> UNetModel.load_state_dict, and glide.load_ckpt."""
+    from oracle import glide as OG
+    from oracle import ldm as OL
+    from minddiffusion_amd import ms_checkpoint as C
+    from minddiffusion_amd.configs import TINY_UNET
+    from minddiffusion_amd.glide import diffusion_creator as DC
+    from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    Checkpoint = _checkpoint_proto_classes(packed_dims)
+    rng = np.random.RandomState(5)
+    # ---- raw reader: every payload type, slicing, scalars, negative ints, a unicode tag
+    bf = rng.standard_normal((3, 5)).astype(np.float32)
+    bf_bits = (bf.view(np.uint32) >> 16).astype(np.uint16)                   # truncated bfloat16 payload
+    raw = {"a.f32": rng.standard_normal((4, 3, 2)).astype(np.float32), "b.f16": rng.standard_normal((7,)).astype(np.float16),
+           "c.bf16": bf_bits, "d.i64": np.array([[-3, 2 ** 40], [7, -(2 ** 50)]], np.int64), "e.scalar": np.float32(2.5),
+           "f.big": rng.standard_normal((33, 17)).astype(np.float32), "g.参数": np.arange(6, dtype=np.int32).reshape(2, 3),
+           "h.bool": np.array([True, False, True])}
+    p1 = str(tmp_path / "raw.ckpt")
+    _write_like_mindspore(Checkpoint, raw, p1, slice_elems=50, types={"c.bf16": "BFloat16"})
+    got = C.load_checkpoint(p1)
+    assert list(got) == list(raw)
+    for k, v in raw.items():
+        if k == "c.bf16":
+            np.testing.assert_array_equal(got[k], (bf_bits.astype(np.uint32) << 16).view(np.float32))
+            assert got[k].dtype == np.float32 and got[k].shape == (3, 5)
+        else:
+            np.testing.assert_array_equal(got[k], np.asarray(v))
+            assert got[k].dtype == np.asarray(v).dtype and got[k].shape == np.asarray(v).shape, k
+    # the protobuf runtime parses our own writer's bytes too (the two serializers agree in both directions)
+    p1b = str(tmp_path / "ours.ckpt")
+    C.save_checkpoint({k: v for k, v in raw.items() if k != "c.bf16"}, p1b, slice_bytes=64)
+    msg = Checkpoint()
+    msg.MergeFromString(open(p1b, "rb").read())          # concatenated messages merge into one repeated field
+    assert [v.tag for v in msg.value][:2] == ["a.f32", "a.f32"] and msg.value[0].tensor.tensor_type == "Float32"
+    assert list(msg.value[0].tensor.dims) == [4, 3, 2]
+    # ---- LatentDiffusion checkpoint (fp16 weights, as the released SD / Wukong checkpoints are stored) -> UNetModel
+    ocfg = dict(TINY_UNET, num_heads=TINY_UNET.get("num_heads", -1), num_head_channels=TINY_UNET.get("num_head_channels", -1))
+    up = {k: v.astype(np.float16) for k, v in OL.init_params(ocfg, seed=3).items()}
+    ck = {C.UNET_PREFIX + k: v for k, v in up.items()}
+    ck[C.VAE_PREFIX + "decoder.conv_in.bias"] = np.zeros(3, np.float32)
+    ck[C.TEXT_PREFIX + "transformer.positional_embedding"] = rng.standard_normal((77, 8)).astype(np.float32)
+    ck["global_step"] = np.array([12345], np.int64)
+    p2 = str(tmp_path / "ldm.ckpt")
+    _write_like_mindspore(Checkpoint, ck, p2, slice_elems=1 << 12)
+    unet_sd, vae_sd, text_sd = C.load_latent_diffusion(p2)
+    assert sorted(unet_sd) == sorted(up) and list(vae_sd) == ["decoder.conv_in.bias"]
+    assert list(text_sd) == ["transformer.positional_embedding"]
+    for k in up:
+        np.testing.assert_array_equal(unet_sd[k], up[k])
+    net = UNetModel(device="cpu", **TINY_UNET).load_state_dict(unet_sd)
+    ref = UNetModel(device="cpu", **TINY_UNET).load_state_dict(up)
+    for k in ref.w:
+        assert torch.equal(net.w[k], ref.w[k]), k
+    # ---- Taichu-GLIDE base checkpoint with the training-wrapper names -> glide.load_ckpt's key rewrite
+    otiny = dict(OG.BASE_OPTIONS, image_size=16, model_channels=64, num_res_blocks=1, channel_mult=(1, 2),
+                 attention_resolutions=(1, 2), text_ctx=16, xf_width=64, xf_layers=2, xf_heads=1, n_vocab=100)
+    bp = OG.init_params(otiny, seed=4)
+    wrapped = {"diffusion_with_p_sample.p_mean_variance.guider_net." + k: v for k, v in bp.items()}
+    p3 = str(tmp_path / "glide.ckpt")
+    _write_like_mindspore(Checkpoint, wrapped, p3, slice_elems=1 << 11)
+    opts = dict(TINY_GLIDE, device="cpu", noise_schedule="squaredcos_cap_v2", diffusion_steps=1000, timestep_respacing="10")
+    m = DC.init_diffusion_model(opts, 3.0, (4, 3, 16, 16), ckpt_path=p3)
+    refg = DC.create_model(**opts)
+    refg.load_state_dict(bp)
+    for k in refg.w:
+        assert torch.equal(m.model.w[k], refg.w[k]), k

@@ -1,0 +1,25 @@
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench
+from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+orig = UNetModel.forward_nhwc
+calls = [0]
+def checked(self, x, t, context, **kw):
+    y = orig(self, x, t, context, **kw)
+    calls[0] += 1
+    torch.cuda.synchronize()
+    fin = bool(torch.isfinite(y).all())
+    if calls[0] <= 3 or not fin:
+        print("call", calls[0], "x", tuple(x.shape), "ctx", tuple(context.shape), context.dtype, "ctx finite", bool(torch.isfinite(context).all()),
+              "ctx_len", self._plans[(x.shape[0], x.shape[2], x.shape[3])].ctx_len, "y finite", fin, "kw", list(kw), flush=True)
+    if not fin:
+        P = self._plans[(x.shape[0], x.shape[2], x.shape[3])]
+        for k, td in enumerate(P.tails):
+            o, tok, xin, out, kc, vtc = td._bufs
+            print("tail", k, {n: (bool(torch.isfinite(v).all()), round(float(v.float().nan_to_num(0,0,0).abs().max()), 2)) for n, v in
+                  (("attn_o", o), ("tok", tok), ("x_in", xin), ("out", out), ("kc", kc), ("vtc", vtc))}, "ctx_len", td.ctx_len, flush=True)
+        sys.exit(1)
+    return y
+UNetModel.forward_nhwc = checked
+sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-graph"]
+bench.main()
