@@ -236,6 +236,7 @@ typedef struct mdx_st_tail_desc {
     float scale;          /* dim_head ** -0.5 */
     float ln_eps;
     int tile_rows;        /* 32 | 64 */
+    int warm;             /* 0 = no L2 warmer wave (A/B switch), anything else = default */
 } mdx_st_tail_desc;
 int mdx_st_tail_f16(const mdx_st_tail_desc* d, mdx_stream_t s);
 /* 1 if mdx_st_tail_f16 has a kernel for this shape (host only): C = 320 with 5 x 64 or 8 x 40 heads today. */

@@ -44,7 +44,7 @@ class StTailDesc(ctypes.Structure):
         ("ctx_k", c_void_p), ("ctx_vt", c_void_p), ("wstream", c_void_p), ("vec", c_void_p),
         ("colstats_out", c_void_p), ("debug_out", c_void_p), ("debug_stage", c_int),
         ("B", c_int), ("tokens", c_int), ("C", c_int), ("heads", c_int), ("dim_head", c_int),
-        ("ctx_len", c_int), ("ctx_cap", c_int), ("scale", c_float), ("ln_eps", c_float), ("tile_rows", c_int),
+        ("ctx_len", c_int), ("ctx_cap", c_int), ("scale", c_float), ("ln_eps", c_float), ("tile_rows", c_int), ("warm", c_int),
     ]
 
 

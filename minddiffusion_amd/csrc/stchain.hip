@@ -42,7 +42,7 @@ struct StTailParams {
     const float* vec;
     float* colstats_out;
     f16* dbg;
-    int M, HW, TC, ctx_len, heads;
+    int M, HW, TC, ctx_len, heads, nshare, lead;
     float scale_log2, eps;
     int stop_after;
     unsigned wstream_bytes, kc_bytes, vtc_bytes;
@@ -114,8 +114,35 @@ struct VecOff {
                          bpo = 15 * C, total = 16 * C;
 };
 
+// The block barriers of the compute path, in order, with the number of weight pieces (position in a wave's stream) the
+// compute waves have consumed when they arrive at each: the warmer wave executes exactly this sequence.  KEEP IN STEP with the
+// lds_barrier() calls of st_tail_kernel (the debug taps add barriers, and run without the warmer).
+struct BarSched {
+    int n;
+    int pos[24];
+};
+template <int KS, int NH>
+constexpr BarSched make_sched() {
+    BarSched s{};
+    int n = 0, c = 0;
+    s.pos[n++] = c;                              // S0: inputs in LDS
+    c += KS; s.pos[n++] = c; s.pos[n++] = c;     // S1 GEMM -> LayerNorm partials | normalised rows written
+    c += KS; s.pos[n++] = c;                     // S2: q2 in H
+    s.pos[n++] = c;                              // S3: cross-attention output in A
+    c += KS; s.pos[n++] = c; s.pos[n++] = c;     // S4 + LayerNorm
+    for (int ch = 0; ch < 4; ++ch) {
+        c += 2 * KS; s.pos[n++] = c;             // GEGLU chunk in H
+        c += KS;
+        if (NH == 1) s.pos[n++] = c;             // single H buffer: readers done
+    }
+    s.pos[n++] = c;                              // t3 in A
+    c += KS; s.pos[n++] = c; s.pos[n++] = c;     // S6 GEMM (x_in in X) | output rows in H
+    s.n = n;
+    return s;
+}
+
 template <int C, int TM, int D>
-__global__ __launch_bounds__((C / 32) * 64) void st_tail_kernel(const StTailParams p) {
+__global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTailParams p) {
     constexpr int NW = C / 32;
     constexpr int NT = NW * 64;
     constexpr int BM = 32 * TM;
@@ -123,12 +150,14 @@ __global__ __launch_bounds__((C / 32) * 64) void st_tail_kernel(const StTailPara
     constexpr int LDB = LDW * 2;
     constexpr int BUF = BM * LDB;
     constexpr int CPR = C / 8;           // 16-byte chunks per row
+    // the FFN's hidden chunks alternate between two buffers where LDS has room for both (32-row blocks): ONE barrier per chunk
+    constexpr int NH = (TM == 1) ? 2 : 1;
     using V = VecOff<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xb = smem;
     char* Ab = smem + BUF;
     char* Hb = smem + 2 * BUF;
-    float* vec = reinterpret_cast<float*>(smem + 3 * BUF);
+    float* vec = reinterpret_cast<float*>(smem + (2 + NH) * BUF);
     float2* part = reinterpret_cast<float2*>(vec + V::total);   // [NW][BM]
 
     const int tid = threadIdx.x;
@@ -140,6 +169,37 @@ __global__ __launch_bounds__((C / 32) * 64) void st_tail_kernel(const StTailPara
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.wstream, p.wstream_bytes);
     constexpr unsigned PIECES = 3 * (C / 16) + 4 * 3 * (C / 16) + (C / 16);   // per wave
+    if (wave == NW) {
+        // L2 warmer wave (one extra wave per block).  The weights are cold (1.7 GB of other weights stream through the caches
+        // between two uses) and every block reads the SAME stream in lockstep, so without help each piece is a first touch for
+        // its XCD's L2 and the ring runs at the HBM round trip (PF pieces per ~2 us per wave: 61 us per launch against 43 us
+        // with L2-resident weights).  The warmer waves of an XCD's blocks (block b runs on XCD b % 8: an observation used for
+        // speed only) touch the stream between them -- one dword per 64 bytes, 4 KiB per instruction -- LEAD pieces ahead of
+        // the compute waves.  It walks the SAME barrier sequence as the compute waves (BarSched below: a wave that skips
+        // s_barrier holds the whole block at its first barrier until it exits -- measured, +19 us), which is also what paces
+        // it; nothing waits for a touch until the very end (a wave must not exit with loads in flight: its registers are
+        // handed to the next wave while the data is still coming -- measured, a memory fault).
+        if (p.nshare <= 0) return;
+        constexpr BarSched S = make_sched<C / 16, NH>();
+        constexpr unsigned CHUNKS = PIECES / 4;                 // 4 KiB chunks per wave stream
+        const unsigned LEAD = (unsigned)p.lead;
+        unsigned ch = (unsigned)(((int)blockIdx.x >> 3) % p.nshare);
+        unsigned tmp = 0;
+        for (int bi = 0; bi < S.n; ++bi) {
+            const unsigned limit = (unsigned)S.pos[bi] + LEAD;
+            while (ch < CHUNKS * NW) {
+                const unsigned pos = ch / NW, w = ch - pos * NW;    // consumption order: position-major across the waves' streams
+                if (pos * 4u >= limit) break;
+                const char* ptr = p.wstream + ((size_t)(w * PIECES + pos * 4u) * 1024u + (size_t)lane * 64u);
+                asm volatile("global_load_dword %0, %1, off" : "+v"(tmp) : "v"(ptr) : "memory");
+                ch += (unsigned)p.nshare;
+            }
+            asm volatile("s_barrier" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tmp == 0x9e3779b9u && p.M < 0) p.out[0] = (f16)0.f;     // never true: keeps the destination register live
+        return;
+    }
     unsigned piece = (unsigned)wave * PIECES;
     const unsigned voff = (unsigned)lane * 16u;
     u32x4 ring[PF];
@@ -251,15 +311,17 @@ __global__ __launch_bounds__((C / 32) * 64) void st_tail_kernel(const StTailPara
     // ---- S3: cross-attention over the cached context keys: A <- softmax(q2 K^T scale) V, per (head, 32-row tile)
     {
         constexpr int KS = (D + 15) / 16, DT = (D + 31) / 32, KT = 3;
-        const int b = m0 / p.HW;
-        const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(p.kc + (size_t)b * p.TC * C, p.kc_bytes);
-        const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(p.vtc + (size_t)b * C * p.TC, p.vtc_bytes);
+        const int xb = m0 / p.HW;
+        const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(p.kc + (size_t)xb * p.TC * C, p.kc_bytes);
+        const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(p.vtc + (size_t)xb * C * p.TC, p.vtc_bytes);
         const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // pi(l31): bits 2 and 3 swapped (attention.hip)
         const u32x4 zero4 = {0u, 0u, 0u, 0u};
         for (int item = wave; item < p.heads * TM; item += NW) {
             const int h = item / TM, rt = item - h * TM;
             // register budget (168 with three waves per SIMD, 40 of them the weight ring): K fragments die into S^T before
-            // the V^T fragments of d tiles >= 1 are fetched; d tile 0 is fetched under the S^T MFMAs and the softmax
+            // the V^T fragments of d tiles >= 1 are fetched; d tile 0 is fetched under the S^T MFMAs and the softmax.
+            // (Requesting the K fragments before the q2 GEMM was tried: its 12 strided loads sit in front of that GEMM's ring
+            // refills -- loads return in order -- and S2..S4 got 5 us slower for the ~1 us round trip it hid.)
             u32x4 kf[KT][KS], vf[DT][2 * KT];
 #pragma unroll
             for (int t = 0; t < KT; ++t)
@@ -370,11 +432,13 @@ __global__ __launch_bounds__((C / 32) * 64) void st_tail_kernel(const StTailPara
                 f16x4 hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) hv[e] = (f16)((accg[0][i][4 * g + e] + aa[e]) * gelu_tanh_f(accg[1][i][4 * g + e] + gg[e]));
-                *reinterpret_cast<f16x4*>(Hb + epi_off + i * 32 * LDB + g * 16) = hv;
+                *reinterpret_cast<f16x4*>(Hb + (c % NH) * BUF + epi_off + i * 32 * LDB + g * 16) = hv;
             }
         lds_barrier();
-        unit<C, TM, 1>(acc2, Hb + lane_row_off, ring, rs_w, voff, piece);
-        lds_barrier();      // every wave is done reading this chunk of H
+        unit<C, TM, 1>(acc2, Hb + (c % NH) * BUF + lane_row_off, ring, rs_w, voff, piece);
+        // one buffer: every wave must be done reading this chunk before the next one is written.  Two buffers: chunk c + 1 goes
+        // to the other one, whose last readers (ff2 of chunk c - 1) all passed the barrier above before any wave got here
+        if (NH == 1) lds_barrier();
     }
     // t3 = acc2 + b2 + t2 -> A ; X <- x_in rows (residual of proj_out)
     {
@@ -455,7 +519,7 @@ __global__ __launch_bounds__((C / 32) * 64) void st_tail_kernel(const StTailPara
 template <int C, int TM, int D>
 void launch_tail(const StTailParams& p, hipStream_t st) {
     constexpr int NW = C / 32, BM = 32 * TM;
-    constexpr size_t lds = (size_t)3 * BM * (C + 8) * 2 + (size_t)VecOff<C>::total * 4 + (size_t)NW * BM * 8;
+    constexpr size_t lds = (size_t)(TM == 1 ? 4 : 3) * BM * (C + 8) * 2 + (size_t)VecOff<C>::total * 4 + (size_t)NW * BM * 8;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
@@ -463,7 +527,7 @@ void launch_tail(const StTailParams& p, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((st_tail_kernel<C, TM, D>), dim3(p.M / BM), dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((st_tail_kernel<C, TM, D>), dim3(p.M / BM), dim3((NW + 1) * 64), lds, st, p);
 }
 
 }  // namespace
@@ -500,6 +564,16 @@ extern "C" int mdx_st_tail_f16(const mdx_st_tail_desc* d, mdx_stream_t s) {
     p.TC = d->ctx_cap;
     p.ctx_len = d->ctx_len;
     p.heads = d->heads;
+    {
+        // L2 warmer waves: the blocks of an XCD share the touching (<= 32 ways); off for debug taps and tiny launches
+        const int per_xcd = (p.M / d->tile_rows) / 8;
+        p.nshare = (d->debug_out || d->warm == 0 || per_xcd < 4) ? 0 : (per_xcd > 32 ? 32 : per_xcd);
+        p.lead = 80;
+        if (d->warm > 1) {      // tuning: warm = lead * 100 + share ways
+            p.lead = d->warm / 100;
+            if (p.nshare > 0 && d->warm % 100 > 0 && d->warm % 100 < p.nshare) p.nshare = d->warm % 100;
+        }
+    }
     p.scale_log2 = d->scale * 1.4426950408889634f;
     p.eps = d->ln_eps;
     p.stop_after = d->debug_out ? d->debug_stage : 0;

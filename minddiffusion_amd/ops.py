@@ -528,6 +528,7 @@ def make_st_tail_desc(attn_out, tok, x_in, out, ctx_k, ctx_vt, stream, vec, B, t
     d.B, d.tokens, d.C, d.heads, d.dim_head = int(B), int(tokens), int(C), int(heads), int(dim_head)
     d.ctx_len, d.ctx_cap = int(ctx_len), int(ctx_cap)
     d.scale, d.ln_eps, d.tile_rows = float(dim_head) ** -0.5, float(ln_eps), int(tile_rows)
+    d.warm = int(os.environ.get("MDX_ST_TAIL_WARM", "1"))
     return d
 
 
