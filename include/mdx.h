@@ -243,6 +243,37 @@ int mdx_st_tail_f16(const mdx_st_tail_desc* d, mdx_stream_t s);
 int mdx_st_tail_supported(int C, int heads, int dim_head, int tokens_per_sample, int tile_rows);
 size_t mdx_st_tail_stream_bytes(int C);
 
+/* ---- Row-local fused head of a SpatialTransformer block, one launch: SpatialTransformer.norm (GroupNorm(32, eps 1e-6), its
+ *      statistics folded from the producer's column partials) -> proj_in -> BasicTransformerBlock.norm1 -> attn1.to_q | to_k |
+ *      to_v (attention.py:83-84, 212, 241-247, 176, 108-112).
+ * x: fp16 [B * tokens][C] (the block's NHWC input); colstats: [B * nrb][C][2] fp32 = per row block and column {sum, sum of
+ * squares} of x as its producer emitted them (mdx_gemm_desc.colstats_out / mdx_st_tail_desc.colstats_out), nrb row blocks per
+ * sample.  Outputs: tok [M][C] (the token stream = residual of attn1), qk [M][2C] row-major (q | k), vt [B][C][vt_ld] = V
+ * transposed -- the operands of mdx_attention_f16.
+ * wstream: ops.pack_st_head (per wave: proj_in, to_q, to_k, to_v column tiles in MFMA fragment order);
+ * vec fp32 [5C] = [gn gamma | gn beta | b_proj_in | ln1 gamma | ln1 beta].
+ * debug_out / debug_stage (tests): 1 GroupNorm(x), 2 tok, 3 LN1(tok). */
+typedef struct mdx_st_head_desc {
+    const void* x;
+    const float* colstats;
+    int nrb;
+    const void* wstream;
+    const float* vec;
+    void* tok;
+    void* qk;
+    void* vt;
+    int vt_ld;
+    void* debug_out;
+    int debug_stage;
+    int B, tokens, C;
+    float gn_eps, ln_eps;
+    int tile_rows;        /* 32 | 64 */
+    int warm;             /* 0 = no L2 warmer wave (A/B switch) */
+} mdx_st_head_desc;
+int mdx_st_head_f16(const mdx_st_head_desc* d, mdx_stream_t s);
+int mdx_st_head_supported(int C, int tokens_per_sample, int tile_rows);
+size_t mdx_st_head_stream_bytes(int C);
+
 /* ---- timestep_embedding (util.py:111-131): t [M] fp32 -> out [M][dim] fp32 = [cos | sin]. */
 int mdx_timestep_embedding_f32(const float* t, float* out, int M, int dim, float max_period, mdx_stream_t s);
 

@@ -48,6 +48,16 @@ class StTailDesc(ctypes.Structure):
     ]
 
 
+class StHeadDesc(ctypes.Structure):
+    """struct mdx_st_head_desc (include/mdx.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("colstats", c_void_p), ("nrb", c_int), ("wstream", c_void_p), ("vec", c_void_p),
+        ("tok", c_void_p), ("qk", c_void_p), ("vt", c_void_p), ("vt_ld", c_int), ("debug_out", c_void_p), ("debug_stage", c_int),
+        ("B", c_int), ("tokens", c_int), ("C", c_int), ("gn_eps", c_float), ("ln_eps", c_float), ("tile_rows", c_int),
+        ("warm", c_int),
+    ]
+
+
 EPI_NONE, EPI_GEGLU, EPI_GELU, EPI_QUICKGELU = 0, 1, 2, 3
 OUT_ROWMAJOR, OUT_TRANSPOSED = 0, 1
 
@@ -77,6 +87,9 @@ SIGNATURES = {
                                   c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "mdx_attention_causal_f16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,
                                   c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "mdx_st_head_f16": (c_int, [ctypes.POINTER(StHeadDesc), c_void_p]),
+    "mdx_st_head_supported": (c_int, [c_int, c_int, c_int]),
+    "mdx_st_head_stream_bytes": (c_size_t, [c_int]),
     "mdx_st_tail_f16": (c_int, [ctypes.POINTER(StTailDesc), c_void_p]),
     "mdx_st_tail_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "mdx_st_tail_stream_bytes": (c_size_t, [c_int]),

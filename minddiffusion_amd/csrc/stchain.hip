@@ -141,6 +141,35 @@ constexpr BarSched make_sched() {
     return s;
 }
 
+// L2 warmer wave (one extra wave per block of the fused-chain kernels).  The weights are cold (1.7 GB of other weights stream
+// through the caches between two uses) and every block reads the SAME stream in lockstep, so without help each piece is a
+// first touch for its XCD's L2 and the ring runs at the HBM round trip (PF pieces per ~2 us per wave: the tail took 61 us per
+// launch against 43 us with L2-resident weights).  The warmer waves of an XCD's blocks (block b runs on XCD b % 8: an
+// observation used for speed only) touch the stream between them -- one dword per 64 bytes, 4 KiB per instruction -- `lead`
+// pieces ahead of the compute waves.  It walks the SAME barrier sequence as the compute waves (a wave that skips s_barrier
+// holds the whole block at its first barrier until it exits -- measured, +19 us), which is also what paces it; nothing waits
+// for a touch until the very end (a wave must not exit with loads in flight: its registers are handed to the next wave while
+// the data is still coming -- measured, a memory fault).
+template <int NW, unsigned PIECES>
+__device__ __forceinline__ void warmer_wave(const char* wstream, const BarSched& S, int nshare, unsigned lead, int lane) {
+    constexpr unsigned CHUNKS = PIECES / 4;                 // 4 KiB chunks per wave stream
+    unsigned ch = (unsigned)(((int)blockIdx.x >> 3) % nshare);
+    unsigned tmp = 0;
+    for (int bi = 0; bi < S.n; ++bi) {
+        const unsigned limit = (unsigned)S.pos[bi] + lead;
+        while (ch < CHUNKS * NW) {
+            const unsigned pos = ch / NW, w = ch - pos * NW;    // consumption order: position-major across the waves' streams
+            if (pos * 4u >= limit) break;
+            const char* ptr = wstream + ((size_t)(w * PIECES + pos * 4u) * 1024u + (size_t)lane * 64u);
+            asm volatile("global_load_dword %0, %1, off" : "+v"(tmp) : "v"(ptr) : "memory");
+            ch += (unsigned)nshare;
+        }
+        asm volatile("s_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(tmp));     // the destination register stays live until here
+}
+
 template <int C, int TM, int D>
 __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTailParams p) {
     constexpr int NW = C / 32;
@@ -169,35 +198,10 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTail
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.wstream, p.wstream_bytes);
     constexpr unsigned PIECES = 3 * (C / 16) + 4 * 3 * (C / 16) + (C / 16);   // per wave
-    if (wave == NW) {
-        // L2 warmer wave (one extra wave per block).  The weights are cold (1.7 GB of other weights stream through the caches
-        // between two uses) and every block reads the SAME stream in lockstep, so without help each piece is a first touch for
-        // its XCD's L2 and the ring runs at the HBM round trip (PF pieces per ~2 us per wave: 61 us per launch against 43 us
-        // with L2-resident weights).  The warmer waves of an XCD's blocks (block b runs on XCD b % 8: an observation used for
-        // speed only) touch the stream between them -- one dword per 64 bytes, 4 KiB per instruction -- LEAD pieces ahead of
-        // the compute waves.  It walks the SAME barrier sequence as the compute waves (BarSched below: a wave that skips
-        // s_barrier holds the whole block at its first barrier until it exits -- measured, +19 us), which is also what paces
-        // it; nothing waits for a touch until the very end (a wave must not exit with loads in flight: its registers are
-        // handed to the next wave while the data is still coming -- measured, a memory fault).
+    if (wave == NW) {      // L2 warmer wave: same barrier sequence as the compute waves (warmer_wave above)
         if (p.nshare <= 0) return;
         constexpr BarSched S = make_sched<C / 16, NH>();
-        constexpr unsigned CHUNKS = PIECES / 4;                 // 4 KiB chunks per wave stream
-        const unsigned LEAD = (unsigned)p.lead;
-        unsigned ch = (unsigned)(((int)blockIdx.x >> 3) % p.nshare);
-        unsigned tmp = 0;
-        for (int bi = 0; bi < S.n; ++bi) {
-            const unsigned limit = (unsigned)S.pos[bi] + LEAD;
-            while (ch < CHUNKS * NW) {
-                const unsigned pos = ch / NW, w = ch - pos * NW;    // consumption order: position-major across the waves' streams
-                if (pos * 4u >= limit) break;
-                const char* ptr = p.wstream + ((size_t)(w * PIECES + pos * 4u) * 1024u + (size_t)lane * 64u);
-                asm volatile("global_load_dword %0, %1, off" : "+v"(tmp) : "v"(ptr) : "memory");
-                ch += (unsigned)p.nshare;
-            }
-            asm volatile("s_barrier" ::: "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tmp == 0x9e3779b9u && p.M < 0) p.out[0] = (f16)0.f;     // never true: keeps the destination register live
+        warmer_wave<NW, PIECES>(p.wstream, S, p.nshare, (unsigned)p.lead, lane);
         return;
     }
     unsigned piece = (unsigned)wave * PIECES;
@@ -530,6 +534,270 @@ void launch_tail(const StTailParams& p, hipStream_t st) {
     hipLaunchKernelGGL((st_tail_kernel<C, TM, D>), dim3(p.M / BM), dim3((NW + 1) * 64), lds, st, p);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-local fused HEAD of a SpatialTransformer block: SpatialTransformer.norm (GroupNorm, statistics folded from the
+// producer's per-row-block column partials) -> proj_in -> BasicTransformerBlock.norm1 -> attn1.to_q | to_k | to_v, one
+// launch (attention.py:83-84, 212, 241-247, 176, 108-112).  Writes the token stream `tok` (residual of attn1), q | k
+// row-major [M][2C] and V^T [B][C][tokens] -- what mdx_attention_f16 reads.
+struct StHeadParams {
+    const f16* x;
+    const float* cs;         // [B * nrb][C][2] column partials of x from its producer
+    const char* wstream;
+    const float* vec;        // [gn gamma | gn beta | b_proj_in | ln1 gamma | ln1 beta]
+    f16* tok;
+    f16* qk;
+    f16* vt;
+    f16* dbg;
+    int M, HW, nrb, vt_ld, nshare, lead, stop_after;
+    float gn_eps, ln_eps;
+};
+
+template <int KS>
+constexpr BarSched make_head_sched() {
+    BarSched s{};
+    int n = 0, c = 0;
+    s.pos[n++] = c; s.pos[n++] = c; s.pos[n++] = c; s.pos[n++] = c;   // channel sums | read | scale / shift | GroupNorm rows in A
+    c += KS; s.pos[n++] = c; s.pos[n++] = c;             // proj_in GEMM -> LayerNorm partials | LN rows in A, tok in X
+    c += KS; s.pos[n++] = c;                             // q tile staged
+    c += KS; s.pos[n++] = c;                             // k tile staged
+    c += KS; s.pos[n++] = c;                             // v tile staged
+    s.n = n;
+    return s;
+}
+
+template <int C, int TM>
+__global__ __launch_bounds__((C / 32 + 1) * 64) void st_head_kernel(const StHeadParams p) {
+    constexpr int NW = C / 32;
+    constexpr int NT = NW * 64;
+    constexpr int BM = 32 * TM;
+    constexpr int LDW = C + 8;
+    constexpr int LDB = LDW * 2;
+    constexpr int BUF = BM * LDB;
+    constexpr int CPR = C / 8;
+    constexpr int CPG = C / 32;          // channels per GroupNorm group (32 groups)
+    constexpr unsigned PIECES = 4 * (C / 16);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Xb = smem;
+    char* Ab = smem + BUF;
+    char* Hb = smem + 2 * BUF;
+    float* vec = reinterpret_cast<float*>(smem + 3 * BUF);      // [5 C]
+    float2* csum = reinterpret_cast<float2*>(vec + 5 * C);      // [C] channel {sum, sumsq}, then {scale, shift}
+    float2* part = csum + C;                                    // [NW][BM]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = wave * 32;
+    if (wave == NW) {
+        if (p.nshare <= 0) return;
+        constexpr BarSched S = make_head_sched<C / 16>();
+        warmer_wave<NW, PIECES>(p.wstream, S, p.nshare, (unsigned)p.lead, lane);
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.wstream, (unsigned)(NW * PIECES * 1024u));
+    unsigned piece = (unsigned)wave * PIECES;
+    const unsigned voff = (unsigned)lane * 16u;
+    u32x4 ring[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) ring[j] = wload(rs_w, voff, piece + j);
+
+    // ---- rows of x (raw) into registers, vectors into LDS, GroupNorm statistics of this sample from the column partials
+    constexpr int XL = (BM * CPR + NT - 1) / NT;
+    f16x8 xr[XL];
+    {
+        const f16* gx = p.x + (size_t)m0 * C;
+#pragma unroll
+        for (int k = 0; k < XL; ++k) {
+            const int idx = tid + k * NT;
+            if (idx < BM * CPR) xr[k] = *reinterpret_cast<const f16x8*>(gx + (size_t)(idx / CPR) * C + (idx % CPR) * 8);
+        }
+        for (int idx = tid; idx < 5 * C / 4; idx += NT)
+            reinterpret_cast<float4*>(vec)[idx] = reinterpret_cast<const float4*>(p.vec)[idx];
+        const int b = m0 / p.HW;
+        const int c = tid >> 1, half = tid & 1;       // NT == 2 C: two threads per channel, half of the row blocks each
+        const float2* src = reinterpret_cast<const float2*>(p.cs) + (size_t)b * p.nrb * C + c;
+        const int k0 = half * ((p.nrb + 1) >> 1), k1 = half ? p.nrb : ((p.nrb + 1) >> 1);
+        float su = 0.f, sq = 0.f;
+        for (int k = k0; k < k1; ++k) {
+            const float2 v = src[(size_t)k * C];
+            su += v.x;
+            sq += v.y;
+        }
+        su += __shfl_xor(su, 1, 64);
+        sq += __shfl_xor(sq, 1, 64);
+        if (half == 0) csum[c] = make_float2(su, sq);
+    }
+    lds_barrier();
+    {
+        const int c = tid >> 1;
+        const int g = c / CPG;
+        float su = 0.f, sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < CPG; ++e) {
+            const float2 v = csum[g * CPG + e];
+            su += v.x;
+            sq += v.y;
+        }
+        const float inv = 1.0f / ((float)CPG * (float)p.HW);
+        const float mean = su * inv;
+        float var = sq * inv - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        const float a = vec[c] * rsqrtf(var + p.gn_eps);
+        const float sh = vec[C + c] - mean * a;
+        lds_barrier();          // every thread has read the channel sums
+        if ((tid & 1) == 0) csum[c] = make_float2(a, sh);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < XL; ++k) {
+        const int idx = tid + k * NT;
+        if (idx < BM * CPR) {
+            const int row = idx / CPR, ch = idx - row * CPR;
+            f16x8 y;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float2 ss = csum[ch * 8 + e];
+                y[e] = (f16)((float)xr[k][e] * ss.x + ss.y);
+            }
+            *reinterpret_cast<f16x8*>(Ab + row * LDB + ch * 16) = y;
+        }
+    }
+    lds_barrier();
+
+    const int lane_row_off = l31 * LDB + hi * 16;
+    const int epi_off = l31 * LDB + (n0 + 4 * hi) * 2;
+    auto dump = [&](const char* buf) {
+        lds_barrier();
+        for (int idx = tid; idx < BM * CPR; idx += NT) {
+            const int row = idx / CPR, ch = idx - row * CPR;
+            *reinterpret_cast<f16x8*>(p.dbg + (size_t)(m0 + row) * C + ch * 8) =
+                *reinterpret_cast<const f16x8*>(buf + row * LDB + ch * 16);
+        }
+    };
+    if (p.stop_after == 1) { dump(Ab); return; }
+
+    // ---- proj_in: tok = GN(x) Wpi^T + b ; X <- tok ; A <- LN1(tok)
+    f32x16 acc[1][TM];
+    zero_acc(acc);
+    unit<C, TM, 1>(acc, Ab + lane_row_off, ring, rs_w, voff, piece);
+    {
+        const float* bias = vec + 2 * C;
+        const float* gamma = vec + 3 * C;
+        const float* beta = vec + 4 * C;
+        f16x4 th[TM][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float su = 0.f, sq = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bb = *reinterpret_cast<const float4*>(bias + n0 + 8 * g + 4 * hi);
+                const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f16 h = (f16)(acc[0][i][4 * g + e] + b4[e]);
+                    th[i][g][e] = h;
+                    const float f = (float)h;
+                    su += f;
+                    sq += f * f;
+                }
+            }
+            su += __shfl_xor(su, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (hi == 0) part[wave * BM + i * 32 + l31] = make_float2(su, sq);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float su = 0.f, sq = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float2 v = part[w * BM + i * 32 + l31];
+                su += v.x;
+                sq += v.y;
+            }
+            const float mean = su * (1.0f / C);
+            float var = sq * (1.0f / C) - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            const float rstd = rsqrtf(var + p.ln_eps);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 ga = *reinterpret_cast<const float4*>(gamma + n0 + 8 * g + 4 * hi);
+                const float4 be = *reinterpret_cast<const float4*>(beta + n0 + 8 * g + 4 * hi);
+                const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
+                f16x4 xn;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xn[e] = (f16)(((float)th[i][g][e] - mean) * rstd * g4[e] + b4[e]);
+                *reinterpret_cast<f16x4*>(Ab + epi_off + i * 32 * LDB + g * 16) = xn;
+                *reinterpret_cast<f16x4*>(Xb + epi_off + i * 32 * LDB + g * 16) = th[i][g];
+            }
+        }
+        lds_barrier();
+    }
+    if (p.stop_after == 2) { dump(Xb); return; }
+    if (p.stop_after == 3) { dump(Ab); return; }
+    // token rows -> global (the residual stream the tail reads)
+    for (int idx = tid; idx < BM * CPR; idx += NT) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        *reinterpret_cast<f16x8*>(p.tok + (size_t)(m0 + row) * C + ch * 8) = *reinterpret_cast<const f16x8*>(Xb + row * LDB + ch * 16);
+    }
+
+    // ---- q | k | v tiles: GEMM -> staging buffer (H, X, H) -> coalesced stores; V goes out transposed
+    auto stage_tile = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f16x4*>(buf + epi_off + i * 32 * LDB + g * 16) =
+                    f16x4{(f16)acc[0][i][4 * g], (f16)acc[0][i][4 * g + 1], (f16)acc[0][i][4 * g + 2], (f16)acc[0][i][4 * g + 3]};
+        lds_barrier();
+    };
+    auto store_rows = [&](const char* buf, int col0) {
+        for (int idx = tid; idx < BM * CPR; idx += NT) {
+            const int row = idx / CPR, ch = idx - row * CPR;
+            *reinterpret_cast<f16x8*>(p.qk + (size_t)(m0 + row) * (2 * C) + col0 + ch * 8) =
+                *reinterpret_cast<const f16x8*>(buf + row * LDB + ch * 16);
+        }
+    };
+    zero_acc(acc);
+    unit<C, TM, 1>(acc, Ab + lane_row_off, ring, rs_w, voff, piece);
+    stage_tile(Hb);
+    store_rows(Hb, 0);
+    zero_acc(acc);
+    unit<C, TM, 1>(acc, Ab + lane_row_off, ring, rs_w, voff, piece);
+    stage_tile(Xb);          // (every thread finished copying tok out of X before the barrier inside the q stage)
+    store_rows(Xb, C);
+    zero_acc(acc);
+    unit<C, TM, 1>(acc, Ab + lane_row_off, ring, rs_w, voff, piece);
+    stage_tile(Hb);          // (the q rows were copied out of H before the barrier inside the k stage)
+    {
+        const int b = m0 / p.HW, tok0 = m0 - b * p.HW;
+        constexpr int JC = BM / 8;       // 8-token chunks per channel
+        for (int idx = tid; idx < C * JC; idx += NT) {
+            const int c = idx / JC, j = idx - c * JC;
+            f16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const f16*>(Hb + (j * 8 + e) * LDB + c * 2);
+            *reinterpret_cast<f16x8*>(p.vt + ((size_t)b * C + c) * p.vt_ld + tok0 + j * 8) = v;
+        }
+    }
+}
+
+template <int C, int TM>
+void launch_head(const StHeadParams& p, hipStream_t st) {
+    constexpr int NW = C / 32, BM = 32 * TM;
+    constexpr size_t lds = (size_t)3 * BM * (C + 8) * 2 + (size_t)5 * C * 4 + (size_t)C * 8 + (size_t)NW * BM * 8;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&st_head_kernel<C, TM>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((st_head_kernel<C, TM>), dim3(p.M / BM), dim3((NW + 1) * 64), lds, st, p);
+}
 }  // namespace
 
 extern "C" size_t mdx_st_tail_stream_bytes(int C) { return (size_t)(C / 32) * (16 * (C / 16)) * 1024; }
@@ -587,5 +855,44 @@ extern "C" int mdx_st_tail_f16(const mdx_st_tail_desc* d, mdx_stream_t s) {
         if (d->tile_rows == 64) launch_tail<320, 2, 40>(p, st); else launch_tail<320, 1, 40>(p, st);
     }
     MDX_LAUNCH_CHECK("mdx_st_tail_f16");
+    return MDX_OK;
+}
+
+extern "C" size_t mdx_st_head_stream_bytes(int C) { return (size_t)(C / 32) * (4 * (C / 16)) * 1024; }
+
+extern "C" int mdx_st_head_supported(int C, int tokens_per_sample, int tile_rows) {
+    return C == 320 && (tile_rows == 32 || tile_rows == 64) && tokens_per_sample > 0 && tokens_per_sample % tile_rows == 0 &&
+           tokens_per_sample % 8 == 0;
+}
+
+extern "C" int mdx_st_head_f16(const mdx_st_head_desc* d, mdx_stream_t s) {
+    MDX_REQUIRE(d && d->x && d->colstats && d->wstream && d->vec && d->tok && d->qk && d->vt, "mdx_st_head_f16: null pointer");
+    MDX_REQUIRE(mdx_st_head_supported(d->C, d->tokens, d->tile_rows), "mdx_st_head_f16: unsupported shape C=%d tokens=%d tile_rows=%d",
+                d->C, d->tokens, d->tile_rows);
+    MDX_REQUIRE(d->B > 0 && d->nrb > 0 && d->vt_ld >= d->tokens && d->vt_ld % 8 == 0, "mdx_st_head_f16: bad extents");
+    StHeadParams p{};
+    p.x = (const f16*)d->x;
+    p.cs = d->colstats;
+    p.wstream = (const char*)d->wstream;
+    p.vec = d->vec;
+    p.tok = (f16*)d->tok;
+    p.qk = (f16*)d->qk;
+    p.vt = (f16*)d->vt;
+    p.dbg = (f16*)d->debug_out;
+    p.M = d->B * d->tokens;
+    p.HW = d->tokens;
+    p.nrb = d->nrb;
+    p.vt_ld = d->vt_ld;
+    p.stop_after = d->debug_out ? d->debug_stage : 0;
+    p.gn_eps = d->gn_eps;
+    p.ln_eps = d->ln_eps;
+    {
+        const int per_xcd = (p.M / d->tile_rows) / 8;
+        p.nshare = (d->debug_out || d->warm == 0 || per_xcd < 4) ? 0 : (per_xcd > 32 ? 32 : per_xcd);
+        p.lead = 80;
+    }
+    hipStream_t st = (hipStream_t)s;
+    if (d->tile_rows == 64) launch_head<320, 2>(p, st); else launch_head<320, 1>(p, st);
+    MDX_LAUNCH_CHECK("mdx_st_head_f16");
     return MDX_OK;
 }

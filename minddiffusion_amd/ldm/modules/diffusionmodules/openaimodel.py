@@ -360,6 +360,11 @@ class UNetModel:
                             po.reshape(po.shape[0], po.shape[1]),
                             w[t + "attn1.o.b"], w[t + "norm2.g"], w[t + "norm2.b"], w[t + "attn2.o.b"], w[t + "norm3.g"],
                             w[t + "norm3.b"], gb, w[t + "ff2.b"], w[pre + "proj_out.b"])
+                        if ops.st_head_supported(inner, 64, 64):
+                            pi = self._dev(P[pre + "proj_in.weight"], f16)
+                            w[t + "head.stream"], w[t + "head.vec"] = ops.pack_st_head(
+                                pi.reshape(pi.shape[0], pi.shape[1]), wq, wk, wv, w[pre + "norm.g"], w[pre + "norm.b"],
+                                w[pre + "proj_in.b"], w[t + "norm1.g"], w[t + "norm1.b"])
             elif kind == "down" and self.conv_resample:
                 w[pre + "w"] = self._pack_conv(P[pre + "op.conv.weight"])
                 w[pre + "b"] = self._dev(P[pre + "op.conv.bias"], f32)
@@ -392,7 +397,7 @@ class UNetModel:
     class _Plan:
         pass
 
-    def _plan(self, B, H, W):
+    def _plan(self, B, H, W, _fuse_head=True):
         key = (B, H, W)
         if key in self._plans:
             return self._plans[key]
@@ -533,6 +538,37 @@ class UNetModel:
                     return r
             return 0
 
+        heads_fused = []
+
+        def head_rows(t, x, n, heads, dh):
+            """Rows per block of the fused SpatialTransformer head (GroupNorm .. q|k|v^T), or 0.  Only together with the fused
+            tail, and only when x's producer is a GEMM / conv launch (its epilogue supplies the GroupNorm column partials)."""
+            if not _fuse_head or (t + "head.stream") not in w or ops.get_option("unet_st_head") == 0:
+                return 0
+            r = tail_rows(t, n, heads, dh)
+            if not r or not ops.st_head_supported(heads * dh, n, r) or producer.get(x.data_ptr()) is None:
+                return 0
+            return r
+
+        def fused_tail(t, rows_t, o, tok, x, ch, inner, heads, dh, n):
+            """Everything after the self-attention core of block `t` + proj_out + the residual: ONE row-local launch."""
+            kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
+            vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
+            ctx_kv[t] = (kc, vtc)
+            out = A.get((B, n, ch))
+            td = ops.make_st_tail_desc(o, tok, x, out, kc, vtc, w[t + "tail.stream"], w[t + "tail.vec"], B, n, ch, heads,
+                                       dh, 1, TC, tile_rows=rows_t)
+            tails.append(td)
+            td._bufs = (o, tok, x, out, kc, vtc)      # keeps the views alive; tools / tests read them
+            producer[out.data_ptr()] = td
+
+            def run_tail(td=td):
+                td.ctx_len = P.ctx_len      # read at call time like the attention ops; a captured graph bakes it in
+                ops.st_tail_run(td)
+            emit(run_tail, "gemm", 2 * B * n * 16 * inner * inner + 4 * B * heads * n * 77 * dh, 1,
+                 f"st_tail M={B * n} C={inner} rows={rows_t} (to_out1..proj_out fused)")
+            return out
+
         def stats_buf(rows, width):
             """{sum, sumsq} per 64-column slice of a token row: written by the GEMM that produces the rows, read by the
             GEMM that consumes LayerNorm(rows) (mdx_gemm_desc.stats_out / ln_stats).  One buffer per shape: the stream is
@@ -593,10 +629,33 @@ class UNetModel:
             n = h * wd
             inner = heads * dh
             scale = dh ** -0.5
+            t0 = pre + "transformer_blocks.0."
+            rows_h = head_rows(t0, x, n, heads, dh)
+            if rows_h:
+                # fused head + fused tail: GroupNorm .. q|k|v^T in one launch, the attention core, to_out1 .. proj_out in one
+                tok = A.get((B, n, inner))
+                qk = A.get((B, n, 2 * inner))
+                vt = A.get((B, inner, n))
+                hd = ops.make_st_head_desc(x, x, 1, w[t0 + "head.stream"], w[t0 + "head.vec"], tok, qk, vt, n, B, n, ch,
+                                           tile_rows=rows_h)
+                hd.colstats = 0      # wired by ops.wire_groupnorm_colstats from x's producer (or the plan is rebuilt without it)
+                heads_fused.append(hd)
+                hd._bufs = (x, tok, qk, vt)
+                gn_calls.append(dict(x1=x, x2=None, head=hd, meta=len(meta), film=False,
+                                     prod=(producer.get(x.data_ptr()), None)))
+                emit(lambda hd=hd: ops.st_head_run(hd), "gemm", 2 * B * n * 4 * inner * inner, 1,
+                     f"st_head M={B * n} C={inner} rows={rows_h} (GroupNorm..q|k|v fused)")
+                o = A.get((B, n, inner))
+                emit(lambda qk=qk, vt=vt, o=o: ops.attention(
+                    qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
+                    n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner),
+                    "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
+                out = fused_tail(t0, tail_rows(t0, n, heads, dh), o, tok, x, ch, inner, heads, dh, n)
+                A.release(qk); A.release(vt); A.release(tok); A.release(o)
+                return out
             a = A.get((B, n, ch))
             add_gn(x, None, w[pre + "norm.g"], w[pre + "norm.b"], 1e-6, False, a)
             # LayerNorm fold: `st` receives the row statistics from each producer of the token stream
-            t0 = pre + "transformer_blocks.0."
             st = stats_buf(B * n, inner) if (t0 + "attn2.q.s") in w else None
             fold1 = st is not None and (t0 + "attn1.qkv.s") in w
 
@@ -629,22 +688,7 @@ class UNetModel:
                     "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
                 rows_t = tail_rows(t, n, heads, dh)
                 if rows_t:
-                    # everything after the self-attention core of this block + proj_out + the residual: ONE row-local launch
-                    kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
-                    vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
-                    ctx_kv[t] = (kc, vtc)
-                    out = A.get((B, n, ch))
-                    td = ops.make_st_tail_desc(o, tok, x, out, kc, vtc, w[t + "tail.stream"], w[t + "tail.vec"], B, n, ch, heads,
-                                               dh, 1, TC, tile_rows=rows_t)
-                    tails.append(td)
-                    td._bufs = (o, tok, x, out, kc, vtc)      # keeps the views alive; tools / tests read them
-                    producer[out.data_ptr()] = td
-
-                    def run_tail(td=td):
-                        td.ctx_len = P.ctx_len      # read at call time like the attention ops; a captured graph bakes it in
-                        ops.st_tail_run(td)
-                    emit(run_tail, "gemm", 2 * B * n * 16 * inner * inner + 4 * B * heads * n * 77 * dh, 1,
-                         f"st_tail M={B * n} C={inner} rows={rows_t} (to_out1..proj_out fused)")
+                    out = fused_tail(t, rows_t, o, tok, x, ch, inner, heads, dh, n)
                     A.release(qk); A.release(vt); A.release(tok); A.release(ln)
                     return out
                 tok2 = dense(main, o, B, n, inner, inner, w[t + "attn1.o.w"], bias=w[t + "attn1.o.b"], residual=tok,
@@ -796,6 +840,10 @@ class UNetModel:
                 L = cpg // math.gcd(cpg, 8)
                 if L <= 64 and HW * L * 16 <= (64 << 10):
                     meta[c["meta"]]["launches"] = 1
+        if any(not hd.colstats for hd in heads_fused):
+            # a fused head whose input tensor's producer cannot emit column statistics in its final launch form: plan again
+            # with the unfused GroupNorm / proj_in / qkv launches (plans are built once per shape)
+            return self._plan(B, H, W, _fuse_head=False)
         ops.account_gemm_launches(meta)     # last: the column-statistics wiring above can change a launch's table row
         P.main, P.ctxops, P.descs, P.meta = main, ctxops, descs, meta
         assert len(main) == len(meta)
@@ -803,6 +851,7 @@ class UNetModel:
         P.ln_stats = ln_stats
         P.arena = A   # owns the activation buffers (descriptors only hold raw device pointers)
         P.tails = tails
+        P.heads_fused = heads_fused
         P.ctx_kv = ctx_kv     # the cached context K / V^T buffers: descriptors hold raw pointers only
         P.graph = None
         P.graph_failed = False

@@ -15,7 +15,8 @@ f32 = torch.float32
 # Library-level options (experiment / tuning switches that used to be environment variables read inside the library):
 # one explicit table instead of getenv() calls scattered through the code.
 # -1 auto | 0 never | 32 | 64 rows per block of the fused SpatialTransformer tail (MDX_UNET_ST_TAIL presets it for A/B runs)
-_OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1"))}
+_OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
+            "unet_st_head": int(os.environ.get("MDX_UNET_ST_HEAD", "-1"))}     # 0 = keep GroupNorm / proj_in / qkv unfused
 
 
 def set_option(name, value):
@@ -431,10 +432,11 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
     import math
     for c in gn_calls:
         _, HW, C1 = c["x1"].shape
+        is_head = c.get("head") is not None     # fused SpatialTransformer head: the statistics feed that launch
         C2 = 0 if c["x2"] is None else c["x2"].shape[2]
         cpg = (C1 + C2) // 32
         L = cpg // math.gcd(cpg, 8)           # chunk columns of the minimal whole-group column block
-        if L <= 64 and HW * L * 16 <= (64 << 10):
+        if not is_head and L <= 64 and HW * L * 16 <= (64 << 10):
             meta[c["meta"]]["launches"] = 1   # the one-launch fused kernel (norm.hip groupnorm_impl)
             continue
 
@@ -459,7 +461,7 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
             # launch will make (a 64-row split-K reduce writing into a buffer sized for 128-row tiles).
             d.colstats_out = 8
             rows = gemm_query(d)[5]
-            if rows <= 0 or HW % rows or HW // rows > 64:
+            if rows <= 0 or HW % rows or (HW // rows > 64 and not is_head):
                 d.colstats_out = 0
                 return None      # (> 64 row blocks per sample: the fold in every gn_apply block would outweigh the pass it saves --
                                  #  measured on the 256x256 / 128x128 levels of the GLIDE up-sampler, profiles/r02_e_ab.txt)
@@ -468,6 +470,10 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
             table[key] = (buf, HW // rows)
             return table[key]
         s1 = stats_of(c["prod"][0], C1)
+        if is_head:
+            if s1 is not None:
+                c["head"].colstats, c["head"].nrb = s1[0].data_ptr(), int(s1[1])
+            continue
         s2 = stats_of(c["prod"][1], C2) if C2 else (None, 0)
         if s1 is None or s2 is None:
             continue
@@ -534,3 +540,34 @@ def make_st_tail_desc(attn_out, tok, x_in, out, ctx_k, ctx_vt, stream, vec, B, t
 
 def st_tail_run(desc):
     _lib.check(_lib.load().mdx_st_tail_f16(ctypes.byref(desc), _stream()), "mdx_st_tail_f16")
+
+
+def pack_st_head(wpi, wq, wk, wv, gn_g, gn_b, bpi, g1, be1):
+    """Weights / vectors of the fused SpatialTransformer head (mdx_st_head_f16): per wave its proj_in, to_q, to_k, to_v column
+    tiles as one contiguous stream of MFMA-fragment pieces.  Returns (stream fp16 [C/32, 4 C/16, 512], vec fp32 [5 C])."""
+    f = pack_frag_weight
+    stream = torch.cat([f(wpi), f(wq), f(wk), f(wv)], 1).contiguous()
+    vec = torch.cat([t.to(f32).reshape(-1) for t in (gn_g, gn_b, bpi, g1, be1)]).contiguous()
+    return stream, vec
+
+
+def st_head_supported(C, tokens, tile_rows):
+    return bool(_lib.load().mdx_st_head_supported(int(C), int(tokens), int(tile_rows)))
+
+
+def make_st_head_desc(x, colstats, nrb, stream, vec, tok, qk, vt, vt_ld, B, tokens, C, tile_rows=32, gn_eps=1e-6, ln_eps=1e-5,
+                      debug_out=None, debug_stage=0):
+    d = _lib.StHeadDesc()
+    d.x, d.colstats, d.nrb = x.data_ptr(), colstats.data_ptr(), int(nrb)
+    d.wstream, d.vec = stream.data_ptr(), vec.data_ptr()
+    d.tok, d.qk, d.vt, d.vt_ld = tok.data_ptr(), qk.data_ptr(), vt.data_ptr(), int(vt_ld)
+    d.debug_out = 0 if debug_out is None else debug_out.data_ptr()
+    d.debug_stage = int(debug_stage)
+    d.B, d.tokens, d.C = int(B), int(tokens), int(C)
+    d.gn_eps, d.ln_eps, d.tile_rows = float(gn_eps), float(ln_eps), int(tile_rows)
+    d.warm = int(os.environ.get("MDX_ST_TAIL_WARM", "1"))
+    return d
+
+
+def st_head_run(desc):
+    _lib.check(_lib.load().mdx_st_head_f16(ctypes.byref(desc), _stream()), "mdx_st_head_f16")

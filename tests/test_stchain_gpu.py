@@ -217,3 +217,86 @@ def test_st_tail_rejects_bad_arguments(ops):
         run_fused(ops, w, x, B, tokens, C, heads, 81, 64)               # ctx_len > capacity
     assert not ops.st_tail_supported(640, 10, 64, 1024, 64)
     assert ops.st_tail_supported(320, 8, 40, 4096, 64)
+
+
+# --------------------------------------------------------------------------- fused head (mdx_st_head_f16)
+def group_norm_rows(x, B, tokens, C, g, b, eps, groups=32):
+    """GroupNorm(32) of NHWC rows [B * tokens, C] (util.py:87-108; biased variance)."""
+    xr = x.reshape(B, tokens, groups, C // groups)
+    mu = xr.mean(axis=(1, 3), keepdims=True)
+    var = ((xr - mu) ** 2).mean(axis=(1, 3), keepdims=True)
+    return ((xr - mu) / np.sqrt(var + eps)).reshape(B * tokens, C) * g + b
+
+
+def make_head_case(seed, B, tokens, C):
+    rng = np.random.RandomState(seed)
+    w = {n: h16(rng.standard_normal((C, C)) / np.sqrt(C)) for n in ("pi", "q", "k", "v")}
+    for n in ("gn_b", "bpi", "be1"):
+        w[n] = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    for n in ("gn_g", "g1"):
+        w[n] = (1.0 + 0.2 * rng.standard_normal(C)).astype(np.float32)
+    # per-channel offsets and scales so that the GroupNorm statistics matter
+    x = h16(rng.standard_normal((B * tokens, C)) * (0.5 + rng.rand(C)) + rng.standard_normal(C))
+    return w, x
+
+
+def head_ref(w, x, B, tokens, C, round16):
+    r = (lambda a: h16(a).astype(np.float64)) if round16 else (lambda a: a)
+    f = lambda a: np.asarray(a, np.float64)
+    st = {}
+    st[1] = r(group_norm_rows(f(x), B, tokens, C, f(w["gn_g"]), f(w["gn_b"]), 1e-6))
+    st[2] = r(st[1] @ f(w["pi"]).T + f(w["bpi"]))
+    st[3] = r(layer_norm(st[2], f(w["g1"]), f(w["be1"]), 1e-5))
+    st["q"], st["k"], st["v"] = (r(st[3] @ f(w[n]).T) for n in ("q", "k", "v"))
+    return st
+
+
+def run_head(ops, w, x, B, tokens, C, tile_rows, rows_per_stat_block, stage=0):
+    M = B * tokens
+    xd = dev16(x)
+    stream, vec = ops.pack_st_head(*(dev16(w[n]) for n in ("pi", "q", "k", "v")),
+                                   *(dev32(w[n]) for n in ("gn_g", "gn_b", "bpi", "g1", "be1")))
+    nrb = tokens // rows_per_stat_block
+    blk = xd.float().reshape(B * nrb, rows_per_stat_block, C)          # what the producer's epilogue would have emitted
+    cs = torch.stack([blk.sum(1), (blk * blk).sum(1)], 2).contiguous()
+    tok = torch.full((M, C), float("nan"), dtype=torch.float16, device=DEV)
+    qk = torch.full((M, 2 * C), float("nan"), dtype=torch.float16, device=DEV)
+    vt = torch.full((B, C, tokens), float("nan"), dtype=torch.float16, device=DEV)
+    dbg = torch.full((M, C), float("nan"), dtype=torch.float16, device=DEV) if stage else None
+    d = ops.make_st_head_desc(xd, cs, nrb, stream, vec, tok, qk, vt, tokens, B, tokens, C, tile_rows=tile_rows, debug_out=dbg,
+                              debug_stage=stage)
+    ops.st_head_run(d)
+    torch.cuda.synchronize()
+    return dbg if stage else (tok, qk, vt)
+
+
+@pytest.mark.parametrize("tile_rows", [32, 64])
+def test_st_head_vs_reference(ops, tile_rows):
+    """GroupNorm (statistics from per-row-block column partials) -> proj_in -> LayerNorm -> q | k | V^T against the fp16-storage
+    restatement stage by stage (1e-3) and the all-fp32 restatement (3e-3); B = 2 so that the per-sample statistics and the V^T
+    addressing are exercised, 128-row statistic blocks as a HALO conv producer emits them."""
+    B, tokens, C = 2, 1024, 320
+    w, x = make_head_case(5, B, tokens, C)
+    ref16, ref32 = head_ref(w, x, B, tokens, C, True), head_ref(w, x, B, tokens, C, False)
+    for stage, name in ((1, "groupnorm"), (2, "tok"), (3, "ln1")):
+        got = run_head(ops, w, x, B, tokens, C, tile_rows, 128, stage)
+        check(f"st_head_r{tile_rows}_{name}_vs_fp16ref", got, ref16[stage], rel_l2=1e-3, max_rel=6e-3)
+    tok, qk, vt = run_head(ops, w, x, B, tokens, C, tile_rows, 128)
+    check(f"st_head_r{tile_rows}_tok", tok, ref16[2], rel_l2=1e-3, max_rel=6e-3)
+    check(f"st_head_r{tile_rows}_q", qk[:, :C], ref16["q"], rel_l2=1e-3, max_rel=6e-3)
+    check(f"st_head_r{tile_rows}_k", qk[:, C:], ref16["k"], rel_l2=1e-3, max_rel=6e-3)
+    vref = ref16["v"].reshape(B, tokens, C).transpose(0, 2, 1)
+    check(f"st_head_r{tile_rows}_vt", vt, vref, rel_l2=1e-3, max_rel=6e-3)
+    check(f"st_head_r{tile_rows}_q_vs_fp32ref", qk[:, :C], ref32["q"], rel_l2=3e-3)
+    check(f"st_head_r{tile_rows}_vt_vs_fp32ref", vt, ref32["v"].reshape(B, tokens, C).transpose(0, 2, 1), rel_l2=3e-3)
+
+
+def test_st_head_statistic_block_sizes(ops):
+    """The fold must not depend on how the producer cut the rows: 32-row blocks (a fused tail upstream), 64, and one block
+    per sample give the same normalised rows."""
+    B, tokens, C = 2, 256, 320
+    w, x = make_head_case(9, B, tokens, C)
+    ref16 = head_ref(w, x, B, tokens, C, True)
+    for rows in (32, 64, 256):
+        got = run_head(ops, w, x, B, tokens, C, 32, rows, 1)
+        check(f"st_head_stats_rows{rows}", got, ref16[1], rel_l2=1e-3, max_rel=6e-3)
