@@ -45,6 +45,13 @@ typedef void* mdx_stream_t; /* hipStream_t */
 
 int mdx_version(void);
 const char* mdx_last_error(void);
+/* Tuning / experiment switches of the library (process-global ints; defaults = what the product runs; set before the first
+ * launch they affect, not thread safe).  The library itself reads NO environment variables.  Names:
+ *   gemm_tuned (1)  gemm_bm (0 = auto)  gemm_bn (0)  gemm_ring (0 = auto, 2..5)  gemm_halo (1)  gemm_halo8 (1)
+ *   gemm_splitk_fixup_max (4)  gemm_spread (1)  halo_nsb (0 = auto)  gn_min_blocks (512)  gn_fused (1)
+ * Unknown names return MDX_E_INVALID. */
+int mdx_set_option(const char* name, int value);
+int mdx_get_option(const char* name, int* value);
 
 /* ---- layout boundary: LatentDiffusion.apply_model casts/wraps (ldm/models/diffusion/ddpm.py:290-306) */
 /* x [B][C][H][W] fp32 -> y [B][H*W][Cpad] fp16, channels C..Cpad-1 zero-filled. */
@@ -111,9 +118,10 @@ typedef struct mdx_gemm_desc {
                              kernel: every (tile, split) block parks its fp32 partial in the workspace and takes a ticket on
                              the tile's arrival counter; the block that completes a tile sums the partials in split order and
                              runs the epilogue (no reduce launch).  The counters are the first MDX_GEMM_WS_HEAD bytes of the
-                             workspace: they must be ZERO when the workspace is first handed to the library (every launch
-                             leaves them zero again) and nothing else may write them; a workspace may be shared by
-                             launches on ONE stream.  Transposed-output split launches use [split][M][N] slabs + a reduce
+                             workspace.  The library zeroes them itself (hipMemsetAsync on the caller's stream) the first time it
+                             sees a workspace ADDRESS, and every launch leaves them zero again; nothing else may write them.  A
+                             caller that frees a workspace and reuses the address for another one must zero the head itself.  A
+                             workspace may be shared by launches on ONE stream only (two streams would race on the counters).  Transposed-output split launches use [split][M][N] slabs + a reduce
                              launch as before (no counters). */
     size_t workspace_bytes;
     long out_bs;          /* row-major only: element stride between samples (0 = dense); lets a projection write

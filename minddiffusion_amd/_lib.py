@@ -65,6 +65,8 @@ OUT_ROWMAJOR, OUT_TRANSPOSED = 0, 1
 SIGNATURES = {
     "mdx_version": (c_int, []),
     "mdx_last_error": (ctypes.c_char_p, []),
+    "mdx_set_option": (c_int, [ctypes.c_char_p, c_int]),
+    "mdx_get_option": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int)]),
     "mdx_nchw_to_nhwc_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mdx_nhwc_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mdx_groupnorm_ws_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -116,6 +118,13 @@ SIGNATURES = {
 }
 
 _lib = None
+_ENV_OPTIONS = {
+    "MDX_GEMM_TUNED": ("gemm_tuned", int), "MDX_GEMM_BM": ("gemm_bm", int), "MDX_GEMM_BN": ("gemm_bn", int),
+    "MDX_GEMM_CFG": ("gemm_ring", lambda v: int(v.split(",")[-1])), "MDX_GEMM_HALO": ("gemm_halo", int),
+    "MDX_GEMM_HALO8": ("gemm_halo8", int), "MDX_GEMM_SPLITK_FIXUP_MAX": ("gemm_splitk_fixup_max", int),
+    "MDX_GEMM_SPREAD": ("gemm_spread", int), "MDX_HALO_NSB": ("halo_nsb", int), "MDX_GN_MIN_BLOCKS": ("gn_min_blocks", int),
+    "MDX_GN_FUSED": ("gn_fused", int),
+}
 
 
 def load():
@@ -138,6 +147,13 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # The library reads no environment variables (include/mdx.h: mdx_set_option).  The MDX_* variables the tools and the
+    # experiment scripts under tools/exp/ pass are translated HERE, once, at load time.
+    for env, (name, conv) in _ENV_OPTIONS.items():
+        if env in os.environ:
+            rc = lib.mdx_set_option(name.encode(), conv(os.environ[env]))
+            if rc != 0:
+                raise MdxError(f"{env}: {lib.mdx_last_error().decode()}")
     return lib
 
 

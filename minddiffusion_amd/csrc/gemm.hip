@@ -27,6 +27,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
+#include <unordered_set>
 
 namespace {
 
@@ -1316,8 +1318,7 @@ int tuned_variant(const GemmParams& p) {
 bool halo_eligible(const GemmParams& p, int bm);
 
 const TunedEntry* lookup_tuned(const GemmParams& p) {
-    static const bool use_table = !(getenv("MDX_GEMM_TUNED") && atoi(getenv("MDX_GEMM_TUNED")) == 0) &&
-                                  !getenv("MDX_GEMM_BM") && !getenv("MDX_GEMM_BN");
+    const bool use_table = mdx_opt(MDX_OPT_GEMM_TUNED) && !mdx_opt(MDX_OPT_GEMM_BM) && !mdx_opt(MDX_OPT_GEMM_BN);
     if (!use_table || p.bn_hint || p.st_hint || p.stride != 1 || p.upsample) return nullptr;
     const int var1 = tuned_variant(p) + 1;
     const TunedEntry* any = nullptr;
@@ -1338,8 +1339,8 @@ int pick_bn(const GemmParams& p) {
     if (p.bn_hint == 64 || p.bn_hint == 128) return p.bn_hint;
     if (const TunedEntry* e = lookup_tuned(p))
         if (e->bn) return e->bn;
-    static const char* envbn = getenv("MDX_GEMM_BN");
-    if (envbn && (atoi(envbn) == 64 || atoi(envbn) == 128)) return atoi(envbn);
+    const int optbn = mdx_opt(MDX_OPT_GEMM_BN);
+    if (optbn == 64 || optbn == 128) return optbn;
     if (p.N % 128 == 0) return 128;
     if (p.N % 64 == 0 || p.N < 128) return 64;
     return (p.N % 128 > 64) ? 128 : 64;
@@ -1349,21 +1350,15 @@ struct GemmCfg {
     int bm, bn, bk, ns;
 };
 
-// Tile configuration.  Experiments: MDX_GEMM_CFG="bk,ns" overrides (bk in {32,64}, ns in {2,3,4}).
+// Tile configuration.  Experiments: mdx_set_option("gemm_ring", 2..5) forces the LDS ring depth.
 GemmCfg pick_cfg(const GemmParams& p) {
     GemmCfg c;
     c.bm = 128;   // finalised by choose_tiling
     c.bn = pick_bn(p);
     c.bk = 64;
     c.ns = 2;   // ring depth is finalised in mdx_gemm_f16 once the grid size is known
-    static const char* env = getenv("MDX_GEMM_CFG");
-    if (env) {
-        int bk = 0, ns = 0;
-        if (sscanf(env, "%d,%d", &bk, &ns) == 2 && bk == 64 && ns >= 2 && ns <= 5) {
-            c.bk = bk;
-            c.ns = ns;
-        }
-    }
+    const int ring = mdx_opt(MDX_OPT_GEMM_RING);
+    if (ring >= 2 && ring <= 5) c.ns = ring;
     return c;
 }
 
@@ -1383,7 +1378,7 @@ struct Tiling {
 };
 
 Tiling choose_tiling(const GemmParams& p, int bn, int forced_ns, int forced_bm) {
-    static const char* envbm = getenv("MDX_GEMM_BM");
+    const int envbm = mdx_opt(MDX_OPT_GEMM_BM);
     if (forced_ns <= 0 && forced_bm <= 0)
         if (const TunedEntry* e = lookup_tuned(p)) return Tiling{e->bm, e->ns};
     const int kt = (p.K + 63) / 64;
@@ -1395,7 +1390,7 @@ Tiling choose_tiling(const GemmParams& p, int bn, int forced_ns, int forced_bm) 
     static const int order[3] = {128, 256, 64};   // increasing launch complexity (see the hysteresis below)
     for (int oi = 0; oi < 3; ++oi) {
         const int bm = order[oi];
-        if (envbm && atoi(envbm) != bm) continue;
+        if (envbm && envbm != bm) continue;
         if (forced_bm > 0 && forced_bm != bm) continue;
         const bool halo = bm >= 128 && halo_eligible(p, bm);
         // 256-row tiles exist for the HALO kernel only and are opt-in (MDX_GEMM_BM=256): measured on MI355X they move
@@ -1516,16 +1511,14 @@ void launch_halo_cfg(const GemmParams& p, int nsb, bool swap, dim3 grid, hipStre
 
 // 8 x 8-pixel images (the deepest UNet level at a 64 x 64 latent): two whole samples per 128-row tile (PW = 8).
 bool halo8_eligible(const GemmParams& p) {
-    static const char* env8 = getenv("MDX_GEMM_HALO8");
-    if (env8 && atoi(env8) == 0) return false;
+    if (!mdx_opt(MDX_OPT_GEMM_HALO8)) return false;
     return p.H == 8 && p.W == 8;
 }
 
 // The HALO kernel applies to 3x3 / stride 1 / single-source convs whose image tiles into 8 x 16 (16 x 16) patches, or
 // whose images are 8 x 8 (bm = 128 only).
 bool halo_eligible(const GemmParams& p, int bm) {
-    static const char* env = getenv("MDX_GEMM_HALO");
-    if (env && atoi(env) == 0) return false;
+    if (!mdx_opt(MDX_OPT_GEMM_HALO)) return false;
     if (!(p.ksize == 3 && p.stride == 1 && !p.upsample && p.c2 == 0 && p.cin % 64 == 0 && p.out_mode == MDX_OUT_ROWMAJOR))
         return false;
     if (bm == 128 && halo8_eligible(p)) return true;
@@ -1546,13 +1539,13 @@ extern "C" int mdx_probe_gemm_trace(void* buf, size_t bytes) {
     return MDX_OK;
 }
 
-// Split-K launches of at most MDX_GEMM_SPLITK_FIXUP_MAX (default 4) splits reduce in the kernel (splitk_last_block_reduce)
+// Split-K launches of at most `gemm_splitk_fixup_max` (mdx_set_option; default 4) splits reduce in the kernel (splitk_last_block_reduce)
 // when the output is row-major and the tiles fit the ticket area.  The last arriver reads nsplit partials serially at the
 // ~65 GB/s one block can pull, so the in-kernel form only beats the reduce launch it replaces for few splits (measured at UNet
 // batch 2, profiles/r02_l_splitk_fixup.txt: 4 splits -1.7 us, 3 splits -1.4 us, 5 splits 0 ... +1.7 us, 10 splits +7 us,
 // 20 splits +8 us per launch); deeper splits, transposed outputs and deferred reduces keep the [split][M][N] slabs + reduce kernel.
 static bool fixup_eligible(const mdx_gemm_desc* d, const GemmParams& p, int bm, int bn, int ns) {
-    static const int max_ns = getenv("MDX_GEMM_SPLITK_FIXUP_MAX") ? atoi(getenv("MDX_GEMM_SPLITK_FIXUP_MAX")) : 4;
+    const int max_ns = mdx_opt(MDX_OPT_GEMM_SPLITK_FIXUP_MAX);
     if (ns > max_ns) return false;
     if (p.out_mode != MDX_OUT_ROWMAJOR || d->defer_reduce) return false;
     const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
@@ -1724,6 +1717,27 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     }
     MDX_REQUIRE(!d->defer_reduce || ns > 1, "mdx_gemm_f16: defer_reduce set but the launch does not split K");
     MDX_REQUIRE(!rs.fixup || ((uintptr_t)p.ws % 16 == 0), "mdx_gemm_f16: workspace must be 16-byte aligned");
+    if (rs.fixup) {
+        // The tiles' arrival counters live in the first MDX_GEMM_WS_HEAD bytes of the caller's workspace and must start at
+        // zero.  The first time the library sees a workspace address it zeroes them itself, on the caller's stream, ahead of
+        // the launch (a caller handing over a fresh hipMalloc'd buffer used to get a device trap).  Every launch leaves them
+        // zero again; a caller that frees a workspace and later reuses the ADDRESS for a new one must zero the head itself
+        // (include/mdx.h).
+        static std::mutex mu;
+        static std::unordered_set<const void*> seen;
+        bool first;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            first = seen.insert(d->workspace).second;
+        }
+        if (first) {
+            const hipError_t e = hipMemsetAsync(d->workspace, 0, MDX_GEMM_WS_HEAD, st);
+            if (e != hipSuccess) {
+                mdx_set_error("mdx_gemm_f16: zeroing the workspace head failed: %s", hipGetErrorString(e));
+                return MDX_E_HIP;
+            }
+        }
+    }
     p.tiles_m = (p.M + c.bm - 1) / c.bm;
     p.tiles_n = (p.N + bn - 1) / bn;
     const bool fastk = (p.cin % 64 == 0) && (p.c2 == 0 || p.c1 % 64 == 0);
@@ -1733,14 +1747,13 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     // share the bigger operand inside an XCD: unique activation bytes vs weight bytes
     p.n_fastest = ((size_t)p.M * p.cin >= (size_t)p.N * p.K) ? 1 : 0;
     dim3 grid(8 * p.tiles_per_xcd, ns);
-    static const int spread_env = getenv("MDX_GEMM_SPREAD") ? atoi(getenv("MDX_GEMM_SPREAD")) : 1;
-    p.spread = (p.tiles_m == 1 && spread_env) ? 1 : 0;
+    p.spread = (p.tiles_m == 1 && mdx_opt(MDX_OPT_GEMM_SPREAD)) ? 1 : 0;
     if (p.spread) grid = dim3(ntiles * ns, 1);
     p.trace = (g_gemm_trace && (size_t)grid.x * grid.y <= g_gemm_trace_slots) ? g_gemm_trace : nullptr;
     GemmCfg cc = c;
     const bool nw8 = rs.stages >= 10;                      // eight waves per block (generic kernel, 128-row tiles)
     const int st_req = nw8 ? rs.stages - 8 : rs.stages;    // requested ring depth (0 = the rule below)
-    if (!getenv("MDX_GEMM_CFG")) {
+    if (!(mdx_opt(MDX_OPT_GEMM_RING) >= 2 && mdx_opt(MDX_OPT_GEMM_RING) <= 5)) {
         // ring depth: three stages wherever they still leave two blocks per CU (every tile but 128 x 128: 3 x 24 KB), and for
         // 128 x 128 tiles when the grid has at most one block per CU anyway; otherwise two.  tools/tune_gemm.py measures both
         // depths per shape (round 2: 143 of 153 retuned rows chose three) and the table overrides this rule.
@@ -1755,8 +1768,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         // tiles keep two (a third stage would evict the second block)
         int nsb = (c.bm == 256 || bn == 64) ? 3 : 2;
         if (st_req == 2 || st_req == 3) nsb = st_req;
-        static const char* envn = getenv("MDX_HALO_NSB");
-        if (envn && atoi(envn) >= 2 && atoi(envn) <= 3) nsb = atoi(envn);
+        if (mdx_opt(MDX_OPT_HALO_NSB) >= 2 && mdx_opt(MDX_OPT_HALO_NSB) <= 3) nsb = mdx_opt(MDX_OPT_HALO_NSB);
         if (c.bm == 256) {
             if (bn == 128) launch_halo_cfg<256, 128>(p, nsb, swap, grid, st); else launch_halo_cfg<256, 64>(p, nsb, swap, grid, st);
         } else if (halo8_eligible(p)) {

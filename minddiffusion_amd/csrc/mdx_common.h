@@ -49,6 +49,24 @@ struct MdxSplitInfo {
 };
 int mdx_internal_split_info(const mdx_gemm_desc* d, MdxSplitInfo* info);
 
+// Library options (mdx_set_option): the tuning / experiment switches that used to be getenv() calls spread over the library.
+// Process-global ints with defaults = what the product runs; set them before the first launch they affect.
+enum MdxOpt {
+    MDX_OPT_GEMM_TUNED,          // 1: consult the measured tile table (gemm_tuned.inc)
+    MDX_OPT_GEMM_BM,             // 0 = auto | 64 | 128 | 256: force the M tile
+    MDX_OPT_GEMM_BN,             // 0 = auto | 64 | 128: force the N tile
+    MDX_OPT_GEMM_RING,           // 0 = auto | 2..5: force the LDS ring depth of the generic kernel
+    MDX_OPT_GEMM_HALO,           // 1: 3x3 convs may use the HALO kernel
+    MDX_OPT_GEMM_HALO8,          // 1: 8x8 images may use the two-sample HALO tile
+    MDX_OPT_GEMM_SPLITK_FIXUP_MAX,   // split-K launches of at most this many splits reduce in the kernel (4)
+    MDX_OPT_GEMM_SPREAD,         // 1: single-M-tile launches deal (tile, split) items round-robin to the XCDs
+    MDX_OPT_HALO_NSB,            // 0 = auto | 2 | 3: weight ring depth of the HALO kernel
+    MDX_OPT_GN_MIN_BLOCKS,       // GroupNorm: narrow the column blocks until the grid has this many blocks (512)
+    MDX_OPT_GN_FUSED,            // 1: small tensors use the one-launch GroupNorm
+    MDX_OPT_COUNT
+};
+int mdx_opt(int id);
+
 // ---- device helpers
 // sigmoid(x) = 1 / (1 + 2^(-x log2 e)) on the raw transcendental units (v_exp_f32 + v_rcp_f32, 1 ulp each): an IEEE
 // division here costs ~10 VALU instructions per element and the epilogues / GroupNorm apply it to every output.

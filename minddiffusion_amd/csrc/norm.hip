@@ -488,7 +488,7 @@ void gn_geometry(GnParams& p) {
     // 64x64x320 tensor with 128 blocks for 256 CUs: narrow the column blocks (whole groups at a time) until the grid
     // has >= 512 blocks (measured -1.4 % on the whole UNet evaluation at batch 2; batch 16 already has 1024 and
     // loses 1 % with narrow columns, so it keeps the wide ones)
-    static const int min_blocks = getenv("MDX_GN_MIN_BLOCKS") ? atoi(getenv("MDX_GN_MIN_BLOCKS")) : 512;
+    const int min_blocks = mdx_opt(MDX_OPT_GN_MIN_BLOCKS);
     const int slabs = cap < max_by_pix ? cap : max_by_pix;
     while (cw > L && ((p.CC + cw - 1) / cw) * p.B * slabs < min_blocks) cw -= L;
     p.cw = cw;
@@ -628,10 +628,9 @@ static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const 
         // fused single-launch path when one block can walk all pixels of its column block quickly: <= 64 KiB per block,
         // i.e. the 16x16 and 8x8 latent levels (measured per shape: 8.7 vs 12.4 us at HW = 256, 7.5 vs 10.7 at HW = 64;
         // at HW >= 1024 the few, long blocks lose to the two-launch slab scheme)
-        static const char* envf = getenv("MDX_GN_FUSED");
         const int lcm = p.cpg / gcd_i(p.cpg, 8) * 8;
         const int L = lcm / 8;
-        if (!(envf && atoi(envf) == 0) && L <= 64 && (size_t)HW * L * 16 <= (64u << 10)) {
+        if (mdx_opt(MDX_OPT_GN_FUSED) && L <= 64 && (size_t)HW * L * 16 <= (64u << 10)) {
             p.cw = L > p.CC ? p.CC : L;
             p.ncb = (p.CC + p.cw - 1) / p.cw;
             p.nblk = 1;

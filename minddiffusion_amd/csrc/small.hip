@@ -15,6 +15,36 @@ void mdx_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mdx_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------ library options
+static const char* const g_opt_names[MDX_OPT_COUNT] = {"gemm_tuned", "gemm_bm", "gemm_bn", "gemm_ring", "gemm_halo", "gemm_halo8",
+                                                        "gemm_splitk_fixup_max", "gemm_spread", "halo_nsb", "gn_min_blocks",
+                                                        "gn_fused"};
+static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1};
+
+int mdx_opt(int id) { return g_opt[id]; }
+
+extern "C" int mdx_set_option(const char* name, int value) {
+    MDX_REQUIRE(name, "mdx_set_option: null name");
+    for (int i = 0; i < MDX_OPT_COUNT; ++i)
+        if (!strcmp(name, g_opt_names[i])) {
+            g_opt[i] = value;
+            return MDX_OK;
+        }
+    mdx_set_error("mdx_set_option: unknown option '%s'", name);
+    return MDX_E_INVALID;
+}
+
+extern "C" int mdx_get_option(const char* name, int* value) {
+    MDX_REQUIRE(name && value, "mdx_get_option: null argument");
+    for (int i = 0; i < MDX_OPT_COUNT; ++i)
+        if (!strcmp(name, g_opt_names[i])) {
+            *value = g_opt[i];
+            return MDX_OK;
+        }
+    mdx_set_error("mdx_get_option: unknown option '%s'", name);
+    return MDX_E_INVALID;
+}
 extern "C" int mdx_version(void) { return 1; }
 
 namespace {

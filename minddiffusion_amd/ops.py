@@ -20,13 +20,20 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
 
 
 def set_option(name, value):
-    if name not in _OPTIONS:
-        raise _lib.MdxError(f"unknown option {name!r} (known: {sorted(_OPTIONS)})")
-    _OPTIONS[name] = int(value)
+    """Python-level planner options (unet_st_tail, unet_st_head) or, for any other name, a library option
+    (include/mdx.h: mdx_set_option -- gemm_tuned, gemm_bm, gemm_splitk_fixup_max, ...)."""
+    if name in _OPTIONS:
+        _OPTIONS[name] = int(value)
+        return
+    _lib.check(_lib.load().mdx_set_option(name.encode(), int(value)), "mdx_set_option")
 
 
 def get_option(name):
-    return _OPTIONS[name]
+    if name in _OPTIONS:
+        return _OPTIONS[name]
+    out = ctypes.c_int(0)
+    _lib.check(_lib.load().mdx_get_option(name.encode(), ctypes.byref(out)), "mdx_get_option")
+    return int(out.value)
 
 
 def _stream():

@@ -684,3 +684,29 @@ def test_checkpoint_reader_against_independent_protobuf_writer(tmp_path, packed_
     refg.load_state_dict(bp)
     for k in refg.w:
         assert torch.equal(m.model.w[k], refg.w[k]), k
+
+
+def test_library_options_replace_environment_variables():
+    """the library reads no environment variables; its tuning switches are mdx_set_option names."""
+    import subprocess
+    from minddiffusion_amd import _lib, ops
+    lib = _lib.load()
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
+    assert ops.get_option("gemm_splitk_fixup_max") == 4 and ops.get_option("gemm_tuned") == 1
+    ops.set_option("gemm_splitk_fixup_max", 2)
+    try:
+        assert ops.get_option("gemm_splitk_fixup_max") == 2
+        # the option reaches the launch decision: a 3-way split no longer reduces in the kernel
+        d = ops.GemmDesc()
+        d.a = d.w = d.out = 4096
+        d.c1, d.N, d.B, d.H, d.W, d.ksize, d.stride, d.out_ld, d.splitk = 1280, 1280, 2, 256, 1, 1, 1, 1280, 3
+        d.workspace, d.workspace_bytes = 4096, 64 << 20
+        assert ops.gemm_query(d)[2] == 3 and ops.gemm_query(d)[6] == 0
+        ops.set_option("gemm_splitk_fixup_max", 4)
+        assert ops.gemm_query(d)[6] == 1
+    finally:
+        ops.set_option("gemm_splitk_fixup_max", 4)
+    with pytest.raises(_lib.MdxError, match="unknown option"):
+        ops.set_option("no_such_option", 1)
+    assert lib.mdx_set_option(b"gemm_bm", 0) == 0
