@@ -223,6 +223,97 @@ def test_gemm_splitk_workspace_reuse(ops):
         check(f"gemm_splitk_reuse_M{pr[3]}", o, pr[7], rel_l2=1e-3)
 
 
+def test_gemm_splitk_ticket_stress(ops):
+    """In-kernel split-K reduce (csrc/gemm.hip splitk_last_block_reduce: write-through partials, one relaxed agent-scope
+    ticket per tile, the last arriver sums in split order) under stress: three problems that ALL take the in-kernel form
+    (2, 3 and 4 splits; many tiles; row statistics / GEGLU epilogues on top) rotate through ONE workspace whose partial area
+    is NaN-poisoned before every round and whose ticket head the LIBRARY zeroes (a torch.empty workspace: not pre-zeroed by
+    the caller), 400 eager rounds + 300 replays of a two-round hipGraph (2 800 launches of the in-kernel form in all).  A
+    visibility bug -- a partial read before its writer's stores landed, a stale line, a ticket seen early -- would surface as a
+    NaN from the poisoned area or as a changed bit: every round must be bit-identical to the first, and the first must agree
+    with the same problems run through the separate reduce kernel (gemm_splitk_fixup_max = 0; same split order, but its
+    epilogue rounds once instead of staging through fp16, so: to 2 fp16 ulp, not to the bit)."""
+    rng = np.random.RandomState(99)
+    specs = [(512, 1280, 1280, 3, "plain"), (2048, 640, 2560, 2, "stats"), (512, 1280, 5120, 4, "plain"),
+             (256, 2560, 640, 2, "geglu")]
+    probs = []
+    for (M, N, K, sk, kind) in specs:
+        a = dev16(h16(rng.standard_normal((M, K))))
+        w = pack_dense(h16(rng.standard_normal((N, K)) / math.sqrt(K)))
+        bv = dev32(rng.standard_normal(N).astype(np.float32))
+        res = dev16(h16(rng.standard_normal((M, N)))) if kind != "geglu" else None
+        probs.append((a, w, bv, res, M, N, K, sk, kind))
+
+    def build(ws):
+        descs = []
+        for (a, w, bv, res, M, N, K, sk, kind) in probs:
+            cols = N // 2 if kind == "geglu" else N
+            out = torch.empty(M, cols, dtype=torch.float16, device=DEV)
+            st = torch.zeros((M, N // 64, 2), dtype=torch.float32, device=DEV) if kind == "stats" else None
+            d = ops.make_gemm_desc(a, w, N, M, 1, 1, K, out, cols, bias=bv, splitk=sk, residual=res,
+                                   residual_ld=N if res is not None else 0, stats_out=st,
+                                   epilogue=ops.EPI_GEGLU if kind == "geglu" else ops.EPI_NONE)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+            descs.append((d, out, st))
+        return descs
+
+    need = 0
+    for (a, w, bv, res, M, N, K, sk, kind) in probs:
+        need = max(need, 16384 + sk * ((M + 127) // 128 * 128) * ((N + 127) // 128 * 128) * 4)
+    # reference: the reduce-kernel form
+    ops.set_option("gemm_splitk_fixup_max", 0)
+    try:
+        ws0 = ops.new_gemm_workspace(need, DEV)
+        ref_descs = build(ws0)
+        for d, _, _ in ref_descs:
+            assert ops.gemm_query(d)[6] == 0
+            ops.gemm_run(d)
+        torch.cuda.synchronize()
+        refs = [(o.clone(), None if st is None else st.clone()) for _, o, st in ref_descs]
+    finally:
+        ops.set_option("gemm_splitk_fixup_max", 4)
+    ws = torch.empty(need // 4 + 1, dtype=torch.float32, device=DEV)      # NOT zeroed: the library owns the ticket head
+    ws.fill_(float("nan"))
+    descs = build(ws)
+    for d, _, _ in descs:
+        q = ops.gemm_query(d)
+        assert q[6] == 1 and q[2] >= 2, f"expected the in-kernel reduce, got {q}"
+
+    def one_round():
+        for d, _, _ in descs:
+            ops.gemm_run(d)
+
+    one_round()
+    torch.cuda.synchronize()
+    first = [(o.clone(), None if st is None else st.clone()) for _, o, st in descs]
+    for (o, st), (ro, rst), pr in zip(first, refs, probs):
+        check(f"splitk_ticket_vs_reduce_kernel_M{pr[4]}_N{pr[5]}_K{pr[6]}", o, ro, rel_l2=5e-4, max_rel=4e-3)
+
+    def same(tag):
+        for (d, o, st), (fo, fst), pr in zip(descs, first, probs):
+            assert torch.equal(o, fo), f"{tag}: output of M={pr[4]} N={pr[5]} K={pr[6]} changed between launches"
+            if st is not None:
+                assert torch.equal(st, fst), f"{tag}: row statistics changed between launches"
+    for rep in range(400):
+        ws[4096:].fill_(float("nan"))       # stale partials of the previous round must never be read
+        one_round()
+        if rep % 50 == 49:
+            torch.cuda.synchronize()
+            same(f"eager round {rep}")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        one_round()
+        one_round()
+    for rep in range(300):
+        g.replay()
+        if rep % 100 == 99:
+            torch.cuda.synchronize()
+            same(f"graph replay {rep}")
+    torch.cuda.synchronize()
+    same("end")
+    assert bool((ws[:4096].view(torch.int32) == 0).all()), "arrival counters not back at zero"
+
+
 def test_gemm_two_source_1x1(ops):
     """ResBlock skip_connection on the (virtual) concat of h and the UNet skip tensor (openaimodel.py:174,568)."""
     rng = np.random.RandomState(5)
@@ -506,6 +597,54 @@ def test_attention(ops, B, heads, Nq, Nk, spike, D):
                   Nq * C, C, Nk * C, C, C * ld, ld, Nq * C, C)
     # P is rounded to fp16 before PV and O is stored fp16: 2e-3 relative
     check(f"attention_B{B}_h{heads}_q{Nq}_k{Nk}_d{D}_spike{int(spike)}", out, ref, rel_l2=2e-3, max_abs=2e-2)
+
+
+RAMPS = {
+    # per-64-key-tile offsets of every query's scores, in the log2 units the kernel's exponentials are taken in
+    "stale3": lambda t: 3.0 * t,                       # reference maximum stale by 3, 6 -> rescale at 9 (> 2^8), ...
+    "stale6.5": lambda t: 6.5 * t,                     # stale by 6.5, then 13 -> rescale every second tile
+    "edge7.9": lambda t: 7.9 * t,                      # just under the threshold: P up to 2^7.9 = 239 in fp16
+    "always12": lambda t: 12.0 * t,                    # every tile outgrows the reference by more than 2^8
+    "sawtooth": lambda t: [0.0, 7.0, 14.0, -6.0, 1.9, 9.8, 17.0, 40.0][t % 8],   # down-steps + one huge late tile
+}
+
+
+@pytest.mark.parametrize("ramp", sorted(RAMPS))
+@pytest.mark.parametrize("D,heads", [(40, 2), (64, 2), (80, 1), (160, 1)])
+@pytest.mark.parametrize("mode", ["self", "cross", "causal"])
+def test_attention_stale_maximum_regime(ops, ramp, D, heads, mode):
+    """The lazily moved softmax reference (csrc/attention.hip: the running maximum is only replaced when a query of the wave
+    outgrows it by more than 2^8): key tiles whose scores climb by 3 / 6.5 / 7.9 / 12 log2 units per tile, and a sawtooth with
+    down-steps and one +40 tile, so that P fragments between 1 and 2^8 are rounded to fp16 under a stale reference, the
+    ballot-uniform rescale branch is taken on some tiles and skipped on others, for all four head dims, ragged key counts
+    (cross) and the masked causal variant.  Reference: exact float64 softmax."""
+    B = 1
+    Nq, Nk = {"self": (256, 512), "cross": (200, 330), "causal": (384, 384)}[mode]
+    C = heads * D
+    rng = np.random.RandomState(sum(map(ord, ramp)) + D + Nk)
+    q = h16(0.5 * rng.standard_normal((B, Nq, C)))
+    k = h16(0.5 * rng.standard_normal((B, Nk, C)))
+    v = h16(rng.standard_normal((B, Nk, C)))
+    # one dedicated channel per head carries the ramp: q_last = 8, k_last(tile) = offset / (8 * scale * log2 e)
+    scale_log2 = D ** -0.5 * 1.4426950408889634
+    for hh in range(heads):
+        q[:, :, hh * D + D - 1] = 8.0
+        for j in range(Nk):
+            k[:, j, hh * D + D - 1] = RAMPS[ramp](j // 64) / (8.0 * scale_log2)
+    q, k = h16(q), h16(k)
+    qt, kt, vt_ = [torch.tensor(t, dtype=torch.float64).reshape(B, -1, heads, D).permute(0, 2, 1, 3) for t in (q, k, v)]
+    sc = torch.matmul(qt, kt.transpose(2, 3)) * D ** -0.5
+    if mode == "causal":
+        sc = sc + torch.triu(torch.full((Nq, Nk), float("-inf"), dtype=torch.float64), 1)
+    ref = torch.matmul(torch.softmax(sc, -1), vt_).permute(0, 2, 1, 3).reshape(B, Nq, C)
+    ld = (Nk + 7) // 8 * 8
+    vt = np.zeros((B, C, ld), np.float32)
+    vt[:, :, :Nk] = v.transpose(0, 2, 1)
+    qd, kd, vtd = dev16(q), dev16(k), dev16(vt)
+    out = torch.empty((B, Nq, C), dtype=torch.float16, device=DEV)
+    ops.attention(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), out.data_ptr(), B, heads, D, Nq, Nk, D ** -0.5,
+                  Nq * C, C, Nk * C, C, C * ld, ld, Nq * C, C, causal=(mode == "causal"))
+    check(f"attention_{mode}_{ramp}_d{D}", out, ref, rel_l2=2e-3, max_abs=2e-2)
 
 
 @pytest.mark.parametrize("B,heads,N,D", [(2, 2, 80, 64), (1, 3, 77, 64), (2, 1, 200, 64), (1, 2, 384, 64), (1, 8, 80, 40)])
