@@ -202,7 +202,8 @@ def roofline_from_families(acc, evals_label):
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-        "kernel": "gemm_kernel / conv3x3_halo_kernel (+ splitk_reduce): every implicit-GEMM conv3x3 / conv1x1 / dense launch of "
+        "kernel": "gemm_kernel / conv3x3_halo_kernel (+ splitk_reduce) / st_head_kernel / st_tail_kernel: every implicit-GEMM conv3x3 / "
+                  "conv1x1 / dense launch and every fused SpatialTransformer head / tail launch (chains of dense GEMMs) of "
                   + evals_label + ", HIP events per op on the launch stream, ops in their real sequence",
         "launches_per_unit_of_profile": round(g["launches"], 1),
         "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
@@ -237,7 +238,8 @@ def cpu_baseline(n_evals=3):
     }
 
 
-PMC_FILE = "r02_pmc_traffic.json"
+PMC_FILE = "r03_pmc_traffic.json"
+PMC_MFMA_FILE = "r03_pmc_mfma.json"
 
 
 def pmc_traffic(gemm_launches_now):
@@ -266,6 +268,31 @@ def pmc_traffic(gemm_launches_now):
         return None, f"no PMC passes for this build ({type(e).__name__})"
 
 
+def pmc_mfma_busy(roof, gemm_launches_now):
+    """Matrix-pipe occupancy per kernel family of THIS bench command, from the committed rocprofv3 PMC pass
+    (tools/pmc_mfma.py: SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 32 SIMDs per shader engine)).
+    PMC counters cannot be read from inside the timed process; the file is used only when its GEMM-family launch count per
+    evaluation equals this run's (same launch mix), else `mfma_busy` stays absent and the reason is given."""
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_MFMA_FILE)) as f:
+            doc = json.load(f)
+        n = doc["families"]["gemm"]["launches_per_eval"] + doc["families"].get("splitk_reduce", {}).get("launches_per_eval", 0)
+        if abs(n - gemm_launches_now) > 0.01 * gemm_launches_now:
+            roof["mfma_busy_note"] = (f"profiles/{PMC_MFMA_FILE} holds {n:.0f} GEMM-family launches per evaluation, this build "
+                                      f"issues {gemm_launches_now}: stale PMC pass, not reported")
+            return
+        for fam, ent in roof["families"].items():
+            src = doc["families"].get(fam)
+            if src is not None and src.get("mfma_busy") is not None:
+                ent["mfma_busy"] = src["mfma_busy"]
+        g = doc["families"]["gemm"]
+        roof["mfma_busy"] = g.get("mfma_busy")
+        roof["mfma_busy_note"] = (f"matrix-pipe occupancy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 32 SIMDs per SE) per "
+                                  f"family, rocprofv3 --pmc pass of `{doc.get('command', '?')}`; profiles/{PMC_MFMA_FILE}")
+    except Exception as e:
+        roof["mfma_busy_note"] = f"no MFMA-busy PMC pass for this build ({type(e).__name__})"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,11 +301,11 @@ def main():
     ap.add_argument("--config", default="sd2_512", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="headline line only (the default N = 1 run also times BASELINE configs[2..4], see OTHER_CONFIGS)")
     args = ap.parse_args()
-    cfg = CONFIGS[args.config]
 
     from minddiffusion_amd import distributed as D
-    from minddiffusion_amd.pipeline import DiffusionPipeline
 
     rank, world, local_rank = D.init_from_env()
     if world != args.gpus:
@@ -287,6 +314,37 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    result = run_config(args.config, args, rank, world, device, args.steps, args.warmup,
+                        cpu=(world == 1 and not args.no_cpu_baseline and args.config == "sd2_512"))
+    if rank == 0 and world == 1 and args.config == "sd2_512" and not args.no_other_configs:
+        # The other BASELINE configs' per-GPU shares, timed by the SAME command the driver runs: >= 3 timed
+        # units each after one warm-up; the headline fields above are untouched.
+        result["other_configs"] = {}
+        for name in OTHER_CONFIGS:
+            torch.cuda.empty_cache()
+            r = run_config(name, args, rank, world, device, 3, 1, cpu=False)
+            result["other_configs"][name] = {
+                "metric": r["metric"], "value": r["value"], "unit": r["unit"], "steps": r["steps"], "warmup": r["warmup"],
+                "ms_per_step": r["ms_per_step"], "per_unet_step_ms": r.get("per_unet_step_ms"),
+                "workload": r["config"]["workload"], "global_batch": r["config"]["global_batch"],
+                "hip_graph": r["config"]["hip_graph"], "families": r["roofline"]["families"],
+                "gemm_family_tflops": r["roofline"]["achieved"], "whole_path": r["roofline"]["whole_path"]}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+OTHER_CONFIGS = ("wukong_512_plms", "sd2_768", "glide_256")
+
+
+def run_config(config, args, rank, world, device, steps, warmup, cpu):
+    """Build the models of one CONFIGS entry, time `steps` units after `warmup`, profile the plan's kernel families.  Returns
+    the result dict on rank 0 (None elsewhere)."""
+    from minddiffusion_amd import distributed as D
+    from minddiffusion_amd.pipeline import DiffusionPipeline
+    cfg = CONFIGS[config]
     batch = cfg["batch"]
     Bg = batch * world
 
@@ -338,11 +396,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         out = one_step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -352,15 +410,15 @@ def main():
         elapsed = float(tt.item())
     assert torch.isfinite(out).all()
 
-    ms_per_step = elapsed / args.steps * 1e3
-    units_per_s = Bg * args.steps / elapsed
+    ms_per_step = elapsed / steps * 1e3
+    units_per_s = Bg * steps / elapsed
     if rank == 0:
         result = {
             "metric": cfg["metric"], "value": round(units_per_s, 4), "unit": cfg["unit"], "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": cfg["workload"] + "; synthetic seeded weights + synthetic text conditioning",
-                       "name": args.config, "global_batch": Bg, "parallelism": f"batch-shard x{world}",
+                       "name": config, "global_batch": Bg, "parallelism": f"batch-shard x{world}",
                        "hip_graph": None},
         }
         if cfg["family"] == "ldm":
@@ -415,8 +473,9 @@ def main():
                     result["text_encode_ms"] = round(float(np.median([a.elapsed_time(b) for a, b in evs[2:]])), 3)
                 result["vae_decode_ms"] = round(vms, 3)
                 result["vae_decode_tflops"] = round(cfg["vae_tflop"] * batch / vms * 1e3, 1)
-            if args.config == "sd2_512":
+            if config == "sd2_512":
                 roof["traffic"], roof["traffic_note"] = pmc_traffic(gemm_launches)
+                pmc_mfma_busy(roof, gemm_launches)
         else:
             # Taichu-GLIDE: one image = 60 guided base evaluations (UNet batch 2P) + 27 super-resolution evaluations (batch P);
             # profile both plans and weight them by their evaluation counts
@@ -434,14 +493,9 @@ def main():
         if roof.get("achieved") is None:
             roof["achieved"], roof["frac"] = roof["whole_path"]["achieved"], roof["whole_path"]["frac"]
         result["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline and args.config == "sd2_512":
-            result["cpu_baseline"] = cpu_baseline()
-        else:
-            result["cpu_baseline"] = None
-        print(json.dumps(result), flush=True)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        result["cpu_baseline"] = cpu_baseline() if cpu else None
+        return result
+    return None
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@ except Exception as e:
 PY
       done ;;
     prof)
-      timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o $TAG -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_prof.log 2>&1
+      timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o $TAG -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/bench_prof.log 2>&1
       DB=$(find gpurun_out/prof_bench -name "*_results.db" | head -1)
       [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/bench_kernel_stats.md
       rm -rf gpurun_out/prof_bench; head -30 $OUT/bench_kernel_stats.md ;;
@@ -37,13 +37,21 @@ PY
       for c in FETCH_SIZE WRITE_SIZE; do
         for attempt in 1 2 3; do     # rocprofv3 --pmc occasionally dies with SIGSEGV inside the profiled process (ROCm 7.2): retry
           rm -rf gpurun_out/pmc/$c
-          timeout 400 rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc/$c -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $OUT/pmc_$c.log 2>&1
+          timeout 400 rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc/$c -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph --no-other-configs > $OUT/pmc_$c.log 2>&1
           [ -n "$(find gpurun_out/pmc/$c -name '*_results.db' 2>/dev/null | head -1)" ] && break
           echo "pmc $c attempt $attempt failed"
         done
         tail -2 $OUT/pmc_$c.log | cut -c1-200
       done
-      python tools/pmc_traffic.py gpurun_out/pmc "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph (the timed configuration launched eagerly: rocprofv3 --pmc segfaults on hipGraph replay; same kernels, same launch mix)" > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err; rm -rf gpurun_out/pmc; cat $OUT/pmc_traffic.json | head -60; cat $OUT/pmc_traffic.err | tail -3 ;;
+      python tools/pmc_traffic.py gpurun_out/pmc "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph (the timed configuration launched eagerly: rocprofv3 --pmc segfaults on hipGraph replay; same kernels, same launch mix)" ${ATTN_PER_EVAL:-27} > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err; rm -rf gpurun_out/pmc; cat $OUT/pmc_traffic.json | head -60; cat $OUT/pmc_traffic.err | tail -3 ;;
+    pmc_mfma)
+      for attempt in 1 2 3; do
+        rm -rf gpurun_out/pmc/MFMA
+        timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d gpurun_out/pmc/MFMA -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph --no-other-configs > $OUT/pmc_mfma.log 2>&1
+        [ -n "$(find gpurun_out/pmc/MFMA -name '*_results.db' 2>/dev/null | head -1)" ] && break
+        echo "pmc mfma attempt $attempt failed"
+      done
+      python tools/pmc_mfma.py $(find gpurun_out/pmc/MFMA -name '*_results.db' | head -1) "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph --no-other-configs (the timed configuration launched eagerly: rocprofv3 --pmc segfaults on hipGraph replay)" ${ATTN_PER_EVAL:-27} > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err; rm -rf gpurun_out/pmc/MFMA; cat $OUT/pmc_mfma.json | head -70; tail -3 $OUT/pmc_mfma.err ;;
     opprof)
       timeout 200 python tools/op_profile.py --batch 2 --top 400 > $OUT/op_profile_b2.txt 2>&1; head -8 $OUT/op_profile_b2.txt ;;
     *) echo "unknown stage $stage" ;;

@@ -21,8 +21,8 @@ from collections import defaultdict
 def family(name):
     if name.startswith("void at::") or "at::native" in name or "rocclr" in name:
         return None   # torch's weight-initialisation / copy kernels
-    if "gemm_kernel" in name or "conv3x3_halo_kernel" in name:
-        return "gemm"
+    if "gemm_kernel" in name or "conv3x3_halo_kernel" in name or "st_tail_kernel" in name or "st_head_kernel" in name:
+        return "gemm"      # (the fused SpatialTransformer head / tail launches are chains of dense GEMMs)
     if "splitk_reduce" in name:
         return "splitk_reduce"
     if "attn_kernel" in name:
@@ -53,7 +53,9 @@ def main():
     command = sys.argv[2] if len(sys.argv) > 2 else "python tools/op_profile.py --batch 2 --passes 1"
     fetch = load(f"{root}/FETCH_SIZE/pmc_results.db", "FETCH_SIZE")
     write = load(f"{root}/WRITE_SIZE/pmc_results.db", "WRITE_SIZE")
-    evals = fetch["attention"][0] / 32.0 if fetch["attention"][0] else 1.0   # 32 attention launches per SDv2 UNet eval
+    # attention launches per SDv2 UNet evaluation: 32, or 27 when the five 64 x 64 cross-attentions run inside the fused tails
+    per_eval = float(sys.argv[3]) if len(sys.argv) > 3 else 32.0
+    evals = fetch["attention"][0] / per_eval if fetch["attention"][0] else 1.0
     out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- " + command,
            "unet_evals_in_trace": evals,
            "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B); MALL hits included",
