@@ -78,6 +78,12 @@ int mdx_groupnorm_colstats_f16(const void* x1, int C1, const float* cs1, int nrb
                                int nrb2, const float* gamma, const float* beta, const float* scale, const float* shift,
                                int mod_ld, void* y, int B, int HW, int groups, float eps, int silu, mdx_stream_t s);
 
+/* Two-level fold of a producer's column partials: dst[b][j][c] = sum of the f = ceil(nrb / nrb2) consecutive row blocks
+ * j f .. j f + f - 1 of src[b][.][c] (src [B * nrb][C][2], dst [B * nrb2][C][2], nrb2 == ceil(nrb / f)).  Tensors with hundreds of
+ * row blocks per sample (Taichu-GLIDE's 128 x 128 / 256 x 256 levels) are folded once to <= 64 blocks and then normalised by
+ * mdx_groupnorm_colstats_f16 -- one small launch instead of the statistics pass over the tensor. */
+int mdx_colstats_fold_f32(const float* src, int nrb, float* dst, int nrb2, int B, int C, mdx_stream_t s);
+
 /* Same with the FiLM modulation of GLIDE's ResBlock (Taichu-GLIDE/.../unet.py:203-208):
  *   y = silu?( GN(x) * (1 + scale[b][c]) + shift[b][c] ),  scale/shift fp32 rows of stride mod_ld. */
 int mdx_groupnorm_scaleshift_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,
@@ -159,6 +165,12 @@ typedef struct mdx_gemm_desc {
     int tile_m;           /* 0 = auto (tuned table, then the cost model); 64 | 128 forces the M tile.  For tools/tune_gemm.py,
                              which measures the (tile_m, splitk) candidates of every UNet shape on the device. */
     int tile_n;           /* 0 = auto; 64 | 128 forces the N tile (same purpose; GEGLU always uses 128) */
+    int w_frag;           /* 1: `w` is packed in MFMA-FRAGMENT order instead of the tile-major format above -- [N / 32 column tiles]
+                             [K / 16 k-steps][64 lanes][8 halves], piece (ct, s)[lane] = W[32 ct + lane % 32][16 s + 8 (lane / 32)
+                             + 0..7], K in the conv order of item 1 (ops.pack_conv_weight_frag) -- and the launch streams it
+                             HBM -> registers (weight-streaming form of the HALO 3x3 conv for M <= 512: no weight tiles in LDS,
+                             one barrier per 64-channel chunk).  3x3 / stride 1 / single source / Cin % 64 == 0 convs that
+                             resolve to the HALO kernel only; set tile_m = 128.  Results are bit-identical to the tile-major form. */
     int stages;           /* 0 = auto; 2 .. 6 forces the depth of the LDS ring the K tiles are DMA'd through (same purpose; 64-row
                              tiles up to 6, 128-row tiles up to 5, HALO weight ring 2 | 3); 10 | 11 = depth 2 | 3 with EIGHT
                              waves per block (generic kernel, tile_m = 128 only) */

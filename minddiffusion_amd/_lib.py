@@ -33,7 +33,7 @@ class GemmDesc(ctypes.Structure):
         ("out2", c_void_p), ("out2_ld", c_int), ("n_split", c_int), ("asym_pad", c_int),
         ("stats_out", c_void_p), ("ln_stats", c_void_p), ("ln_s", c_void_p), ("ln_nt", c_int), ("ln_eps", c_float),
         ("colstats_out", c_void_p), ("colstats_cap", c_int), ("defer_reduce", c_int),
-        ("tile_m", c_int), ("tile_n", c_int), ("stages", c_int),
+        ("tile_m", c_int), ("tile_n", c_int), ("w_frag", c_int), ("stages", c_int),
     ]
 
 
@@ -75,6 +75,7 @@ SIGNATURES = {
     "mdx_groupnorm_colstats_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float,
                                            c_int, c_void_p]),
+    "mdx_colstats_fold_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mdx_groupnorm_from_splitk_f16": (c_int, [ctypes.POINTER(GemmDesc), c_void_p, c_void_p, c_void_p, c_int, c_float, c_int,
                                               c_void_p]),
     "mdx_groupnorm_from_splitk_ok": (c_int, [ctypes.POINTER(GemmDesc), c_int]),

@@ -815,7 +815,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
 // (zero padding from the buffer bounds check) sits in LDS once per 64-channel chunk: 200 halo rows instead of nine
 // 128-row im2col tiles -- the activation share of the per-CU DMA stream (what bounds a lone block per CU,
 // profiles/r01_dma_probe.txt) drops from 144 to 25 KiB per chunk, 288 -> 169 KiB in all at BN = 128.
-template <int BM, int BN, int NSB, bool SWAP, int PW>
+//
+// BDIR (weight-streaming form, for M <= 512 where every launch is bound by how fast it pulls cold weights): the weights are
+// packed in MFMA-fragment order ([N / 32][K / 16][64 lanes][8], ops.pack_frag_weight) and go HBM/L2 -> VGPR directly, PFB
+// pieces of 1 KiB in flight per wave and column tile -- no weight tiles in LDS, no weight DMA, and ONE barrier per 64-channel
+// chunk (the halo swap) instead of one per tap.  With the LDS ring a block keeps two 8 KiB weight tiles in flight (32 KiB
+// per CU: ~2 TB/s chip-wide at the HBM round trip); here 4 waves x 12 KiB x 2 blocks = 96 KiB per CU.  Same k order per
+// output, same epilogue: bit-identical results.
+template <int BM, int BN, int NSB, bool SWAP, int PW, bool BDIR = false>
 __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel(const GemmParams p) {
     static_assert(PW == 16 || (PW == 8 && BM == 128), "patch width 16, or 8 with two-sample tiles");
     constexpr int NW = BM / 32;              // waves: (NW/2) x 2, each 64 patch pixels x BN/2 channels
@@ -935,6 +942,81 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     float bpre[16];
     gemm_bias_prefetch<BN, SWAP, NW>(p, n0, bpre);
 
+    if constexpr (BDIR) {
+        constexpr int PFB = 12;                                  // divides the 36 k-steps of a chunk: static ring positions
+        const unsigned kpieces = (unsigned)p.kt64 * 4u;          // 1 KiB pieces (16-wide k-steps) per 32-column tile
+        unsigned pbase[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) pbase[j] = (unsigned)((n0 + wn * (BN / 2) + j * 32) >> 5) * kpieces + (unsigned)kt_begin * 4u;
+        const unsigned voffw = (unsigned)lane * 16u;
+        // halo first, then the ring: the halo DMAs are then older than the PFB * TN youngest loads at every chunk boundary
+#pragma unroll
+        for (int q = 0; q < HJ; ++q) dma_halo(q, c_begin, 0);
+        u32x4 ring[TN][PFB];
+#pragma unroll
+        for (int q = 0; q < PFB; ++q)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) ring[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voffw, (pbase[j] + q) * 1024u, 0);
+        trace_mark(p, 1);
+        unsigned step = 0;
+        for (int c = c_begin; c < c_end; ++c) {
+            const int hb = (c - c_begin) & 1;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PFB * TN) : "memory");     // this chunk's halo has landed (own DMAs)
+            __builtin_amdgcn_s_barrier();                                      // ... everyone's; buffer hb ^ 1 is free
+            if (c + 1 < c_end) {
+#pragma unroll
+                for (int q = 0; q < HJ; ++q) dma_halo(q, c + 1, hb ^ 1);
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int dq = ky * HWD + kx;
+                int a_row[TM], a_key[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    a_row[i] = hb * HALO_BYTES + (hp0[i] + dq) * 128;
+                    if constexpr (PW == 16)
+                        a_key[i] = ((((l31 & 15) + kx) >> 1) & 7) << 4;
+                    else
+                        a_key[i] = (((((l31 & 7) + kx) >> 1) & 3) | ((((l31 >> 3) + ky) & 1) << 2)) << 4;
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    f16x8 af[TM];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        af[i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + (((2 * s + hi) << 4) ^ a_key[i]));
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int rp = (tap * 4 + s) % PFB;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const f16x8 b = __builtin_bit_cast(f16x8, ring[j][rp]);
+                        ring[j][rp] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, voffw, (pbase[j] + step + (unsigned)(tap * 4 + s) + PFB) * 1024u, 0);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            if constexpr (SWAP)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, af[i], acc[i][j], 0, 0, 0);
+                            else
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], b, acc[i][j], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // keep every refill where it is written (else they sink to their use)
+                }
+            }
+            step += 36;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ring refills past the end of the range are still in flight
+        __syncthreads();
+        trace_mark(p, 3);
+        if constexpr (PW == 16)
+            gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split, bpre, tile_m,
+                                            tile_id);
+        else
+            gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{tile_m * BM}, n0, split, bpre, tile_m, tile_id);
+        trace_mark(p, 4);
+        return;
+    }
     // prologue: whole halo of the first chunk + the first NSB-1 weight tiles
 #pragma unroll
     for (int q = 0; q < HJ; ++q) dma_halo(q, c_begin, 0);
@@ -1485,19 +1567,25 @@ bool launch_bn(const GemmCfg& c, const GemmParams& p, bool swap, bool fastk, dim
     return true;
 }
 
-template <int BM, int BN, int NSB, bool SWAP, int PW = 16>
+template <int BM, int BN, int NSB, bool SWAP, int PW = 16, bool BDIR = false>
 void launch_halo(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t hinst = ((PW == 16 ? (BM / 16 + 2) * 18 : (BM / 64) * 100) + 7) / 8;
-    constexpr size_t ring = 2 * hinst * 1024 + (size_t)NSB * BN * 128;
+    constexpr size_t ring = 2 * hinst * 1024 + (BDIR ? 0 : (size_t)NSB * BN * 128);
     constexpr size_t epi = (size_t)BM * (BN + 8) * 2 + 4096;
     constexpr size_t lds = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW, BDIR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW>), grid, dim3(BM * 2), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW, BDIR>), grid, dim3(BM * 2), lds, st, p);
+}
+
+// weight-streaming form (fragment-major weights): 128-row tiles only, no weight ring in LDS
+template <int BN, int PW>
+void launch_halo_bdir(const GemmParams& p, bool swap, dim3 grid, hipStream_t st) {
+    if (swap) launch_halo<128, BN, 2, true, PW, true>(p, grid, st); else launch_halo<128, BN, 2, false, PW, true>(p, grid, st);
 }
 
 template <int BM, int BN, int PW = 16>
@@ -1761,6 +1849,7 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         if (st_req >= 2 && st_req <= 6) cc.ns = st_req;
     }
     const bool swap = (ns == 1 || rs.fixup) && (p.out_mode == MDX_OUT_ROWMAJOR);
+    MDX_REQUIRE(!d->w_frag || halo, "mdx_gemm_f16: fragment-major weights (w_frag) are read by the HALO 3x3 conv only");
     bool ok;
     if (halo) {
         // weight ring depth: three stages where two blocks per CU still fit (64-column tiles: 46 KB halos + 3 x 8 KB; measured
@@ -1769,7 +1858,14 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         int nsb = (c.bm == 256 || bn == 64) ? 3 : 2;
         if (st_req == 2 || st_req == 3) nsb = st_req;
         if (mdx_opt(MDX_OPT_HALO_NSB) >= 2 && mdx_opt(MDX_OPT_HALO_NSB) <= 3) nsb = mdx_opt(MDX_OPT_HALO_NSB);
-        if (c.bm == 256) {
+        if (d->w_frag) {
+            MDX_REQUIRE(c.bm == 128, "mdx_gemm_f16: fragment-major weights run on 128-row HALO tiles only (got tile_m %d)", c.bm);
+            if (halo8_eligible(p)) {
+                if (bn == 128) launch_halo_bdir<128, 8>(p, swap, grid, st); else launch_halo_bdir<64, 8>(p, swap, grid, st);
+            } else {
+                if (bn == 128) launch_halo_bdir<128, 16>(p, swap, grid, st); else launch_halo_bdir<64, 16>(p, swap, grid, st);
+            }
+        } else if (c.bm == 256) {
             if (bn == 128) launch_halo_cfg<256, 128>(p, nsb, swap, grid, st); else launch_halo_cfg<256, 64>(p, nsb, swap, grid, st);
         } else if (halo8_eligible(p)) {
             if (bn == 128) launch_halo_cfg<128, 128, 8>(p, nsb, swap, grid, st); else launch_halo_cfg<128, 64, 8>(p, nsb, swap, grid, st);

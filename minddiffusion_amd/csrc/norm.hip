@@ -720,6 +720,40 @@ extern "C" int mdx_groupnorm_from_splitk_f16(const mdx_gemm_desc* prod, const fl
     return MDX_OK;
 }
 
+// Two-level fold of a producer's column partials: dst[b][j][c] = sum over the `f` consecutive row blocks j*f .. j*f+f-1 of
+// src[b][.][c] (fixed order: deterministic).  Tensors with hundreds of row blocks per sample (GLIDE's 128 x 128 / 256 x 256
+// levels: 512 HALO patches) are folded ONCE here to <= 64 blocks instead of in every gn_apply block.
+__global__ __launch_bounds__(256) void colstats_fold_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int nrb,
+                                                            int nrb2, int f, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y, b = blockIdx.z;
+    if (c >= C) return;
+    const float2* s = src + ((size_t)b * nrb + (size_t)j * f) * C + c;
+    const int n = min(f, nrb - j * f);
+    float su = 0.f, sq = 0.f;
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+        const float2 v0 = s[(size_t)k * C], v1 = s[(size_t)(k + 1) * C], v2 = s[(size_t)(k + 2) * C], v3 = s[(size_t)(k + 3) * C];
+        su += v0.x; sq += v0.y; su += v1.x; sq += v1.y; su += v2.x; sq += v2.y; su += v3.x; sq += v3.y;
+    }
+    for (; k < n; ++k) {
+        const float2 v = s[(size_t)k * C];
+        su += v.x;
+        sq += v.y;
+    }
+    dst[((size_t)b * nrb2 + j) * C + c] = make_float2(su, sq);
+}
+
+extern "C" int mdx_colstats_fold_f32(const float* src, int nrb, float* dst, int nrb2, int B, int C, mdx_stream_t s) {
+    MDX_REQUIRE(src && dst && nrb > 0 && nrb2 > 0 && nrb2 <= nrb && B > 0 && C > 0, "mdx_colstats_fold_f32: bad arguments");
+    const int f = (nrb + nrb2 - 1) / nrb2;
+    MDX_REQUIRE((nrb + f - 1) / f == nrb2, "mdx_colstats_fold_f32: nrb2 must be ceil(nrb / f) for an integer fold factor f");
+    hipLaunchKernelGGL(colstats_fold_kernel, dim3((C + 255) / 256, nrb2, B), dim3(256), 0, (hipStream_t)s,
+                       reinterpret_cast<const float2*>(src), reinterpret_cast<float2*>(dst), nrb, nrb2, f, C);
+    MDX_LAUNCH_CHECK("mdx_colstats_fold_f32");
+    return MDX_OK;
+}
+
 extern "C" int mdx_groupnorm_colstats_f16(const void* x1, int C1, const float* cs1, int nrb1, const void* x2, int C2,
                                           const float* cs2, int nrb2, const float* gamma, const float* beta,
                                           const float* scale, const float* shift, int mod_ld, void* y, int B, int HW,

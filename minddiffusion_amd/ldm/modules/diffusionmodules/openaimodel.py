@@ -385,6 +385,7 @@ class UNetModel:
             w["out.w"] = self._pack_conv(P["id_predictor.1.conv.weight"], cout_pad=self.cout_pad)
             w["out.cb"] = self._pad_vec(P["id_predictor.1.conv.bias"], self.cout_pad)
         self.w = w
+        self._frag_w = {}
         self._plans = {}
         self._ctx_key = None
         self._ctx_ref = None
@@ -434,6 +435,7 @@ class UNetModel:
 
         def add_gemm(oplist, **kw):
             d = ops.make_gemm_desc(**kw)
+            d._w_tensor = kw["w"]       # (python-side attribute: the packed weight tensor this descriptor points at)
             descs.append(d)
             if oplist is main:
                 producer[kw["out"].data_ptr()] = d
@@ -807,6 +809,24 @@ class UNetModel:
             d.workspace = P.gemm_ws.data_ptr()
             d.workspace_bytes = P.gemm_ws.numel() * 4
         P.gn_ws = torch.empty(max(gn_need[0], 4), dtype=f32, device=dev)
+        # ---- weight-streaming form of the small-M 3x3 convs (mdx_gemm_desc.w_frag): at M = 128 (the 8 x 8 level at UNet batch
+        # 2) a conv is a 30 MB weight stream with almost no arithmetic; the launches that resolve to 128 x 64 HALO tiles read a
+        # fragment-major copy of their weights straight into registers, twelve 1 KiB pieces in flight per wave.  Measured
+        # (round 3, op profile): M = 128 convs 20.3 -> 18.8 us, M = 512 convs 30.0 -> 31.0 us (each piece is fetched by the two
+        # waves that share its columns, which halves the unique bytes in flight): default threshold 128.
+        if ops.get_option("unet_conv_stream"):
+            for d in descs:
+                M = d.B * d.H * d.W      # (stride 1: output rows)
+                if not (d.ksize == 3 and d.stride == 1 and not d.upsample and d.c2 == 0 and d.c1 % 64 == 0 and d.N % 64 == 0
+                        and M <= ops.get_option("unet_conv_stream") and d.out_mode == ops.OUT_ROWMAJOR):
+                    continue
+                q = ops.gemm_query(d)
+                if not (q[0] == 128 and q[1] == 64 and q[3] == 1):
+                    continue
+                wkey = d._w_tensor.data_ptr()
+                if wkey not in self._frag_w:    # (one fragment-major copy per weight, shared by the plans of every shape)
+                    self._frag_w[wkey] = ops.pack_frag_weight(ops.unpack_gemm_weight(d._w_tensor, d.N, 9 * d.c1)).reshape(-1)
+                d.w, d.w_frag = self._frag_w[wkey].data_ptr(), 1
         # ---- GroupNorm statistics from the producers (mdx_gemm_desc.colstats_out): every GroupNorm input of the UNet is a conv
         # / Dense output (openaimodel.py:136,159,521; attention.py:83), so the launch that stores it can also emit per-column
         # {sum, sumsq} of each of its row blocks; the GroupNorm then folds those instead of re-reading the tensor (gn_stats

@@ -16,7 +16,12 @@ f32 = torch.float32
 # one explicit table instead of getenv() calls scattered through the code.
 # -1 auto | 0 never | 32 | 64 rows per block of the fused SpatialTransformer tail (MDX_UNET_ST_TAIL presets it for A/B runs)
 _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
-            "unet_st_head": int(os.environ.get("MDX_UNET_ST_HEAD", "-1"))}     # 0 = keep GroupNorm / proj_in / qkv unfused
+            "unet_st_head": int(os.environ.get("MDX_UNET_ST_HEAD", "-1")),     # 0 = keep GroupNorm / proj_in / qkv unfused
+            # 3x3 convs with at most this many output rows stream fragment-major weights to registers (0 = never)
+            "unet_conv_stream": int(os.environ.get("MDX_UNET_CONV_STREAM", "128")),
+            # GroupNorm inputs with > 64 row blocks per sample: 1 = pre-fold their column partials (mdx_colstats_fold_f32), 0 = the
+            # two-launch statistics pass.  Measured round 3: GLIDE 256x256 7.57 -> 7.44 images/s with the fold, SDv2 96x96 equal
+            "gn_colstats_fold": int(os.environ.get("MDX_GN_COLSTATS_FOLD", "0"))}
 
 
 def set_option(name, value):
@@ -96,10 +101,34 @@ def groupnorm(x1, x2, gamma, beta, eps, silu, ws=None, out=None, groups=32):
     return out
 
 
+class FoldedColStats:
+    """Column partials with more than 64 row blocks per sample (include/mdx.h: mdx_colstats_fold_f32): `raw` [B * nrb, C, 2] is
+    what the producer writes, `folded` [B * nrb2, C, 2] what the GroupNorm reads; groupnorm_colstats launches the fold."""
+
+    def __init__(self, raw, nrb, batch):
+        f = (nrb + 63) // 64
+        self.raw, self.nrb, self.batch = raw, nrb, batch
+        self.nrb2 = (nrb + f - 1) // f
+        self.folded = torch.zeros((batch * self.nrb2, raw.shape[1], 2), dtype=f32, device=raw.device)
+
+    def data_ptr(self):         # (the producer's descriptor points at the raw partials)
+        return self.raw.data_ptr()
+
+    def fold(self):
+        _lib.check(_lib.load().mdx_colstats_fold_f32(_ptr(self.raw), self.nrb, _ptr(self.folded), self.nrb2, self.batch,
+                                                     self.raw.shape[1], _stream()), "mdx_colstats_fold_f32")
+        return self.folded, self.nrb2
+
+
 def groupnorm_colstats(x1, cs1, nrb1, x2, cs2, nrb2, gamma, beta, eps, silu, out=None, groups=32, scale=None, shift=None,
                        mod_ld=0):
     """GroupNorm(groups)(cat(x1, x2)) [* (1 + scale) + shift] [+SiLU] with the statistics folded from the producers' column
-    partials (mdx_gemm_desc.colstats_out): one launch, one read of x."""
+    partials (mdx_gemm_desc.colstats_out): one launch, one read of x (plus one small fold launch per source with more than
+    64 row blocks per sample)."""
+    if isinstance(cs1, FoldedColStats):
+        cs1, nrb1 = cs1.fold()
+    if isinstance(cs2, FoldedColStats):
+        cs2, nrb2 = cs2.fold()
     B, HW, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[2]
     if out is None:
@@ -234,10 +263,30 @@ def pack_conv_weight(w4d, cin_pad=None, cout_pad=None):
     return pack_gemm_weight(conv_weight_k_order(w4d, cin_pad, cout_pad))
 
 
+def pack_conv_weight_frag(w4d):
+    """[Cout, Cin, 3, 3] -> the MFMA-fragment-major packing of mdx_gemm_desc.w_frag (Cout % 64 == 0, Cin % 64 == 0)."""
+    co, ci = w4d.shape[0], w4d.shape[1]
+    assert co % 64 == 0 and ci % 64 == 0
+    return pack_frag_weight(conv_weight_k_order(w4d).to(f16)).reshape(-1)
+
+
+def unpack_gemm_weight(packed, N, K):
+    """Inverse of pack_gemm_weight: the tile-major, pre-swizzled storage -> [N, K] (plan-time re-packing of a conv that turns
+    out to want the fragment-major form once its M is known)."""
+    Np, Kp = (N + 63) // 64 * 64, (K + 63) // 64 * 64
+    t = packed.view(Np // 64, Kp // 64, 64, 8, 8)
+    r = torch.arange(64, device=packed.device)
+    src = torch.arange(8, device=packed.device)[None, :] ^ ((r >> 1) & 7)[:, None]      # position -> logical chunk
+    inv = torch.argsort(src, 1)                                                          # logical chunk -> position
+    idx = inv[None, None, :, :, None].expand(Np // 64, Kp // 64, 64, 8, 8)
+    return torch.gather(t, 3, idx).permute(0, 2, 1, 3, 4).reshape(Np, Kp)[:N, :K].contiguous()
+
+
 def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, rowbias=None, rowbias_ld=0,
                    residual=None, residual_ld=0, ksize=1, stride=1, upsample=0, epilogue=EPI_NONE,
                    out_mode=OUT_ROWMAJOR, splitk=0, workspace=None, out_bs=0, out2=None, out2_ld=0, n_split=0, asym_pad=0,
-                   stats_out=None, ln_stats=None, ln_s=None, ln_eps=1e-5, tile_m=0, tile_n=0, colstats_out=None, stages=0):
+                   stats_out=None, ln_stats=None, ln_s=None, ln_eps=1e-5, tile_m=0, tile_n=0, colstats_out=None, stages=0,
+                   w_frag=0):
     d = GemmDesc()
     d.a = a.data_ptr()
     d.a2 = 0 if a2 is None else a2.data_ptr()
@@ -264,7 +313,7 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
     d.ln_s = 0 if ln_s is None else ln_s.data_ptr()
     d.ln_nt = 0 if ln_stats is None else (int(c1) + int(c2)) // 64
     d.ln_eps = float(ln_eps)
-    d.tile_m, d.tile_n, d.stages = int(tile_m), int(tile_n), int(stages)
+    d.tile_m, d.tile_n, d.stages, d.w_frag = int(tile_m), int(tile_n), int(stages), int(w_frag)
     d.colstats_out = 0 if colstats_out is None else colstats_out.data_ptr()
     d.colstats_cap = 0 if colstats_out is None else int(colstats_out.shape[0])
     return d
@@ -437,6 +486,7 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
     producer, desc of x2's producer), meta = index into `meta`; sets call["cs"] = (cs1, nrb1, cs2, nrb2).  `table` keeps the
     statistics buffers alive (descriptor address -> tensor)."""
     import math
+    fold_many = get_option("gn_colstats_fold") != 0
     for c in gn_calls:
         _, HW, C1 = c["x1"].shape
         is_head = c.get("head") is not None     # fused SpatialTransformer head: the statistics feed that launch
@@ -468,13 +518,21 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
             # launch will make (a 64-row split-K reduce writing into a buffer sized for 128-row tiles).
             d.colstats_out = 8
             rows = gemm_query(d)[5]
-            if rows <= 0 or HW % rows or (HW // rows > 64 and not is_head):
+            if rows <= 0 or HW % rows or HW // rows > 4096:
                 d.colstats_out = 0
-                return None      # (> 64 row blocks per sample: the fold in every gn_apply block would outweigh the pass it saves --
-                                 #  measured on the 256x256 / 128x128 levels of the GLIDE up-sampler, profiles/r02_e_ab.txt)
+                return None
             buf = torch.zeros((batch * (HW // rows), cx, 2), dtype=f32, device=device)
             d.colstats_out, d.colstats_cap = buf.data_ptr(), batch * (HW // rows)
-            table[key] = (buf, HW // rows)
+            if HW // rows > 64 and not is_head and fold_many:
+                # > 64 row blocks per sample (GLIDE's 128 x 128 / 256 x 256 levels: 512 HALO patches): folding them in EVERY
+                # gn_apply block cost more than the statistics pass it saved (profiles/r02_e_ab.txt); they are folded ONCE by
+                # a small launch in front of the GroupNorm instead (mdx_colstats_fold_f32)
+                table[key] = (FoldedColStats(buf, HW // rows, batch), HW // rows)
+            elif HW // rows > 64 and not is_head:
+                d.colstats_out = 0
+                return None
+            else:
+                table[key] = (buf, HW // rows)
             return table[key]
         s1 = stats_of(c["prod"][0], C1)
         if is_head:
@@ -485,7 +543,7 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
         if s1 is None or s2 is None:
             continue
         c["cs"] = (s1[0], s1[1], s2[0], s2[1])
-        meta[c["meta"]]["launches"] = 1
+        meta[c["meta"]]["launches"] = 1 + isinstance(s1[0], FoldedColStats) + isinstance(s2[0], FoldedColStats)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -881,3 +881,75 @@ def test_groupnorm_fused_with_splitk_reduce(ops, B, H, W, Cin, Cout, ks, splitk,
     dn.defer_reduce = 1
     with pytest.raises(Exception):
         _ops.gemm_run(dn)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,splitk,tile_n", [
+    (2, 8, 8, 128, 128, 1, 64),       # two-sample 8 x 8 tiles, one chunk pair, no split
+    (2, 8, 8, 1280, 1280, 10, 64),    # the deepest UNet level: M = 128, K = 11520, ten chunk-aligned splits (reduce kernel)
+    (2, 8, 8, 640, 320, 3, 64),       # in-kernel split-K reduce on top of the streamed weights
+    (3, 8, 8, 256, 192, 2, 64),       # odd batch: the second sample of the last tile does not exist
+    (2, 16, 16, 1280, 1280, 5, 64),   # 16 x 16 level: 8 x 16 patches (PW = 16), M = 512
+    (1, 16, 32, 192, 128, 1, 128),    # 128-column tiles
+])
+def test_conv3x3_weight_streaming_form_is_bit_identical(ops, B, H, W, Cin, Cout, splitk, tile_n):
+    """mdx_gemm_desc.w_frag: the HALO 3x3 conv reading fragment-major weights straight into registers (no weight tiles in LDS,
+    one barrier per 64-channel chunk) multiplies and adds every output's products in the same order as the tile-major form --
+    bit-identical, with bias + per-sample time-embedding row + residual on top -- and agrees with the fp32 reference to fp16
+    accuracy."""
+    rng = np.random.RandomState(B * H + Cin + Cout)
+    x = h16(rng.standard_normal((B, Cin, H, W)))
+    wt = h16(rng.standard_normal((Cout, Cin, 3, 3)) / math.sqrt(9 * Cin))
+    bv = rng.standard_normal(Cout).astype(np.float32)
+    rb = rng.standard_normal((B, Cout)).astype(np.float32)
+    res = h16(rng.standard_normal((B, Cout, H, W)))
+    ref = O.conv2d(torch.tensor(x), torch.tensor(wt), torch.tensor(bv)) + torch.tensor(rb)[:, :, None, None] + torch.tensor(res)
+    xd, resd = dev16(nhwc(x)), dev16(nhwc(res))
+    outs = {}
+    for frag in (0, 1):
+        wd = ops.pack_conv_weight_frag(torch.tensor(wt).to(DEV)) if frag else pack_conv(wt)
+        out = torch.empty((B, H * W, Cout), dtype=torch.float16, device=DEV)
+        d = ops.make_gemm_desc(xd, wd, Cout, B, H, W, Cin, out, Cout, bias=dev32(bv), rowbias=dev32(rb), rowbias_ld=Cout,
+                               residual=resd, residual_ld=Cout, ksize=3, splitk=splitk, tile_m=128, tile_n=tile_n, w_frag=frag)
+        need = ops.gemm_workspace_bytes(d)
+        ws = ops.new_gemm_workspace(max(need, 1 << 20), DEV)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        q = ops.gemm_query(d)
+        assert q[3] == 1 and q[0] == 128, q
+        ops.gemm_run(d)
+        torch.cuda.synchronize()
+        outs[frag] = out.clone()
+    assert torch.equal(outs[0], outs[1]), "weight-streaming form differs from the tile-major form"
+    got = from_nhwc(outs[1].float().cpu().numpy().reshape(B, H * W, Cout), B, H, W)
+    check(f"conv3x3_stream_B{B}_{H}x{W}_{Cin}_{Cout}_s{splitk}", got, ref, rel_l2=1e-3)
+    # the launch refuses fragment-major weights where the HALO kernel does not apply
+    bad = ops.make_gemm_desc(xd, wd, Cout, B, H, W, Cin, out, Cout, ksize=3, stride=2, w_frag=1)
+    from minddiffusion_amd._lib import MdxError
+    with pytest.raises(MdxError):
+        ops.gemm_run(bad)
+
+
+@pytest.mark.parametrize("nrb,C,B", [(512, 192, 2), (72, 320, 3), (65, 640, 1)])
+def test_groupnorm_colstats_two_level_fold(ops, nrb, C, B):
+    """mdx_colstats_fold_f32 + mdx_groupnorm_colstats_f16: column partials with more than 64 row blocks per sample (GLIDE's
+    256 x 256 level: 512 HALO patches; SDv2 at 96 x 96: 72) folded once to <= 64 blocks, then normalised -- against the
+    fp32 GroupNorm of the tensor and against the fold done on the host."""
+    rows = 16
+    HW = nrb * rows
+    rng = np.random.RandomState(nrb + C)
+    x = h16(rng.standard_normal((B, HW, C)) * (0.5 + rng.rand(C)) + rng.standard_normal(C))
+    g, b = (1.0 + 0.2 * rng.standard_normal(C)).astype(np.float32), (0.1 * rng.standard_normal(C)).astype(np.float32)
+    xd = dev16(x)
+    blk = xd.float().reshape(B * nrb, rows, C)
+    cs = torch.stack([blk.sum(1), (blk * blk).sum(1)], 2).contiguous()
+    f = ops.FoldedColStats(cs, nrb, B)
+    folded, nrb2 = f.fold()
+    torch.cuda.synchronize()
+    assert nrb2 <= 64
+    fac = (nrb + nrb2 - 1) // nrb2
+    pad = torch.zeros((B, nrb2 * fac - nrb, C, 2), device=DEV)
+    host = torch.cat([cs.reshape(B, nrb, C, 2), pad], 1).reshape(B, nrb2, fac, C, 2).sum(2).reshape(B * nrb2, C, 2)
+    check(f"colstats_fold_nrb{nrb}", folded, host, rel_l2=1e-6)
+    out = ops.groupnorm_colstats(xd, f, nrb, None, None, 0, dev32(g), dev32(b), 1e-5, True)
+    xt = torch.tensor(x).permute(0, 2, 1).reshape(B, C, HW, 1)
+    ref = O.silu(O.group_norm(xt, torch.tensor(g), torch.tensor(b), 1e-5)).reshape(B, C, HW).permute(0, 2, 1)
+    check(f"groupnorm_folded_colstats_nrb{nrb}_C{C}", out, ref, rel_l2=1e-3)
