@@ -822,15 +822,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
 // chunk (the halo swap) instead of one per tap.  With the LDS ring a block keeps two 8 KiB weight tiles in flight (32 KiB
 // per CU: ~2 TB/s chip-wide at the HBM round trip); here 4 waves x 12 KiB x 2 blocks = 96 KiB per CU.  Same k order per
 // output, same epilogue: bit-identical results.
-template <int BM, int BN, int NSB, bool SWAP, int PW, bool BDIR = false>
+// W4 (BDIR, 128 x 128 tiles, slab output only): the four waves sit side by side along N -- each owns 32 columns and ALL 128 rows --
+// instead of 2 x 2.  In the 2 x 2 arrangement the two waves of a column pair fetch the same weight pieces, so half of the bytes
+// a CU has in flight are duplicates; side by side every piece is fetched once (the A fragments, which come from LDS, are read
+// by all four waves instead).
+template <int BM, int BN, int NSB, bool SWAP, int PW, bool BDIR = false, bool W4 = false>
 __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel(const GemmParams p) {
     static_assert(PW == 16 || (PW == 8 && BM == 128), "patch width 16, or 8 with two-sample tiles");
+    static_assert(!W4 || (BDIR && BM == 128 && BN == 128 && !SWAP), "W4: weight-streaming 128 x 128 tiles with slab output");
     constexpr int NW = BM / 32;              // waves: (NW/2) x 2, each 64 patch pixels x BN/2 channels
     constexpr int PH = BM / 16;              // PW = 16: patch rows (8 | 16)
     constexpr int HWD = PW + 2;              // halo width in pixels (18 | 10)
-    constexpr int WROWS = BM / (NW / 2);     // patch pixels per wave row (64)
+    constexpr int WROWS = W4 ? BM : BM / (NW / 2);     // patch pixels per wave row (64; W4: all 128)
     constexpr int TM = WROWS / 32;
-    constexpr int TN = BN / 64;
+    constexpr int TN = W4 ? 1 : BN / 64;
     constexpr int HROWS = PW == 16 ? (PH + 2) * 18 : (BM / 64) * 100;   // halo pixels (180 | 324 | 200)
     constexpr int HINST = (HROWS + 7) / 8;   // halo DMA instructions per chunk (23 | 41)
     constexpr int HALO_BYTES = HINST * 1024;
@@ -843,7 +848,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = W4 ? 0 : wave >> 1, wn = W4 ? wave : wave & 1;
     const int hi = lane >> 5;
     const int l31 = lane & 31;
 
@@ -947,7 +952,8 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
         const unsigned kpieces = (unsigned)p.kt64 * 4u;          // 1 KiB pieces (16-wide k-steps) per 32-column tile
         unsigned pbase[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) pbase[j] = (unsigned)((n0 + wn * (BN / 2) + j * 32) >> 5) * kpieces + (unsigned)kt_begin * 4u;
+        for (int j = 0; j < TN; ++j)
+            pbase[j] = (unsigned)((n0 + (W4 ? wn * 32 : wn * (BN / 2) + j * 32)) >> 5) * kpieces + (unsigned)kt_begin * 4u;
         const unsigned voffw = (unsigned)lane * 16u;
         // halo first, then the ring: the halo DMAs are then older than the PFB * TN youngest loads at every chunk boundary
 #pragma unroll
@@ -1009,14 +1015,35 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ring refills past the end of the range are still in flight
         __syncthreads();
         trace_mark(p, 3);
-        if constexpr (PW == 16)
-            gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split, bpre, tile_m,
-                                            tile_id);
-        else
-            gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{tile_m * BM}, n0, split, bpre, tile_m, tile_id);
-        trace_mark(p, 4);
-        return;
+        if constexpr (W4) {
+            // split-K partial slab [split][M][N], C layout (lane -> column, registers -> rows): 128-byte row segments per store
+            float* wsz = p.ws + (size_t)split * p.M * p.N;
+            const int n = n0 + wn * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    int m;
+                    if constexpr (PW == 16)
+                        m = (pb * p.H + py0) * p.W + px0 + (row >> 4) * p.W + (row & 15);
+                    else
+                        m = tile_m * BM + row;
+                    if (m < p.M && n < p.N) wsz[(size_t)m * p.N + n] = acc[i][0][r];
+                }
+            trace_mark(p, 4);
+            return;
+        } else {
+            if constexpr (PW == 16)
+                gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split, bpre,
+                                                tile_m, tile_id);
+            else
+                gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{tile_m * BM}, n0, split, bpre, tile_m, tile_id);
+            trace_mark(p, 4);
+            return;
+        }
     }
+    if constexpr (!BDIR) {
     // prologue: whole halo of the first chunk + the first NSB-1 weight tiles
 #pragma unroll
     for (int q = 0; q < HJ; ++q) dma_halo(q, c_begin, 0);
@@ -1093,6 +1120,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     else   // two whole 64-pixel samples: tile rows are consecutive output rows
         gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{tile_m * BM}, n0, split, bpre, tile_m, tile_id);
     trace_mark(p, 4);
+    }
 }
 
 // 8 consecutive fp32 of row m from every split-K slab, summed in slab order (deterministic).  The loads of up to four
@@ -1567,7 +1595,7 @@ bool launch_bn(const GemmCfg& c, const GemmParams& p, bool swap, bool fastk, dim
     return true;
 }
 
-template <int BM, int BN, int NSB, bool SWAP, int PW = 16, bool BDIR = false>
+template <int BM, int BN, int NSB, bool SWAP, int PW = 16, bool BDIR = false, bool W4 = false>
 void launch_halo(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t hinst = ((PW == 16 ? (BM / 16 + 2) * 18 : (BM / 64) * 100) + 7) / 8;
     constexpr size_t ring = 2 * hinst * 1024 + (BDIR ? 0 : (size_t)NSB * BN * 128);
@@ -1575,17 +1603,21 @@ void launch_halo(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t lds = ring > epi ? ring : epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW, BDIR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW, BDIR, W4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW, BDIR>), grid, dim3(BM * 2), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW, BDIR, W4>), grid, dim3(BM * 2), lds, st, p);
 }
 
 // weight-streaming form (fragment-major weights): 128-row tiles only, no weight ring in LDS
 template <int BN, int PW>
 void launch_halo_bdir(const GemmParams& p, bool swap, dim3 grid, hipStream_t st) {
     if (swap) launch_halo<128, BN, 2, true, PW, true>(p, grid, st); else launch_halo<128, BN, 2, false, PW, true>(p, grid, st);
+}
+template <int PW>
+void launch_halo_bdir_w4(const GemmParams& p, dim3 grid, hipStream_t st) {
+    launch_halo<128, 128, 2, false, PW, true, true>(p, grid, st);
 }
 
 template <int BM, int BN, int PW = 16>
@@ -1860,10 +1892,14 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         if (mdx_opt(MDX_OPT_HALO_NSB) >= 2 && mdx_opt(MDX_OPT_HALO_NSB) <= 3) nsb = mdx_opt(MDX_OPT_HALO_NSB);
         if (d->w_frag) {
             MDX_REQUIRE(c.bm == 128, "mdx_gemm_f16: fragment-major weights run on 128-row HALO tiles only (got tile_m %d)", c.bm);
+            // 128-column tiles whose split-K partials go to slabs (no in-kernel reduce): waves side by side along N
+            const bool w4 = bn == 128 && ns > 1 && !rs.fixup && !swap;
             if (halo8_eligible(p)) {
-                if (bn == 128) launch_halo_bdir<128, 8>(p, swap, grid, st); else launch_halo_bdir<64, 8>(p, swap, grid, st);
+                if (w4) launch_halo_bdir_w4<8>(p, grid, st);
+                else if (bn == 128) launch_halo_bdir<128, 8>(p, swap, grid, st); else launch_halo_bdir<64, 8>(p, swap, grid, st);
             } else {
-                if (bn == 128) launch_halo_bdir<128, 16>(p, swap, grid, st); else launch_halo_bdir<64, 16>(p, swap, grid, st);
+                if (w4) launch_halo_bdir_w4<16>(p, grid, st);
+                else if (bn == 128) launch_halo_bdir<128, 16>(p, swap, grid, st); else launch_halo_bdir<64, 16>(p, swap, grid, st);
             }
         } else if (c.bm == 256) {
             if (bn == 128) launch_halo_cfg<256, 128>(p, nsb, swap, grid, st); else launch_halo_cfg<256, 64>(p, nsb, swap, grid, st);

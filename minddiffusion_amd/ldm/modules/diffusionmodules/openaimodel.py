@@ -821,7 +821,18 @@ class UNetModel:
                         and M <= ops.get_option("unet_conv_stream") and d.out_mode == ops.OUT_ROWMAJOR):
                     continue
                 q = ops.gemm_query(d)
-                if not (q[0] == 128 and q[1] == 64 and q[3] == 1):
+                w4 = ops.get_option("unet_conv_stream_w4")
+                if w4 and q[3] == 1 and d.N % 128 == 0 and d.c1 // 64 >= 5 and not d.colstats_out and not d.defer_reduce:
+                    # side-by-side waves on 128-column tiles (every weight piece fetched once per block), slab split-K
+                    keep = (d.tile_m, d.tile_n, d.splitk)
+                    d.tile_m, d.tile_n, d.splitk = 128, 128, min(d.c1 // 64, w4)
+                    q = ops.gemm_query(d)
+                    if not (q[0] == 128 and q[1] == 128 and q[3] == 1 and q[2] > 4 and not q[6]):
+                        d.tile_m, d.tile_n, d.splitk = keep
+                        q = ops.gemm_query(d)
+                if not (q[0] == 128 and q[1] in (64, 128) and q[3] == 1):
+                    continue
+                if q[1] == 128 and not (q[2] > 1 and not q[6]):
                     continue
                 wkey = d._w_tensor.data_ptr()
                 if wkey not in self._frag_w:    # (one fragment-major copy per weight, shared by the plans of every shape)
@@ -833,13 +844,16 @@ class UNetModel:
         # disappears: one launch and one read instead of two).  Done for the tensors that take the two-launch path today
         # (>= 1024 pixels per sample); the small deep-level tensors already use the one-launch fused kernel.
         P.colstats = {}
-        # opt-in: the one-launch GroupNorm of the deep levels can also BE the split-K reduce of the conv right in front of it
-        # (mdx_gemm_desc.defer_reduce).  Measured SLOWER at UNet batch 2 (+0.7 % on the evaluation, profiles/r02_c_ab.txt): the
-        # fused launch has only (column blocks x samples) = 64 blocks to pull ~26 MB of slabs, the chip-wide reduce kernel it
-        # replaces has 2048.
-        if os.environ.get("MDX_UNET_GN_SPLITK_FUSE", "0") == "1":
+        # The one-launch GroupNorm of the deep levels can also BE the split-K reduce of the conv right in front of it
+        # (mdx_gemm_desc.defer_reduce): -22 launches per evaluation at equal time (ops._OPTIONS["unet_gn_splitk_fuse"]).
+        fuse_hw = ops.get_option("unet_gn_splitk_fuse")     # fuse for tensors of at most this many pixels per sample (0 = never)
+        if fuse_hw:
             for c in gn_calls:
+                if c.get("head") is not None:
+                    continue
                 _, HW, C1 = c["x1"].shape
+                if HW > fuse_hw:
+                    continue
                 cpg = C1 // 32
                 L = cpg // math.gcd(cpg, 8)
                 d = c["prod"][0]

@@ -21,7 +21,14 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
             "unet_conv_stream": int(os.environ.get("MDX_UNET_CONV_STREAM", "128")),
             # GroupNorm inputs with > 64 row blocks per sample: 1 = pre-fold their column partials (mdx_colstats_fold_f32), 0 = the
             # two-launch statistics pass.  Measured round 3: GLIDE 256x256 7.57 -> 7.44 images/s with the fold, SDv2 96x96 equal
-            "gn_colstats_fold": int(os.environ.get("MDX_GN_COLSTATS_FOLD", "0"))}
+            "gn_colstats_fold": int(os.environ.get("MDX_GN_COLSTATS_FOLD", "0")),
+            # GroupNorms of at most this many pixels per sample take over the split-K reduce of the conv in front of them
+            # (mdx_groupnorm_from_splitk_f16).  Round 3, same box: 0 -> 4.437 ms per UNet step / 285 launches, 64 -> 4.422 / 274,
+            # 256 -> 4.431 / 263 (round 2 had measured +0.7 %: the reduce kernels it replaces were cheaper then)
+            "unet_gn_splitk_fuse": int(os.environ.get("MDX_UNET_GN_SPLITK_FUSE", "256")),
+            # streamed convs: > 0 = 128-column tiles with the four waves side by side and this many K splits at most.  Measured
+            # SLOWER (M = 128 convs 18.5 -> 20.4-23.6 us): off
+            "unet_conv_stream_w4": int(os.environ.get("MDX_UNET_CONV_STREAM_W4", "0"))}
 
 
 def set_option(name, value):

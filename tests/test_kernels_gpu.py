@@ -890,6 +890,9 @@ def test_groupnorm_fused_with_splitk_reduce(ops, B, H, W, Cin, Cout, ks, splitk,
     (3, 8, 8, 256, 192, 2, 64),       # odd batch: the second sample of the last tile does not exist
     (2, 16, 16, 1280, 1280, 5, 64),   # 16 x 16 level: 8 x 16 patches (PW = 16), M = 512
     (1, 16, 32, 192, 128, 1, 128),    # 128-column tiles
+    (2, 8, 8, 1280, 1280, 20, 128),   # 128-column tiles + slab split-K: the four waves side by side along N (W4)
+    (2, 16, 16, 640, 256, 5, 128),    # W4 on 8 x 16 patches
+    (3, 8, 8, 384, 128, 6, 128),      # W4, odd batch
 ])
 def test_conv3x3_weight_streaming_form_is_bit_identical(ops, B, H, W, Cin, Cout, splitk, tile_n):
     """mdx_gemm_desc.w_frag: the HALO 3x3 conv reading fragment-major weights straight into registers (no weight tiles in LDS,
