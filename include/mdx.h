@@ -165,6 +165,16 @@ typedef struct mdx_gemm_desc {
     int tile_m;           /* 0 = auto (tuned table, then the cost model); 64 | 128 forces the M tile.  For tools/tune_gemm.py,
                              which measures the (tile_m, splitk) candidates of every UNet shape on the device. */
     int tile_n;           /* 0 = auto; 64 | 128 forces the N tile (same purpose; GEGLU always uses 128) */
+    /* ResBlock skip_connection fused into the block's second conv (openaimodel.py:174, 201-205): when skip_w is set,
+     *   out = conv3x3(a) + conv1x1(cat(skip_a, skip_a2)) (+ bias + rowbias + residual ...),
+     * the 1x1 conv over the block's RAW input riding on this launch as extra K tiles (one accumulator, one epilogue; `bias` must
+     * hold the SUM of the two convs' biases).  skip_a / skip_a2: NHWC fp16 [B][H][W][skip_c1 / skip_c2] (same H, W), channels
+     * multiples of 64; skip_w: packed tile-major weights of logical shape [N][skip_c1 + skip_c2].  Single-source 3x3 stride-1
+     * convs that resolve to the HALO kernel only (mdx_gemm_query out7[3] == 1); not with w_frag. */
+    const void* skip_a;
+    const void* skip_a2;
+    int skip_c1, skip_c2;
+    const void* skip_w;
     int w_frag;           /* 1: `w` is packed in MFMA-FRAGMENT order instead of the tile-major format above -- [N / 32 column tiles]
                              [K / 16 k-steps][64 lanes][8 halves], piece (ct, s)[lane] = W[32 ct + lane % 32][16 s + 8 (lane / 32)
                              + 0..7], K in the conv order of item 1 (ops.pack_conv_weight_frag) -- and the launch streams it

@@ -67,6 +67,12 @@ struct GemmParams {
     unsigned a_bytes, a2_bytes, w_bytes;
     int bk;
     unsigned long long* trace;   // diagnostics: per-block phase timestamps (mdx_probe_gemm_trace), else null
+    // ResBlock skip_connection fused into conv2 (mdx_gemm_desc.skip_w): extra 1x1 K tiles over the block's raw input
+    const f16* skip_a;
+    const f16* skip_a2;
+    const f16* skip_w;
+    int skip_c1, skip_c2, skip_kt, skip_kt_per_split;
+    unsigned skip_a_bytes, skip_a2_bytes, skip_w_bytes;
 };
 
 
@@ -1112,6 +1118,93 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
         }
     }
 
+    if (p.skip_w) {
+        // ---- ResBlock skip_connection (openaimodel.py:174, 201-205: conv1x1 over the block's RAW input, the virtual concat of
+        // x and the UNet skip tensor on the up path) as extra K tiles of this launch: out = conv3x3(h) + conv1x1(x), one
+        // accumulator, one epilogue, no second launch and no fp16 round trip of the skip tensor.  Generic 128-byte-row A tiles
+        // of this block's patch pixels (rows = patch pixels, 64 channels per tile) in the halo area, weight tiles in the ring
+        // area, two stages, one barrier per tile; this split's share of the skip K tiles.
+        constexpr int SA_BYTES = BM * 128;
+        static_assert(2 * SA_BYTES <= 2 * HALO_BYTES && NSB >= 2, "skip tiles reuse the halo / ring areas");
+        const __amdgpu_buffer_rsrc_t rs_s1 = make_rsrc(p.skip_a, p.skip_a_bytes);
+        const __amdgpu_buffer_rsrc_t rs_s2 = make_rsrc(p.skip_a2 ? p.skip_a2 : p.skip_a, p.skip_a2 ? p.skip_a2_bytes : p.skip_a_bytes);
+        const __amdgpu_buffer_rsrc_t rs_sw = make_rsrc(p.skip_w, p.skip_w_bytes);
+        const int sk_begin = split * p.skip_kt_per_split, sk_end = min(p.skip_kt, sk_begin + p.skip_kt_per_split);
+        constexpr int SAJ = BM / 8 / NW;              // A DMA instructions per wave per tile (8 rows each)
+        int s_pix[SAJ];                               // source pixel of this lane's row, or -1
+        unsigned s_cb[SAJ];
+#pragma unroll
+        for (int j = 0; j < SAJ; ++j) {
+            const int row = (wave * SAJ + j) * 8 + lrow;
+            int pix;
+            if constexpr (PW == 16) {
+                pix = (pb * p.H + py0 + (row >> 4)) * p.W + px0 + (row & 15);
+            } else {
+                pix = tile_m * BM + row;
+                if (pix >= p.M) pix = -1;
+            }
+            s_pix[j] = pix;
+            s_cb[j] = (unsigned)((lchk ^ ((row >> 1) & 7)) * 16);
+        }
+        unsigned sb_off[BJ];
+        const int skt64 = p.skip_kt;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int row = (wave * BJ + j) * 8 + lrow;
+            const int panel = (n0 >> 6) + (row >> 6);
+            sb_off[j] = (unsigned)(((size_t)panel * skt64) * 8192 + ((row & 63) * 8 + lchk) * 16);
+        }
+        auto stage_skip = [&](int kt, int st) {
+            int ci0 = kt * 64;
+            const bool second = ci0 >= p.skip_c1;
+            const int cs2 = (second ? p.skip_c2 : p.skip_c1) * 2;
+            if (second) ci0 -= p.skip_c1;
+#pragma unroll
+            for (int j = 0; j < SAJ; ++j) {
+                const unsigned off = s_pix[j] >= 0 ? (unsigned)(s_pix[j] * cs2) + (unsigned)(ci0 * 2) + s_cb[j] : MDX_OOB;
+                void* dst = smem + st * SA_BYTES + (wave * SAJ + j) * 1024;
+                if (second)
+                    dma16(rs_s2, dst, off);
+                else
+                    dma16(rs_s1, dst, off);
+            }
+#pragma unroll
+            for (int j = 0; j < BJ; ++j)
+                dma16(rs_sw, smem + 2 * HALO_BYTES + st * B_BYTES + (wave * BJ + j) * 1024, sb_off[j] + (unsigned)kt * 8192);
+        };
+        __syncthreads();            // every wave is done with the halos and the weight ring
+        const int sa_row_off = (wm * WROWS + l31) * 128;
+        const int s_swz = (l31 >> 1) & 7;
+        if (sk_begin < sk_end) stage_skip(sk_begin, 0);
+        for (int kt = sk_begin; kt < sk_end; ++kt) {
+            const int st = (kt - sk_begin) & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // tile kt landed for everyone; stage st ^ 1 (tile kt - 1) is free
+            if (kt + 1 < sk_end) stage_skip(kt + 1, st ^ 1);
+            const char* sa = smem + st * SA_BYTES;
+            const char* sbk = smem + 2 * HALO_BYTES + st * B_BYTES;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                f16x8 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const f16x8*>(sa + sa_row_off + i * 32 * 128 + (((2 * s4 + hi) ^ s_swz) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[j] = *reinterpret_cast<const f16x8*>(sbk + (b_row_off - 2 * HALO_BYTES) + j * 32 * 128 + (((2 * s4 + hi) ^ swz_b) << 4));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (SWAP)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
     __syncthreads();
     trace_mark(p, 3);
     if constexpr (PW == 16)
@@ -1388,6 +1481,25 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
         MDX_REQUIRE(p.out_mode == MDX_OUT_ROWMAJOR && p.epilogue == MDX_EPI_NONE && !p.n_split && !p.ln_stats && !p.stats_out &&
                         !p.out_bs && p.N % 8 == 0,
                     "mdx_gemm_f16: column statistics come from plain row-major launches only");
+    p.skip_a = (const f16*)d->skip_a;
+    p.skip_a2 = (const f16*)d->skip_a2;
+    p.skip_w = (const f16*)d->skip_w;
+    p.skip_c1 = d->skip_c1;
+    p.skip_c2 = d->skip_c2;
+    if (p.skip_w) {
+        MDX_REQUIRE(p.skip_a && d->skip_c1 > 0 && d->skip_c1 % 64 == 0 && d->skip_c2 >= 0 && d->skip_c2 % 64 == 0 &&
+                        (d->skip_c2 == 0) == (d->skip_a2 == nullptr),
+                    "mdx_gemm_f16: fused skip needs skip_a, skip_c1 %% 64 == 0, skip_c2 %% 64 == 0 and skip_a2 iff skip_c2");
+        MDX_REQUIRE(p.ksize == 3 && p.stride == 1 && !p.upsample && p.c2 == 0 && p.out_mode == MDX_OUT_ROWMAJOR && !d->w_frag,
+                    "mdx_gemm_f16: the fused skip rides on a single-source 3x3 stride-1 row-major conv (tile-major weights)");
+        p.skip_kt = (d->skip_c1 + d->skip_c2) / 64;
+        const size_t s1 = (size_t)d->B * d->H * d->W * d->skip_c1 * 2, s2 = (size_t)d->B * d->H * d->W * d->skip_c2 * 2;
+        const size_t sw = (size_t)((p.N + 63) / 64) * p.skip_kt * 8192;
+        MDX_REQUIRE(s1 <= 0x80000000ull && s2 <= 0x80000000ull && sw <= 0x80000000ull, "mdx_gemm_f16: skip operand larger than 2 GiB");
+        p.skip_a_bytes = (unsigned)s1;
+        p.skip_a2_bytes = (unsigned)s2;
+        p.skip_w_bytes = (unsigned)sw;
+    }
     if (p.rowbias) MDX_REQUIRE(p.rowbias_ld % 4 == 0, "mdx_gemm_f16: rowbias_ld must be a multiple of 4");
     if (p.residual) MDX_REQUIRE(p.residual_ld % 8 == 0, "mdx_gemm_f16: residual_ld must be a multiple of 8");
     MDX_REQUIRE(p.out_ld % 8 == 0 && p.out_bs % 8 == 0 && p.out_bs >= 0, "mdx_gemm_f16: out_ld / out_bs must be multiples of 8");
@@ -1741,6 +1853,10 @@ static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
         }
     }
     r.halo = r.c.bm >= 128 && halo_eligible(p, r.c.bm);
+    if (p.skip_w && !r.halo) {
+        mdx_set_error("mdx_gemm_f16: the fused skip needs a launch that resolves to the HALO 3x3 kernel (ask mdx_gemm_query first)");
+        return MDX_E_INVALID;
+    }
     p.nsplit = ns;
     if (r.halo) {
         // chunk-aligned splits: a split owns whole 64-channel chunks (9 K tiles each)
@@ -1753,6 +1869,7 @@ static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
     }
     p.nsplit = (p.ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;  // no empty splits
     r.ns = p.nsplit;
+    p.skip_kt_per_split = p.skip_w ? (p.skip_kt + p.nsplit - 1) / p.nsplit : 0;      // every split takes its share of the skip tiles
     r.fixup = r.ns > 1 && fixup_eligible(d, p, r.c.bm, bn, r.ns);
     p.tickets = r.fixup ? reinterpret_cast<unsigned*>(p.ws) : nullptr;
     if (r.ns > 1 && !r.fixup) p.ws += MDX_TICKET_SLOTS;     // [split][M][N] slabs of the reduce-kernel path start behind the head

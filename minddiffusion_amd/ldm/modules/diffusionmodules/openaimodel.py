@@ -499,14 +499,23 @@ class UNetModel:
         P.ctx_pad = None
         ctx_kv = {}
 
-        def conv3(src, cin, cout, wt, bias, h, wd, stride=1, upsample=0, rowbias=None, residual=None, src2=None, c2=0):
+        def conv3(src, cin, cout, wt, bias, h, wd, stride=1, upsample=0, rowbias=None, residual=None, src2=None, c2=0,
+                  skip=None):
+            """skip = (x, x2, c1, c2, packed 1x1 weights): the ResBlock's skip_connection rides on this launch as extra K
+            tiles (mdx_gemm_desc.skip_w); `bias` then holds the sum of both convs' biases."""
             hs, ws_ = (2 * h, 2 * wd) if upsample else (h, wd)
             ho, wo = (hs + 2 - 3) // stride + 1, (ws_ + 2 - 3) // stride + 1
             out = A.get((B, ho * wo, cout))
+            kw = {}
+            if skip is not None:
+                kw = dict(skip_a=skip[0], skip_a2=skip[1], skip_c1=skip[2], skip_c2=skip[3], skip_w=skip[4])
             add_gemm(main, a=src, w=wt, N=cout, B=B, H=h, W=wd, c1=cin - c2, out=out, out_ld=cout, a2=src2, c2=c2,
                      bias=bias, rowbias=rowbias, rowbias_ld=self._emb_total if rowbias is not None else 0,
                      residual=residual, residual_ld=cout if residual is not None else 0, ksize=3, stride=stride,
-                     upsample=upsample)
+                     upsample=upsample, **kw)
+            if skip is not None:
+                meta[-1]["flops"] += 2 * B * ho * wo * cout * (skip[2] + skip[3])
+                meta[-1]["info"] += f" +skip1x1 K={skip[2] + skip[3]}"
             return out, ho, wo
 
         def dense(oplist, src, rows_b, tokens, cin, nout, wt, bias=None, residual=None, epilogue=ops.EPI_NONE,
@@ -579,6 +588,14 @@ class UNetModel:
                 ln_stats[(rows, width)] = torch.zeros((rows, width // 64, 2), dtype=f32, device=dev)
             return ln_stats[(rows, width)]
 
+        def skip_fusable(a2, c1, c2, cout, ho, wo, wt):
+            """Can the ResBlock's 1x1 skip_connection ride on its second conv (mdx_gemm_desc.skip_w)?  Channel counts in whole
+            64-channel K tiles, and the conv must resolve to the HALO 3x3 kernel."""
+            if not ops.get_option("unet_skip_fuse") or c1 % 64 or c2 % 64 or cout % 64:
+                return False
+            probe = ops.make_gemm_desc(a=a2, w=wt, N=cout, B=B, H=ho, W=wo, c1=cout, out=a2, out_ld=cout, ksize=3)
+            return ops.gemm_query(probe)[3] == 1
+
         def resblock(pre, x, x2, cin, cout, h, wd, mode=None):
             """ResBlock.construct openaimodel.py:176-205; x2 = skip tensor of the (virtual) concat.  mode 'up' / 'down' is the
             resblock_updown form: nearest-2x / 2x2 average pooling of BOTH the normalised branch and the skip input
@@ -614,6 +631,15 @@ class UNetModel:
             else:
                 add_gn(hbuf, None, w[pre + "out_layers_norm.g"], w[pre + "out_layers_norm.b"], 1e-5, True, a2)
             A.release(hbuf)
+            if cin != cout and mode is None and skip_fusable(a2, cin - c2, c2, cout, ho, wo, w[pre + "conv2.w"]):
+                # skip_connection (1x1 over the raw input, openaimodel.py:174) as extra K tiles of conv2: one launch less per
+                # ResBlock whose channel count changes, and the skip tensor never exists
+                if (pre + "conv2skip.b") not in w:
+                    w[pre + "conv2skip.b"] = (w[pre + "conv2.b"] + w[pre + "skip.b"]).contiguous()
+                out, _, _ = conv3(a2, cout, cout, w[pre + "conv2.w"], w[pre + "conv2skip.b"], ho, wo,
+                                  skip=(x, x2, cin - c2, c2, w[pre + "skip.w"]))
+                A.release(a2)
+                return out, ho, wo
             if cin != cout:
                 skip = dense(main, x, B, hw, cin, cout, w[pre + "skip.w"], bias=w[pre + "skip.b"], src2=x2, c2=c2)
             else:
@@ -818,7 +844,7 @@ class UNetModel:
             for d in descs:
                 M = d.B * d.H * d.W      # (stride 1: output rows)
                 if not (d.ksize == 3 and d.stride == 1 and not d.upsample and d.c2 == 0 and d.c1 % 64 == 0 and d.N % 64 == 0
-                        and M <= ops.get_option("unet_conv_stream") and d.out_mode == ops.OUT_ROWMAJOR):
+                        and M <= ops.get_option("unet_conv_stream") and d.out_mode == ops.OUT_ROWMAJOR and not d.skip_w):
                     continue
                 q = ops.gemm_query(d)
                 w4 = ops.get_option("unet_conv_stream_w4")

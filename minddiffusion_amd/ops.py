@@ -28,7 +28,9 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
             "unet_gn_splitk_fuse": int(os.environ.get("MDX_UNET_GN_SPLITK_FUSE", "256")),
             # streamed convs: > 0 = 128-column tiles with the four waves side by side and this many K splits at most.  Measured
             # SLOWER (M = 128 convs 18.5 -> 20.4-23.6 us): off
-            "unet_conv_stream_w4": int(os.environ.get("MDX_UNET_CONV_STREAM_W4", "0"))}
+            "unet_conv_stream_w4": int(os.environ.get("MDX_UNET_CONV_STREAM_W4", "0")),
+            # 1 = a ResBlock's 1x1 skip_connection rides on its second 3x3 conv as extra K tiles (mdx_gemm_desc.skip_w)
+            "unet_skip_fuse": int(os.environ.get("MDX_UNET_SKIP_FUSE", "1"))}
 
 
 def set_option(name, value):
@@ -293,7 +295,7 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
                    residual=None, residual_ld=0, ksize=1, stride=1, upsample=0, epilogue=EPI_NONE,
                    out_mode=OUT_ROWMAJOR, splitk=0, workspace=None, out_bs=0, out2=None, out2_ld=0, n_split=0, asym_pad=0,
                    stats_out=None, ln_stats=None, ln_s=None, ln_eps=1e-5, tile_m=0, tile_n=0, colstats_out=None, stages=0,
-                   w_frag=0):
+                   w_frag=0, skip_a=None, skip_a2=None, skip_c1=0, skip_c2=0, skip_w=None):
     d = GemmDesc()
     d.a = a.data_ptr()
     d.a2 = 0 if a2 is None else a2.data_ptr()
@@ -321,6 +323,10 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
     d.ln_nt = 0 if ln_stats is None else (int(c1) + int(c2)) // 64
     d.ln_eps = float(ln_eps)
     d.tile_m, d.tile_n, d.stages, d.w_frag = int(tile_m), int(tile_n), int(stages), int(w_frag)
+    d.skip_a = 0 if skip_a is None else skip_a.data_ptr()
+    d.skip_a2 = 0 if skip_a2 is None else skip_a2.data_ptr()
+    d.skip_c1, d.skip_c2 = int(skip_c1), int(skip_c2)
+    d.skip_w = 0 if skip_w is None else skip_w.data_ptr()
     d.colstats_out = 0 if colstats_out is None else colstats_out.data_ptr()
     d.colstats_cap = 0 if colstats_out is None else int(colstats_out.shape[0])
     return d

@@ -956,3 +956,49 @@ def test_groupnorm_colstats_two_level_fold(ops, nrb, C, B):
     xt = torch.tensor(x).permute(0, 2, 1).reshape(B, C, HW, 1)
     ref = O.silu(O.group_norm(xt, torch.tensor(g), torch.tensor(b), 1e-5)).reshape(B, C, HW).permute(0, 2, 1)
     check(f"groupnorm_folded_colstats_nrb{nrb}_C{C}", out, ref, rel_l2=1e-3)
+
+
+@pytest.mark.parametrize("B,H,W,C,Cs1,Cs2,splitk", [
+    (2, 16, 16, 128, 64, 0, 1),        # single-source skip, one chunk pair
+    (2, 64, 64, 320, 320, 320, 1),     # the 64 x 64 up path: 640 -> 320 skip over the virtual concat, no split
+    (2, 32, 32, 640, 640, 320, 3),     # in-kernel split-K: every split takes its share of the skip tiles
+    (2, 16, 16, 1280, 1280, 1280, 5),  # slab split-K + reduce kernel
+    (2, 8, 8, 1280, 1280, 1280, 10),   # 8 x 8 two-sample tiles
+    (3, 8, 8, 128, 192, 64, 2),        # odd batch on the two-sample tiles
+])
+def test_conv3x3_with_fused_skip_connection(ops, B, H, W, C, Cs1, Cs2, splitk):
+    """mdx_gemm_desc.skip_w: out = conv3x3(h) + conv1x1(cat(x, x2)) + biases + time-embedding row in ONE launch (ResBlock
+    out_layers conv + skip_connection, openaimodel.py:174, 201-205) against the fp32 reference and against the two launches it
+    replaces (conv1x1 -> fp16 -> residual of the conv3x3: one more fp16 rounding, 1e-3)."""
+    rng = np.random.RandomState(B * H + C + Cs1 + Cs2)
+    hmap = h16(rng.standard_normal((B, C, H, W)))
+    x1 = h16(rng.standard_normal((B, Cs1, H, W)))
+    x2 = h16(rng.standard_normal((B, Cs2, H, W))) if Cs2 else None
+    w3 = h16(rng.standard_normal((C, C, 3, 3)) / math.sqrt(9 * C))
+    w1 = h16(rng.standard_normal((C, Cs1 + Cs2, 1, 1)) / math.sqrt(Cs1 + Cs2))
+    b3, b1 = rng.standard_normal(C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    xcat = np.concatenate([x1, x2], 1) if Cs2 else x1
+    ref = (O.conv2d(torch.tensor(hmap), torch.tensor(w3), torch.tensor(b3))
+           + O.conv2d(torch.tensor(xcat), torch.tensor(w1), torch.tensor(b1), padding=0))
+    hd, x1d = dev16(nhwc(hmap)), dev16(nhwc(x1))
+    x2d = dev16(nhwc(x2)) if Cs2 else None
+    w3p, w1p = pack_conv(w3), pack_conv(w1)
+    out = torch.empty((B, H * W, C), dtype=torch.float16, device=DEV)
+    d = ops.make_gemm_desc(hd, w3p, C, B, H, W, C, out, C, bias=dev32(b3 + b1), ksize=3, splitk=splitk,
+                           skip_a=x1d, skip_a2=x2d, skip_c1=Cs1, skip_c2=Cs2, skip_w=w1p)
+    ws = ops.new_gemm_workspace(max(ops.gemm_workspace_bytes(d), 1 << 20), DEV)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    assert ops.gemm_query(d)[3] == 1
+    ops.gemm_run(d)
+    torch.cuda.synchronize()
+    got = from_nhwc(out.float().cpu().numpy(), B, H, W)
+    check(f"conv3x3_fused_skip_B{B}_{H}x{W}_{C}_{Cs1}+{Cs2}_s{splitk}", got, ref, rel_l2=1e-3)
+    # the two launches it replaces
+    skip = ops.gemm(x1d, w1p, C, B, H, W, Cs1, a2=x2d, c2=Cs2, bias=dev32(b1))
+    two = ops.gemm(hd, w3p, C, B, H, W, C, bias=dev32(b3), ksize=3, residual=skip, residual_ld=C)
+    check(f"conv3x3_fused_skip_vs_two_launches_{H}x{W}_{C}", out.reshape(-1, C), two, rel_l2=1e-3)
+    # refused where the HALO kernel does not apply
+    from minddiffusion_amd._lib import MdxError
+    bad = ops.make_gemm_desc(hd, w3p, C, B, H, W, C, out, C, ksize=3, stride=2, skip_a=x1d, skip_c1=Cs1, skip_w=w1p)
+    with pytest.raises(MdxError):
+        ops.gemm_run(bad)
