@@ -165,6 +165,18 @@ typedef struct mdx_gemm_desc {
     int tile_m;           /* 0 = auto (tuned table, then the cost model); 64 | 128 forces the M tile.  For tools/tune_gemm.py,
                              which measures the (tile_m, splitk) candidates of every UNet shape on the device. */
     int tile_n;           /* 0 = auto; 64 | 128 forces the N tile (same purpose; GEGLU always uses 128) */
+    /* nn.GroupNorm(32) [+ SiLU] of the conv's INPUT applied inside the conv (openaimodel.py:136-138, 159-163: GroupNorm -> SiLU ->
+     * Conv2d): gn_colstats = the column partials the input's producer emitted (mdx_gemm_desc.colstats_out /
+     * mdx_st_tail_desc.colstats_out: [B * gn_nrb][Cin][2]), gn_gamma / gn_beta fp32 [Cin].  Every block folds its sample's
+     * partials into a per-channel {scale, shift} table and normalises the halo slices in LDS after they land; `a` is then the RAW
+     * tensor and no GroupNorm launch runs.  Single-source 3x3 stride-1 convs with Cin %% 64 == 0, Cin <= 640, images larger than
+     * 8 x 8, that resolve to the HALO kernel with 64-column tiles (mdx_gemm_query: out7[3] == 1, out7[1] == 64). */
+    const float* gn_colstats;
+    const float* gn_gamma;
+    const float* gn_beta;
+    int gn_nrb;
+    int gn_silu;
+    float gn_eps;
     /* ResBlock skip_connection fused into the block's second conv (openaimodel.py:174, 201-205): when skip_w is set,
      *   out = conv3x3(a) + conv1x1(cat(skip_a, skip_a2)) (+ bias + rowbias + residual ...),
      * the 1x1 conv over the block's RAW input riding on this launch as extra K tiles (one accumulator, one epilogue; `bias` must

@@ -34,6 +34,8 @@ class GemmDesc(ctypes.Structure):
         ("stats_out", c_void_p), ("ln_stats", c_void_p), ("ln_s", c_void_p), ("ln_nt", c_int), ("ln_eps", c_float),
         ("colstats_out", c_void_p), ("colstats_cap", c_int), ("defer_reduce", c_int),
         ("tile_m", c_int), ("tile_n", c_int),
+        ("gn_colstats", c_void_p), ("gn_gamma", c_void_p), ("gn_beta", c_void_p), ("gn_nrb", c_int), ("gn_silu", c_int),
+        ("gn_eps", c_float),
         ("skip_a", c_void_p), ("skip_a2", c_void_p), ("skip_c1", c_int), ("skip_c2", c_int), ("skip_w", c_void_p),
         ("w_frag", c_int), ("stages", c_int),
     ]

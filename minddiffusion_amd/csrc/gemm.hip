@@ -67,6 +67,12 @@ struct GemmParams {
     unsigned a_bytes, a2_bytes, w_bytes;
     int bk;
     unsigned long long* trace;   // diagnostics: per-block phase timestamps (mdx_probe_gemm_trace), else null
+    // GroupNorm (+ SiLU) of the conv's INPUT applied inside the conv (mdx_gemm_desc.gn_colstats)
+    const float* gn_cs;
+    const float* gn_gamma;
+    const float* gn_beta;
+    int gn_nrb, gn_silu;
+    float gn_eps;
     // ResBlock skip_connection fused into conv2 (mdx_gemm_desc.skip_w): extra 1x1 K tiles over the block's raw input
     const f16* skip_a;
     const f16* skip_a2;
@@ -1050,6 +1056,73 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
         }
     }
     if constexpr (!BDIR) {
+    // ---- GroupNorm(32) [+ SiLU] of the INPUT inside the conv (nn.GroupNorm -> SiLU -> Conv2d of a ResBlock, openaimodel.py:
+    // 136-138, 159-163): the producer of the input emitted per-row-block column partials (colstats); this block folds its
+    // sample's partials into a per-channel {scale, shift} table in LDS and normalises every halo slice IN PLACE after it has
+    // landed (each thread the 16-byte pieces its own DMAs brought, so no extra barrier): the normalised tensor is never
+    // written or read, and the GroupNorm launch disappears.  Zero padding stays zero (pieces outside the image are skipped).
+    float2* gn_tab = reinterpret_cast<float2*>(smem + 2 * HALO_BYTES + NSB * B_BYTES);     // [Cin] {a, shift}
+    if constexpr (PW == 16) {
+        if (p.gn_cs) {
+            float2* csum = reinterpret_cast<float2*>(smem);      // [Cin] channel {sum, sumsq}: the halo area is still unused
+            const int cpg = p.cin >> 5;
+            const float2* src = reinterpret_cast<const float2*>(p.gn_cs) + (size_t)pb * p.gn_nrb * p.cin;
+            for (int c = tid; c < p.cin; c += NW * 64) {
+                float su = 0.f, sq = 0.f;
+                int k = 0;
+                for (; k + 8 <= p.gn_nrb; k += 8) {
+                    float2 v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = src[(size_t)(k + e) * p.cin + c];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        su += v[e].x;
+                        sq += v[e].y;
+                    }
+                }
+                for (; k < p.gn_nrb; ++k) {
+                    const float2 v = src[(size_t)k * p.cin + c];
+                    su += v.x;
+                    sq += v.y;
+                }
+                csum[c] = make_float2(su, sq);
+            }
+            __syncthreads();
+            for (int c = tid; c < p.cin; c += NW * 64) {
+                const int g = c / cpg;
+                float su = 0.f, sq = 0.f;
+                for (int e = 0; e < cpg; ++e) {
+                    const float2 v = csum[g * cpg + e];
+                    su += v.x;
+                    sq += v.y;
+                }
+                const float inv = 1.0f / ((float)cpg * (float)(p.H * p.W));
+                const float mean = su * inv;
+                float var = sq * inv - mean * mean;
+                var = var < 0.f ? 0.f : var;
+                const float a = p.gn_gamma[c] * rsqrtf(var + p.gn_eps);
+                gn_tab[c] = make_float2(a, p.gn_beta[c] - mean * a);
+            }
+            __syncthreads();      // table complete; the halo area may be overwritten by the prologue DMAs
+        }
+    }
+    auto gn_transform = [&](int chunk, int hb) {      // normalise this thread's own pieces of halo buffer hb (chunk `chunk`)
+#pragma unroll
+        for (int q = 0; q < HJ; ++q) {
+            if (wave * HJ + q >= HINST || hal_off[q] == MDX_OOB) continue;
+            char* pc = smem + hb * HALO_BYTES + (wave * HJ + q) * 1024 + lane * 16;
+            const int ch0 = chunk * 64 + (int)((hal_off[q] >> 4) & 7u) * 8;       // logical chunk of this lane's piece
+            const f16x8 x = *reinterpret_cast<const f16x8*>(pc);
+            f16x8 y;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float2 t = gn_tab[ch0 + e];
+                const float v = (float)x[e] * t.x + t.y;
+                y[e] = (f16)(p.gn_silu ? silu_f(v) : v);
+            }
+            *reinterpret_cast<f16x8*>(pc) = y;
+        }
+    };
     // prologue: whole halo of the first chunk + the first NSB-1 weight tiles
 #pragma unroll
     for (int q = 0; q < HJ; ++q) dma_halo(q, c_begin, 0);
@@ -1069,6 +1142,12 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BJ) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (PW == 16) {
+                if (tap == 0 && p.gn_cs) {     // own slices have landed (they are older than the newest weight tile)
+                    gn_transform(c, hb);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... and are rewritten before anyone passes the barrier
+                }
+            }
             __builtin_amdgcn_s_barrier();
             if (t == 0) trace_mark(p, 2);
             if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
@@ -1481,6 +1560,19 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
         MDX_REQUIRE(p.out_mode == MDX_OUT_ROWMAJOR && p.epilogue == MDX_EPI_NONE && !p.n_split && !p.ln_stats && !p.stats_out &&
                         !p.out_bs && p.N % 8 == 0,
                     "mdx_gemm_f16: column statistics come from plain row-major launches only");
+    p.gn_cs = d->gn_colstats;
+    p.gn_gamma = d->gn_gamma;
+    p.gn_beta = d->gn_beta;
+    p.gn_nrb = d->gn_nrb;
+    p.gn_silu = d->gn_silu ? 1 : 0;
+    p.gn_eps = d->gn_eps;
+    if (p.gn_cs) {
+        MDX_REQUIRE(p.gn_gamma && p.gn_beta && p.gn_nrb > 0, "mdx_gemm_f16: gn_colstats needs gn_gamma, gn_beta and gn_nrb > 0");
+        MDX_REQUIRE(p.ksize == 3 && p.stride == 1 && !p.upsample && p.c2 == 0 && p.cin % 64 == 0 && p.cin % 32 == 0 &&
+                        p.cin <= 640 && !d->w_frag && !(d->H == 8 && d->W == 8),
+                    "mdx_gemm_f16: the fused input GroupNorm rides on a single-source 3x3 stride-1 conv with Cin %% 64 == 0, "
+                    "Cin <= 640, images larger than 8 x 8 and tile-major weights");
+    }
     p.skip_a = (const f16*)d->skip_a;
     p.skip_a2 = (const f16*)d->skip_a2;
     p.skip_w = (const f16*)d->skip_w;
@@ -1712,11 +1804,13 @@ void launch_halo(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t hinst = ((PW == 16 ? (BM / 16 + 2) * 18 : (BM / 64) * 100) + 7) / 8;
     constexpr size_t ring = 2 * hinst * 1024 + (BDIR ? 0 : (size_t)NSB * BN * 128);
     constexpr size_t epi = (size_t)BM * (BN + 8) * 2 + 4096;
-    constexpr size_t lds = ring > epi ? ring : epi;
+    constexpr size_t lds0 = ring > epi ? ring : epi;
+    constexpr size_t gn_tab_max = (BDIR || PW != 16) ? 0 : 640 * 8;      // {scale, shift} table of the fused input GroupNorm
+    const size_t lds = lds0 + (p.gn_cs ? (size_t)p.cin * 8 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW, BDIR, W4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds0 + gn_tab_max));
         attr_set = true;
     }
     hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW, BDIR, W4>), grid, dim3(BM * 2), lds, st, p);
@@ -1853,6 +1947,11 @@ static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
         }
     }
     r.halo = r.c.bm >= 128 && halo_eligible(p, r.c.bm);
+    if (p.gn_cs && !(r.halo && r.bn == 64 && !halo8_eligible(p))) {
+        mdx_set_error("mdx_gemm_f16: the fused input GroupNorm needs a launch that resolves to the HALO 3x3 kernel with 64-column "
+                      "tiles (ask mdx_gemm_query first)");
+        return MDX_E_INVALID;
+    }
     if (p.skip_w && !r.halo) {
         mdx_set_error("mdx_gemm_f16: the fused skip needs a launch that resolves to the HALO 3x3 kernel (ask mdx_gemm_query first)");
         return MDX_E_INVALID;

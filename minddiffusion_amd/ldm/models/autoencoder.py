@@ -34,6 +34,16 @@ class AutoencoderKL:
         if any(k.startswith(VAE_PREFIX) for k in sd):
             sd = {k[len(VAE_PREFIX):]: v for k, v in sd.items() if k.startswith(VAE_PREFIX)}
         sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
+        # Keys this model does not own (loss.*, discriminator.* of a training checkpoint ...) are reported, not fatal -- the
+        # reference's load_param_into_net ignores them and the CLI prints the list (autoencoder.py:44-54); MISSING keys of a
+        # checkpoint that carries an encoder still raise.
+        own = self.parameter_shapes()
+        self.unexpected_keys = sorted(k for k in sd if k not in own)
+        if self.unexpected_keys:
+            import warnings
+            warnings.warn(f"AutoencoderKL.init_from_ckpt: {len(self.unexpected_keys)} checkpoint keys are not parameters of this "
+                          f"model and were ignored: {self.unexpected_keys[:8]}{' ...' if len(self.unexpected_keys) > 8 else ''}")
+        sd = {k: v for k, v in sd.items() if k in own}
         self.load_state_dict(sd, strict="encoder.conv_in.weight" in sd)
         return self
 

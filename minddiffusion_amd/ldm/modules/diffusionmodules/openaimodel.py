@@ -500,7 +500,7 @@ class UNetModel:
         ctx_kv = {}
 
         def conv3(src, cin, cout, wt, bias, h, wd, stride=1, upsample=0, rowbias=None, residual=None, src2=None, c2=0,
-                  skip=None):
+                  skip=None, gn=None):
             """skip = (x, x2, c1, c2, packed 1x1 weights): the ResBlock's skip_connection rides on this launch as extra K
             tiles (mdx_gemm_desc.skip_w); `bias` then holds the sum of both convs' biases."""
             hs, ws_ = (2 * h, 2 * wd) if upsample else (h, wd)
@@ -509,6 +509,8 @@ class UNetModel:
             kw = {}
             if skip is not None:
                 kw = dict(skip_a=skip[0], skip_a2=skip[1], skip_c1=skip[2], skip_c2=skip[3], skip_w=skip[4])
+            if gn is not None:      # GroupNorm + SiLU of `src` inside the conv; the statistics pointer is wired after planning
+                kw.update(gn_gamma=gn[0], gn_beta=gn[1], gn_eps=gn[2], gn_silu=1)
             add_gemm(main, a=src, w=wt, N=cout, B=B, H=h, W=wd, c1=cin - c2, out=out, out_ld=cout, a2=src2, c2=c2,
                      bias=bias, rowbias=rowbias, rowbias_ld=self._emb_total if rowbias is not None else 0,
                      residual=residual, residual_ld=cout if residual is not None else 0, ksize=3, stride=stride,
@@ -516,6 +518,12 @@ class UNetModel:
             if skip is not None:
                 meta[-1]["flops"] += 2 * B * ho * wo * cout * (skip[2] + skip[3])
                 meta[-1]["info"] += f" +skip1x1 K={skip[2] + skip[3]}"
+            if gn is not None:
+                dd = descs[-1]
+                gn_convs.append(dd)
+                meta[-1]["info"] += " +groupnorm(in)"
+                gn_calls.append(dict(x1=src, x2=None, conv=dd, meta=len(meta) - 1, film=False,
+                                     prod=(producer.get(src.data_ptr()), None)))
             return out, ho, wo
 
         def dense(oplist, src, rows_b, tokens, cin, nout, wt, bias=None, residual=None, epilogue=ops.EPI_NONE,
@@ -588,6 +596,22 @@ class UNetModel:
                 ln_stats[(rows, width)] = torch.zeros((rows, width // 64, 2), dtype=f32, device=dev)
             return ln_stats[(rows, width)]
 
+        gn_convs = []
+
+        def gn_conv_ok(src, c_in, c_out, hh, ww, wt):
+            """Can GroupNorm + SiLU of `src` run inside the 3x3 conv that consumes it (mdx_gemm_desc.gn_colstats)?  At the levels
+            with at least `unet_gn_conv_fuse` output rows (below that the GroupNorm launch doubles as the split-K reduce of the
+            conv in front of it), for inputs some GEMM launch produced (its epilogue supplies the statistics), convs that
+            resolve to the HALO kernel with 64-column tiles."""
+            mrows = ops.get_option("unet_gn_conv_fuse")
+            if not _fuse_head or not mrows or B * hh * ww < mrows or c_in % 64 or c_in > 640 or (hh == 8 and ww == 8):
+                return False
+            if producer.get(src.data_ptr()) is None:
+                return False
+            probe = ops.make_gemm_desc(a=src, w=wt, N=c_out, B=B, H=hh, W=ww, c1=c_in, out=src, out_ld=c_out, ksize=3)
+            q = ops.gemm_query(probe)
+            return q[3] == 1 and q[1] == 64
+
         def skip_fusable(a2, c1, c2, cout, ho, wo, wt):
             """Can the ResBlock's 1x1 skip_connection ride on its second conv (mdx_gemm_desc.skip_w)?  Channel counts in whole
             64-channel K tiles, and the conv must resolve to the HALO 3x3 kernel."""
@@ -602,11 +626,14 @@ class UNetModel:
             (the nearest-2x of the branch is folded into conv1's gather)."""
             c2 = 0 if x2 is None else x2.shape[2]
             hw = h * wd
-            a = A.get((B, hw, cin))
-            add_gn(x, x2, w[pre + "in_layers_norm.g"], w[pre + "in_layers_norm.b"], 1e-5, True, a)
             eoff = self._emb_off[pre]
             film = self.use_scale_shift_norm
             rowbias = None if film else P.emb_all[:, eoff:eoff + cout]  # view: pointer = base + eoff, ld = emb_total
+            gn1 = x2 is None and mode is None and gn_conv_ok(x, cin, cout, h, wd, w[pre + "conv1.w"])
+            a = None
+            if not gn1:
+                a = A.get((B, hw, cin))
+                add_gn(x, x2, w[pre + "in_layers_norm.g"], w[pre + "in_layers_norm.b"], 1e-5, True, a)
             if mode == "up":
                 assert x2 is None and cin == cout
                 hbuf, ho, wo = conv3(a, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd, upsample=1, rowbias=rowbias)
@@ -620,10 +647,36 @@ class UNetModel:
                 A.release(ap)
                 xs = A.get((B, hw // 4, cin))
                 emit(lambda x=x, xs=xs: ops.avgpool2x2(x, B, h, wd, cin, out=xs), "small")
+            elif gn1:     # GroupNorm + SiLU of x inside conv1 (mdx_gemm_desc.gn_colstats): no GroupNorm launch, no normalised copy
+                hbuf, ho, wo = conv3(x, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd, rowbias=rowbias,
+                                     gn=(w[pre + "in_layers_norm.g"], w[pre + "in_layers_norm.b"], 1e-5))
+                xs = x
             else:
                 hbuf, ho, wo = conv3(a, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd, rowbias=rowbias)
                 xs = x
-            A.release(a)
+            if a is not None:
+                A.release(a)
+            gn2 = (not film and mode is None) and gn_conv_ok(hbuf, cout, cout, ho, wo, w[pre + "conv2.w"])
+            if gn2:
+                # out_layers: GroupNorm + SiLU of conv1's output inside conv2 (statistics from conv1's epilogue)
+                gnp = (w[pre + "out_layers_norm.g"], w[pre + "out_layers_norm.b"], 1e-5)
+                if cin != cout and skip_fusable(hbuf, cin - c2, c2, cout, ho, wo, w[pre + "conv2.w"]):
+                    if (pre + "conv2skip.b") not in w:
+                        w[pre + "conv2skip.b"] = (w[pre + "conv2.b"] + w[pre + "skip.b"]).contiguous()
+                    out, _, _ = conv3(hbuf, cout, cout, w[pre + "conv2.w"], w[pre + "conv2skip.b"], ho, wo, gn=gnp,
+                                      skip=(x, x2, cin - c2, c2, w[pre + "skip.w"]))
+                    A.release(hbuf)
+                    return out, ho, wo
+                if cin != cout:
+                    skip = dense(main, x, B, hw, cin, cout, w[pre + "skip.w"], bias=w[pre + "skip.b"], src2=x2, c2=c2)
+                else:
+                    assert x2 is None
+                    skip = xs
+                out, _, _ = conv3(hbuf, cout, cout, w[pre + "conv2.w"], w[pre + "conv2.b"], ho, wo, residual=skip, gn=gnp)
+                A.release(hbuf)
+                if skip is not x:
+                    A.release(skip)
+                return out, ho, wo
             a2 = A.get((B, ho * wo, cout))
             if film:
                 add_gn(hbuf, None, w[pre + "out_layers_norm.g"], w[pre + "out_layers_norm.b"], 1e-5, True, a2,
@@ -844,7 +897,8 @@ class UNetModel:
             for d in descs:
                 M = d.B * d.H * d.W      # (stride 1: output rows)
                 if not (d.ksize == 3 and d.stride == 1 and not d.upsample and d.c2 == 0 and d.c1 % 64 == 0 and d.N % 64 == 0
-                        and M <= ops.get_option("unet_conv_stream") and d.out_mode == ops.OUT_ROWMAJOR and not d.skip_w):
+                        and M <= ops.get_option("unet_conv_stream") and d.out_mode == ops.OUT_ROWMAJOR and not d.skip_w
+                        and not d.gn_gamma):
                     continue
                 q = ops.gemm_query(d)
                 w4 = ops.get_option("unet_conv_stream_w4")
@@ -875,7 +929,7 @@ class UNetModel:
         fuse_hw = ops.get_option("unet_gn_splitk_fuse")     # fuse for tensors of at most this many pixels per sample (0 = never)
         if fuse_hw:
             for c in gn_calls:
-                if c.get("head") is not None:
+                if c.get("head") is not None or c.get("conv") is not None:
                     continue
                 _, HW, C1 = c["x1"].shape
                 if HW > fuse_hw:
@@ -900,10 +954,18 @@ class UNetModel:
                 L = cpg // math.gcd(cpg, 8)
                 if L <= 64 and HW * L * 16 <= (64 << 10):
                     meta[c["meta"]]["launches"] = 1
-        if any(not hd.colstats for hd in heads_fused):
+        if any(not hd.colstats for hd in heads_fused) or any(not dd.gn_colstats for dd in gn_convs):
             # a fused head whose input tensor's producer cannot emit column statistics in its final launch form: plan again
             # with the unfused GroupNorm / proj_in / qkv launches (plans are built once per shape)
             return self._plan(B, H, W, _fuse_head=False)
+        # the statistics epilogue is part of the tile table's launch-variant key: a wired producer may resolve to another row
+        # (another split) than the one the shared workspace was sized for -- size it again and grow it if needed
+        need2 = max([ops.gemm_workspace_bytes(d) for d in descs] + [0])
+        if need2 > P.gemm_ws.numel() * 4:
+            P.gemm_ws = ops.new_gemm_workspace(need2, dev)
+            for d in descs:
+                d.workspace = P.gemm_ws.data_ptr()
+                d.workspace_bytes = P.gemm_ws.numel() * 4
         ops.account_gemm_launches(meta)     # last: the column-statistics wiring above can change a launch's table row
         P.main, P.ctxops, P.descs, P.meta = main, ctxops, descs, meta
         assert len(main) == len(meta)

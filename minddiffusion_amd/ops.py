@@ -30,7 +30,11 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
             # SLOWER (M = 128 convs 18.5 -> 20.4-23.6 us): off
             "unet_conv_stream_w4": int(os.environ.get("MDX_UNET_CONV_STREAM_W4", "0")),
             # 1 = a ResBlock's 1x1 skip_connection rides on its second 3x3 conv as extra K tiles (mdx_gemm_desc.skip_w)
-            "unet_skip_fuse": int(os.environ.get("MDX_UNET_SKIP_FUSE", "1"))}
+            "unet_skip_fuse": int(os.environ.get("MDX_UNET_SKIP_FUSE", "1")),
+            # GroupNorm + SiLU inside the consuming 3x3 conv at levels with at least this many output rows (0 = never)
+            # (mdx_gemm_desc.gn_colstats).  Measured round 3 at UNet batch 2: 7 GroupNorm launches fewer (-0.10 ms) but the convs'
+            # in-LDS normalisation pass costs as much (+0.10 ms): 4.603 -> 4.641 ms per step.  Off.
+            "unet_gn_conv_fuse": int(os.environ.get("MDX_UNET_GN_CONV_FUSE", "0"))}
 
 
 def set_option(name, value):
@@ -295,7 +299,8 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
                    residual=None, residual_ld=0, ksize=1, stride=1, upsample=0, epilogue=EPI_NONE,
                    out_mode=OUT_ROWMAJOR, splitk=0, workspace=None, out_bs=0, out2=None, out2_ld=0, n_split=0, asym_pad=0,
                    stats_out=None, ln_stats=None, ln_s=None, ln_eps=1e-5, tile_m=0, tile_n=0, colstats_out=None, stages=0,
-                   w_frag=0, skip_a=None, skip_a2=None, skip_c1=0, skip_c2=0, skip_w=None):
+                   w_frag=0, skip_a=None, skip_a2=None, skip_c1=0, skip_c2=0, skip_w=None, gn_colstats=None, gn_nrb=0,
+                   gn_gamma=None, gn_beta=None, gn_eps=1e-5, gn_silu=1):
     d = GemmDesc()
     d.a = a.data_ptr()
     d.a2 = 0 if a2 is None else a2.data_ptr()
@@ -323,6 +328,10 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
     d.ln_nt = 0 if ln_stats is None else (int(c1) + int(c2)) // 64
     d.ln_eps = float(ln_eps)
     d.tile_m, d.tile_n, d.stages, d.w_frag = int(tile_m), int(tile_n), int(stages), int(w_frag)
+    d.gn_colstats = 0 if gn_colstats is None else gn_colstats.data_ptr()
+    d.gn_gamma = 0 if gn_gamma is None else gn_gamma.data_ptr()
+    d.gn_beta = 0 if gn_beta is None else gn_beta.data_ptr()
+    d.gn_nrb, d.gn_silu, d.gn_eps = int(gn_nrb), int(gn_silu), float(gn_eps)
     d.skip_a = 0 if skip_a is None else skip_a.data_ptr()
     d.skip_a2 = 0 if skip_a2 is None else skip_a2.data_ptr()
     d.skip_c1, d.skip_c2 = int(skip_c1), int(skip_c2)
@@ -502,7 +511,8 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
     fold_many = get_option("gn_colstats_fold") != 0
     for c in gn_calls:
         _, HW, C1 = c["x1"].shape
-        is_head = c.get("head") is not None     # fused SpatialTransformer head: the statistics feed that launch
+        # fused SpatialTransformer head / GroupNorm inside the consuming conv: the statistics feed that launch (any block count)
+        is_head = c.get("head") is not None or c.get("conv") is not None
         C2 = 0 if c["x2"] is None else c["x2"].shape[2]
         cpg = (C1 + C2) // 32
         L = cpg // math.gcd(cpg, 8)           # chunk columns of the minimal whole-group column block
@@ -549,8 +559,10 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
             return table[key]
         s1 = stats_of(c["prod"][0], C1)
         if is_head:
-            if s1 is not None:
+            if s1 is not None and c.get("head") is not None:
                 c["head"].colstats, c["head"].nrb = s1[0].data_ptr(), int(s1[1])
+            elif s1 is not None:
+                c["conv"].gn_colstats, c["conv"].gn_nrb = s1[0].data_ptr(), int(s1[1])
             continue
         s2 = stats_of(c["prod"][1], C2) if C2 else (None, 0)
         if s1 is None or s2 is None:

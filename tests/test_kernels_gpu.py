@@ -911,7 +911,8 @@ def test_conv3x3_weight_streaming_form_is_bit_identical(ops, B, H, W, Cin, Cout,
     for frag in (0, 1):
         wd = ops.pack_conv_weight_frag(torch.tensor(wt).to(DEV)) if frag else pack_conv(wt)
         out = torch.empty((B, H * W, Cout), dtype=torch.float16, device=DEV)
-        d = ops.make_gemm_desc(xd, wd, Cout, B, H, W, Cin, out, Cout, bias=dev32(bv), rowbias=dev32(rb), rowbias_ld=Cout,
+        bd, rbd = dev32(bv), dev32(rb)      # (a descriptor holds raw pointers only)
+        d = ops.make_gemm_desc(xd, wd, Cout, B, H, W, Cin, out, Cout, bias=bd, rowbias=rbd, rowbias_ld=Cout,
                                residual=resd, residual_ld=Cout, ksize=3, splitk=splitk, tile_m=128, tile_n=tile_n, w_frag=frag)
         need = ops.gemm_workspace_bytes(d)
         ws = ops.new_gemm_workspace(max(need, 1 << 20), DEV)
@@ -984,7 +985,8 @@ def test_conv3x3_with_fused_skip_connection(ops, B, H, W, C, Cs1, Cs2, splitk):
     x2d = dev16(nhwc(x2)) if Cs2 else None
     w3p, w1p = pack_conv(w3), pack_conv(w1)
     out = torch.empty((B, H * W, C), dtype=torch.float16, device=DEV)
-    d = ops.make_gemm_desc(hd, w3p, C, B, H, W, C, out, C, bias=dev32(b3 + b1), ksize=3, splitk=splitk,
+    bsum = dev32(b3 + b1)           # (a descriptor holds raw pointers only: keep every tensor it points at alive)
+    d = ops.make_gemm_desc(hd, w3p, C, B, H, W, C, out, C, bias=bsum, ksize=3, splitk=splitk,
                            skip_a=x1d, skip_a2=x2d, skip_c1=Cs1, skip_c2=Cs2, skip_w=w1p)
     ws = ops.new_gemm_workspace(max(ops.gemm_workspace_bytes(d), 1 << 20), DEV)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -1002,3 +1004,55 @@ def test_conv3x3_with_fused_skip_connection(ops, B, H, W, C, Cs1, Cs2, splitk):
     bad = ops.make_gemm_desc(hd, w3p, C, B, H, W, C, out, C, ksize=3, stride=2, skip_a=x1d, skip_c1=Cs1, skip_w=w1p)
     with pytest.raises(MdxError):
         ops.gemm_run(bad)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,splitk,rows,skip", [
+    (2, 16, 16, 128, 128, 1, 64, False),
+    (2, 64, 64, 320, 320, 1, 128, False),     # the 64 x 64 level (in_layers / out_layers convs)
+    (2, 64, 64, 320, 320, 1, 32, False),      # statistics in 32-row blocks, as a fused SpatialTransformer tail emits them
+    (2, 32, 32, 320, 320, 5, 128, False),     # slab split-K with single-chunk splits
+    (2, 32, 32, 320, 640, 3, 128, False),
+    (2, 32, 32, 640, 640, 3, 128, False),     # 32 x 32 level, in-kernel split-K
+    (2, 32, 32, 640, 640, 3, 128, True),      # ... with the skip_connection riding on the same launch
+    (3, 16, 32, 192, 64, 2, 128, False),      # 6 channels per group, odd batch
+])
+def test_conv3x3_with_fused_input_groupnorm(ops, B, H, W, Cin, Cout, splitk, rows, skip):
+    """mdx_gemm_desc.gn_colstats: GroupNorm(32) -> SiLU -> Conv2d 3x3 (openaimodel.py:136-138, 159-163) in ONE launch on the RAW
+    input, statistics folded from the producer's per-row-block column partials -- against the fp32 reference and against the
+    GroupNorm launch + conv launch it replaces (same formulas, another summation order of the statistics: 1e-3)."""
+    rng = np.random.RandomState(B * H + Cin + Cout + rows)
+    x = h16(rng.standard_normal((B, Cin, H, W)) * (0.5 + rng.rand(Cin))[None, :, None, None] + rng.standard_normal(Cin)[None, :, None, None])
+    g, bt = (1.0 + 0.2 * rng.standard_normal(Cin)).astype(np.float32), (0.1 * rng.standard_normal(Cin)).astype(np.float32)
+    wt = h16(rng.standard_normal((Cout, Cin, 3, 3)) / math.sqrt(9 * Cin))
+    bv = rng.standard_normal(Cout).astype(np.float32)
+    rb = rng.standard_normal((B, Cout)).astype(np.float32)
+    a = O.silu(O.group_norm(torch.tensor(x), torch.tensor(g), torch.tensor(bt), 1e-5))
+    ref = O.conv2d(a, torch.tensor(wt), torch.tensor(bv)) + torch.tensor(rb)[:, :, None, None]
+    kw = {}
+    if skip:
+        xs = h16(rng.standard_normal((B, 2 * Cout, H, W)))
+        ws = h16(rng.standard_normal((Cout, 2 * Cout, 1, 1)) / math.sqrt(2 * Cout))
+        ref = ref + O.conv2d(torch.tensor(xs), torch.tensor(ws), None, padding=0)
+        xsd, wsd = dev16(nhwc(xs)), pack_conv(ws)
+        kw = dict(skip_a=xsd, skip_c1=2 * Cout, skip_w=wsd)
+    xd = dev16(nhwc(x))
+    nrb = H * W // rows
+    blk = xd.float().reshape(B * nrb, rows, Cin)
+    cs = torch.stack([blk.sum(1), (blk * blk).sum(1)], 2).contiguous()
+    out = torch.empty((B, H * W, Cout), dtype=torch.float16, device=DEV)
+    wd, bd, rbd, gd, btd = pack_conv(wt), dev32(bv), dev32(rb), dev32(g), dev32(bt)     # (a descriptor holds raw pointers only)
+    d = ops.make_gemm_desc(xd, wd, Cout, B, H, W, Cin, out, Cout, bias=bd, rowbias=rbd, rowbias_ld=Cout,
+                           ksize=3, splitk=splitk, tile_n=64, gn_colstats=cs, gn_nrb=nrb, gn_gamma=gd, gn_beta=btd,
+                           gn_eps=1e-5, gn_silu=1, **kw)
+    ws_ = ops.new_gemm_workspace(max(ops.gemm_workspace_bytes(d), 1 << 20), DEV)
+    d.workspace, d.workspace_bytes = ws_.data_ptr(), ws_.numel() * 4
+    q = ops.gemm_query(d)
+    assert q[3] == 1 and q[1] == 64, q
+    ops.gemm_run(d)
+    torch.cuda.synchronize()
+    got = from_nhwc(out.float().cpu().numpy(), B, H, W)
+    check(f"conv3x3_fused_gn_B{B}_{H}x{W}_{Cin}_{Cout}_s{splitk}_r{rows}_skip{int(skip)}", got, ref, rel_l2=1.5e-3)
+    if not skip:
+        an = ops.groupnorm(xd, None, gd, btd, 1e-5, True)
+        two = ops.gemm(an, wd, Cout, B, H, W, Cin, bias=bd, rowbias=rbd, rowbias_ld=Cout, ksize=3)
+        check(f"conv3x3_fused_gn_vs_two_launches_{H}x{W}_{Cin}_r{rows}", out.reshape(-1, Cout), two, rel_l2=1e-3)
