@@ -71,6 +71,9 @@ __device__ __forceinline__ void unit(f32x16 (&acc)[T][TM], const char* abuf_lane
     // at the L2 / HBM round-trip time per k-step (measured: 93 -> us per block).  A fragments are read AD steps ahead by hand.
     constexpr int AD = 2;
     f16x8 af[AD + 1][TM];
+    f32x16 odd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) odd[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < AD; ++s)
 #pragma unroll
@@ -89,10 +92,24 @@ __device__ __forceinline__ void unit(f32x16 (&acc)[T][TM], const char* abuf_lane
             const f16x8 b = __builtin_bit_cast(f16x8, ring[j % PF]);
             ring[j % PF] = wload(rs, voff, piece + j + PF);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, af[s % (AD + 1)][i], acc[t][i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (T * TM == 1) {
+                    // a lone accumulator makes every MFMA wait for the one before it (SQ_WAIT_INST_ANY 33 % of the wave cycles
+                    // in the 32-row kernel): odd k-steps go to a second accumulator, summed at the end
+                    if (s & 1)
+                        odd = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, af[s % (AD + 1)][i], odd, 0, 0, 0);
+                    else
+                        acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, af[s % (AD + 1)][i], acc[t][i], 0, 0, 0);
+                } else {
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, af[s % (AD + 1)][i], acc[t][i], 0, 0, 0);
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (T * TM == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += odd[r];
     }
     piece += KS * T;
 }

@@ -514,6 +514,13 @@ class Text2ImUNet:
         import os
         ops.wire_groupnorm_colstats(gn_calls if os.environ.get("MDX_UNET_GN_COLSTATS", "1") != "0" else [], meta, B, dev,
                                     P.colstats)
+        # a wired producer may resolve to another tile-table row than the one the workspace was sized for: size it again
+        need2 = max([ops.gemm_workspace_bytes(d) for d in descs] + [16])
+        if need2 > P.gemm_ws.numel() * 4:
+            P.gemm_ws = ops.new_gemm_workspace(need2, dev)
+            for d in descs:
+                d.workspace = P.gemm_ws.data_ptr()
+                d.workspace_bytes = P.gemm_ws.numel() * 4
         ops.account_gemm_launches(meta)
         P.main, P.meta, P.descs, P.arena = main, meta, descs, A
         P.keep = (t_emb, cat_in, emb, xf_out)

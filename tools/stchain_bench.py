@@ -41,6 +41,14 @@ def timed_graph(build):
     """build() enqueues one pass over all weight sets; returns us per set (graph replay, min of 5)."""
     build()
     torch.cuda.synchronize()
+    if os.environ.get("NOGRAPH"):       # eager launches (rocprofv3 --pmc cannot follow graph replays)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(REPS):
+            build()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (NCOPY * REPS)
     gr = torch.cuda.CUDAGraph()
     with torch.cuda.graph(gr):
         for _ in range(REPS):
