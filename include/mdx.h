@@ -10,8 +10,11 @@
  * Conventions
  *  - All pointers are DEVICE pointers (HBM) unless noted; the caller owns every buffer
  *    including workspaces; the library never allocates device memory and never
- *    synchronises.  All work is enqueued on the caller's stream (hipStream_t passed as
- *    void*), so calls are capturable into a hipGraph.
+ *    synchronises -- with ONE exception: the arrival counters of the in-kernel split-K reduce
+ *    (16 KiB per distinct workspace address, carved from 1 MiB chunks that are zeroed when they
+ *    are allocated; see mdx_gemm_desc.workspace and mdx_gemm_release_counters).  All work is
+ *    enqueued on the caller's stream (hipStream_t passed as void*), so calls are capturable
+ *    into a hipGraph.
  *  - Activations are NHWC ("token-major") fp16: [B][H*W][C]; the reference's NCHW fp32
  *    tensors exist only at the apply_model boundary (mdx_nchw_to_nhwc_f16 /
  *    mdx_nhwc_to_nchw_f32).
@@ -123,11 +126,13 @@ typedef struct mdx_gemm_desc {
     void* workspace;      /* split-K workspace, 16-byte aligned (may be NULL when splitk <= 1).  Row-major launches reduce IN the
                              kernel: every (tile, split) block parks its fp32 partial in the workspace and takes a ticket on
                              the tile's arrival counter; the block that completes a tile sums the partials in split order and
-                             runs the epilogue (no reduce launch).  The counters are the first MDX_GEMM_WS_HEAD bytes of the
-                             workspace.  The library zeroes them itself (hipMemsetAsync on the caller's stream) the first time it
-                             sees a workspace ADDRESS, and every launch leaves them zero again; nothing else may write them.  A
-                             caller that frees a workspace and reuses the address for another one must zero the head itself.  A
-                             workspace may be shared by launches on ONE stream only (two streams would race on the counters).  Transposed-output split launches use [split][M][N] slabs + a reduce
+                             runs the epilogue (no reduce launch).  The counters are LIBRARY-owned, one set per (device,
+                             workspace address), always zero between launches: the workspace needs no initialisation (rounds 2
+                             and 3 kept them in the first MDX_GEMM_WS_HEAD bytes of the workspace, which made "zeroed by the
+                             caller" -- later "zeroed on first sight of an address" -- part of the contract; both broke on
+                             buffers an allocator hands out twice).  The first MDX_GEMM_WS_HEAD bytes stay reserved.  Launches
+                             that can run concurrently (two streams) need distinct workspaces, as their partials always did.
+                             Transposed-output split launches use [split][M][N] slabs + a reduce
                              launch as before (no counters). */
     size_t workspace_bytes;
     long out_bs;          /* row-major only: element stride between samples (0 = dense); lets a projection write
@@ -198,7 +203,7 @@ typedef struct mdx_gemm_desc {
                              waves per block (generic kernel, tile_m = 128 only) */
 } mdx_gemm_desc;
 
-#define MDX_GEMM_WS_HEAD 16384 /* bytes of arrival counters at the head of mdx_gemm_desc.workspace (zero on first use) */
+#define MDX_GEMM_WS_HEAD 16384 /* reserved bytes at the head of mdx_gemm_desc.workspace (the arrival counters' former home; their size) */
 #define MDX_EPI_NONE 0
 #define MDX_EPI_GEGLU 1 /* out[m][j] = a * gelu_tanh(g); packed so that each 128-wide N tile = 64 'a' | 64 'gate' cols
                            (attention.py:41-51) */
@@ -208,6 +213,8 @@ typedef struct mdx_gemm_desc {
 #define MDX_OUT_TRANSPOSED 1 /* out[(b * N + n) * out_ld + tok]: V^T for mdx_attention_f16 */
 
 int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s);
+/* Frees the library-owned split-K arrival counters (nothing may be in flight); later launches allocate them again. */
+int mdx_gemm_release_counters(void);
 /* Bytes of split-K workspace mdx_gemm_f16 wants for this problem under its auto heuristic (0 if none). */
 size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d);
 /* Host-only validation of a descriptor (no launch): MDX_OK or MDX_E_INVALID with mdx_last_error() set. */
@@ -218,6 +225,16 @@ int mdx_gemm_check(const mdx_gemm_desc* d);
  * statistics), 1 if a split launch reduces in the kernel (no reduce launch follows)}.  The parity tests assert with it that
  * the table rows are hit at the benchmarked shapes. */
 int mdx_gemm_query(const mdx_gemm_desc* d, int* out7);
+/* First-use tuner for shapes the measured tile table does not list (no reference counterpart; the reference's graph compiler
+ * picks its kernels).  Times every distinct launch form the library has for this descriptor (tile_m x tile_n x split-K) on
+ * stream `s` -- median of `reps` (1 .. 31, 0 = 5) launches each, after a hipMemsetAsync of `flush` (may be NULL; >= 512 MiB
+ * evicts L2 and the Infinity Cache, i.e. weights arrive cold as they do inside a UNet evaluation) -- and returns the fastest in
+ * best4 = {tile_m, tile_n, splitk, stages} for the descriptor's override fields; all zero = keep the library's choice (it won, or
+ * lost by < 2 %).  us2 (may be NULL) = {library's choice, best} in microseconds.  The CALLER keeps the answer (ops.tune_cache);
+ * the library stores nothing.  This is the one entry that SYNCHRONISES (event waits on `s`): not capturable; every trial
+ * overwrites d->out.  Descriptors with colstats_out, defer_reduce or w_frag are refused (their consumer / weight packing is
+ * tied to the launch form). */
+int mdx_gemm_tune(const mdx_gemm_desc* d, mdx_stream_t s, void* flush, size_t flush_bytes, int reps, int* best4, float* us2);
 
 /* GroupNorm fused with the split-K reduce of its producer (the small tensors of the deep UNet levels, where one block
  * normalises a whole (sample, column block) and the conv in front of it is always split): `prod` is the descriptor of a conv /

@@ -88,6 +88,9 @@ SIGNATURES = {
     "mdx_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "mdx_gemm_f16": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
     "mdx_gemm_workspace_bytes": (c_size_t, [ctypes.POINTER(GemmDesc)]),
+    "mdx_gemm_release_counters": (c_int, []),
+    "mdx_gemm_tune": (c_int, [ctypes.POINTER(GemmDesc), c_void_p, c_void_p, c_size_t, c_int, ctypes.POINTER(c_int),
+                              ctypes.POINTER(ctypes.c_float)]),
     "mdx_gemm_check": (c_int, [ctypes.POINTER(GemmDesc)]),
     "mdx_gemm_query": (c_int, [ctypes.POINTER(GemmDesc), ctypes.POINTER(c_int)]),
     "mdx_attention_f16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,

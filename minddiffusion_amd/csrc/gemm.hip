@@ -27,8 +27,10 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <map>
 #include <mutex>
-#include <unordered_set>
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -42,7 +44,7 @@ struct GemmParams {
     f16* out;
     f16* out2;       // transposed destination of the columns n >= n_split (0 = none): q|k row-major + V^T in ONE launch
     float* ws;
-    unsigned* tickets;       // in-kernel split-K reduce: one arrival counter per output tile (head of the workspace), else null
+    unsigned* tickets;       // in-kernel split-K reduce: one arrival counter per output tile (library-owned, ticket_slot()), else null
     int c1, c2, cin;
     int rowbias_ld, residual_ld, out_ld, out2_ld, n_split;
     // LayerNorm folded into the GEMMs around it (mdx.h): the PRODUCER of the token stream writes per-row {sum, sumsq}
@@ -193,7 +195,7 @@ __device__ __forceinline__ void gemm_bias_prefetch(const GemmParams& p, const in
 // (buffer_store ... sc1), every wave drains its stores (s_waitcnt vmcnt(0)), block barrier, ONE lane takes the ticket with a
 // relaxed agent-scope atomic; the last arriver reads the partials with agent-scope (sc1) loads, which cannot hit a stale
 // line of its CU's L1 or its XCD's L2.  No placement assumption: a tile's splits may run on any CUs of any XCDs.
-// The counter is reset by the last arriver, so the ticket area only has to be zero before the FIRST launch on a workspace.
+// The counter is reset by the last arriver, so a tile's counter is zero whenever no launch is in flight on its workspace.
 constexpr int MDX_TICKET_SLOTS = MDX_GEMM_WS_HEAD / 4;      // tiles per launch that can take tickets
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -227,7 +229,7 @@ __device__ __forceinline__ bool splitk_last_block_reduce(const GemmParams& p, f3
     int* flag = reinterpret_cast<int*>(smem);
     if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(p.tickets + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old >= (unsigned)p.nsplit) __builtin_trap();     // the caller did not zero the head of the workspace (mdx.h)
+        if (old >= (unsigned)p.nsplit) __builtin_trap();     // counters corrupted (two streams sharing one workspace, mdx.h)
         *flag = old == (unsigned)p.nsplit - 1u;
     }
     __syncthreads();
@@ -1919,6 +1921,82 @@ struct Resolved {
     bool fixup;      // split-K reduced by the last block of each tile (no reduce launch)
 };
 
+// Arrival counters of the in-kernel split-K reduce.  They used to sit in the first MDX_GEMM_WS_HEAD bytes of the caller's
+// workspace, which made "hand the workspace over zeroed" part of the contract: a fresh hipMalloc'd buffer trapped, and zeroing on
+// the first sight of an ADDRESS broke as soon as an allocator handed the same address out twice (round 3: the stress test after
+// another test's workspace).  Now the library owns them: MDX_TICKET_SLOTS counters per (device, workspace address), carved from
+// 1 MiB chunks that are zeroed once when they are allocated -- the ONE exception to "the library never allocates device memory"
+// (include/mdx.h).  Every launch leaves its counters zero, so a slot is valid for whatever buffer an address names later; launches
+// that may run concurrently have distinct workspaces (their partials) and therefore distinct counters.  The chunk is allocated with
+// the thread's stream-capture mode relaxed and zeroed on a private stream, so a first use inside a capture works too.
+struct TicketPools {
+    std::mutex mu;
+    std::map<std::pair<int, const void*>, unsigned*> slot;
+    struct Dev { char* next = nullptr; int left = 0; hipStream_t zero_stream = nullptr; };
+    std::map<int, Dev> dev;
+    std::vector<std::pair<int, void*>> chunks;
+};
+static TicketPools g_tickets;
+constexpr int TICKET_CHUNK_SLOTS = 64;
+
+static int ticket_slot(const void* ws, unsigned** out) {
+    int dv = 0;
+    hipError_t e = hipGetDevice(&dv);
+    if (e != hipSuccess) {
+        mdx_set_error("mdx_gemm_f16: hipGetDevice failed: %s", hipGetErrorString(e));
+        return MDX_E_HIP;
+    }
+    std::lock_guard<std::mutex> lk(g_tickets.mu);
+    const auto key = std::make_pair(dv, ws);
+    const auto it = g_tickets.slot.find(key);
+    if (it != g_tickets.slot.end()) {
+        *out = it->second;
+        return MDX_OK;
+    }
+    TicketPools::Dev& d = g_tickets.dev[dv];
+    if (d.left == 0) {
+        const size_t bytes = (size_t)TICKET_CHUNK_SLOTS * MDX_GEMM_WS_HEAD;
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        void* mem = nullptr;
+        e = hipMalloc(&mem, bytes);
+        if (e == hipSuccess && !d.zero_stream) e = hipStreamCreateWithFlags(&d.zero_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemsetAsync(mem, 0, bytes, d.zero_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d.zero_stream);
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (e != hipSuccess) {
+            if (mem) (void)hipFree(mem);
+            mdx_set_error("mdx_gemm_f16: allocating the split-K arrival counters failed: %s", hipGetErrorString(e));
+            return MDX_E_HIP;
+        }
+        g_tickets.chunks.emplace_back(dv, mem);
+        d.next = static_cast<char*>(mem);
+        d.left = TICKET_CHUNK_SLOTS;
+    }
+    unsigned* s = reinterpret_cast<unsigned*>(d.next);
+    d.next += MDX_GEMM_WS_HEAD;
+    d.left -= 1;
+    g_tickets.slot.emplace(key, s);
+    *out = s;
+    return MDX_OK;
+}
+
+// Frees the arrival counters (nothing may be in flight).  Later launches allocate again.
+extern "C" int mdx_gemm_release_counters(void) {
+    std::lock_guard<std::mutex> lk(g_tickets.mu);
+    int dv = 0;
+    (void)hipGetDevice(&dv);
+    for (auto& c : g_tickets.chunks) {
+        (void)hipSetDevice(c.first);
+        (void)hipFree(c.second);
+    }
+    (void)hipSetDevice(dv);
+    g_tickets.chunks.clear();
+    g_tickets.slot.clear();
+    g_tickets.dev.clear();
+    return MDX_OK;
+}
+
 static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
     r.c = pick_cfg(p);
     const int bn = r.bn = r.c.bn;
@@ -2054,25 +2132,8 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     MDX_REQUIRE(!d->defer_reduce || ns > 1, "mdx_gemm_f16: defer_reduce set but the launch does not split K");
     MDX_REQUIRE(!rs.fixup || ((uintptr_t)p.ws % 16 == 0), "mdx_gemm_f16: workspace must be 16-byte aligned");
     if (rs.fixup) {
-        // The tiles' arrival counters live in the first MDX_GEMM_WS_HEAD bytes of the caller's workspace and must start at
-        // zero.  The first time the library sees a workspace address it zeroes them itself, on the caller's stream, ahead of
-        // the launch (a caller handing over a fresh hipMalloc'd buffer used to get a device trap).  Every launch leaves them
-        // zero again; a caller that frees a workspace and later reuses the ADDRESS for a new one must zero the head itself
-        // (include/mdx.h).
-        static std::mutex mu;
-        static std::unordered_set<const void*> seen;
-        bool first;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            first = seen.insert(d->workspace).second;
-        }
-        if (first) {
-            const hipError_t e = hipMemsetAsync(d->workspace, 0, MDX_GEMM_WS_HEAD, st);
-            if (e != hipSuccess) {
-                mdx_set_error("mdx_gemm_f16: zeroing the workspace head failed: %s", hipGetErrorString(e));
-                return MDX_E_HIP;
-            }
-        }
+        const int trc = ticket_slot(d->workspace, &p.tickets);
+        if (trc != MDX_OK) return trc;
     }
     p.tiles_m = (p.M + c.bm - 1) / c.bm;
     p.tiles_n = (p.N + bn - 1) / bn;
@@ -2143,5 +2204,97 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
         MDX_LAUNCH_CHECK("mdx_gemm_f16(splitk reduce)");
     }
+    return MDX_OK;
+}
+
+// First-use tuner (include/mdx.h).  The tile table (gemm_tuned.inc) covers the shapes of the benchmarked configurations; any
+// other resolution / batch resolves through the cost model, which is 10-20 % off on some shapes.  This entry measures the
+// launch forms the library has for ONE descriptor on the caller's stream -- tile_m x tile_n x split-K, every distinct form
+// mdx_gemm_query resolves them to -- and returns the fastest as values for the descriptor's tile_m / tile_n / splitk / stages
+// override fields (all zero = the library's own choice was the fastest, or within 2 % of it).  The caller keeps the answer (the
+// cache is on the caller's side: minddiffusion_amd/ops.py tune_cache); the library keeps nothing.  It is the one entry that
+// SYNCHRONISES (event waits on `s`) and so cannot be captured; the descriptor's output buffer is overwritten by every trial.
+extern "C" int mdx_gemm_tune(const mdx_gemm_desc* d, mdx_stream_t s, void* flush, size_t flush_bytes, int reps, int* best4,
+                             float* us2) {
+    MDX_REQUIRE(d != nullptr && best4 != nullptr, "mdx_gemm_tune: null argument");
+    MDX_REQUIRE(!d->defer_reduce && !d->colstats_out && !d->w_frag,
+                "mdx_gemm_tune: descriptors whose consumer depends on the launch form (colstats_out, defer_reduce) or whose weights "
+                "are packed for one form (w_frag) keep the library's choice");
+    hipStream_t st = reinterpret_cast<hipStream_t>(s);
+    if (reps < 1) reps = 5;
+    if (reps > 31) reps = 31;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        mdx_set_error("mdx_gemm_tune: hipEventCreate failed");
+        return MDX_E_HIP;
+    }
+    auto measure = [&](const mdx_gemm_desc& c, float* us) -> int {
+        int rc = mdx_gemm_f16(&c, st);       // warm-up; also the validity check of this form
+        if (rc != MDX_OK) return rc;
+        float t[32];
+        for (int r = 0; r < reps; ++r) {
+            if (flush && flush_bytes) (void)hipMemsetAsync(flush, r & 1, flush_bytes, st);      // evict L2 / MALL: cold weights
+            (void)hipEventRecord(e0, st);
+            rc = mdx_gemm_f16(&c, st);
+            (void)hipEventRecord(e1, st);
+            if (rc != MDX_OK) return rc;
+            if (hipEventSynchronize(e1) != hipSuccess) {
+                mdx_set_error("mdx_gemm_tune: a trial launch failed on the device");
+                return MDX_E_HIP;
+            }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            t[r] = ms * 1e3f;
+        }
+        std::sort(t, t + reps);
+        *us = t[reps / 2];
+        return MDX_OK;
+    };
+    mdx_gemm_desc base = *d;
+    base.tile_m = base.tile_n = base.splitk = base.stages = 0;
+    int q0[7];
+    int rc = mdx_gemm_query(&base, q0);
+    float t_auto = 0.f;
+    if (rc == MDX_OK) rc = measure(base, &t_auto);
+    if (rc != MDX_OK) {
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return rc;
+    }
+    float t_best = t_auto;
+    int best[4] = {0, 0, 0, 0};
+    std::vector<long> seen;
+    auto form = [](const int* q) { return (long)q[0] | ((long)q[1] << 10) | ((long)q[2] << 20) | ((long)q[3] << 30) | ((long)q[6] << 31); };
+    seen.push_back(form(q0));
+    static const int BMS[] = {64, 128, 256}, BNS[] = {64, 128}, NSS[] = {1, 2, 3, 4, 6, 8, 12, 16, 20};
+    for (int bm : BMS)
+        for (int bn : BNS)
+            for (int ns : NSS) {
+                mdx_gemm_desc c = base;
+                c.tile_m = bm;
+                c.tile_n = bn;
+                c.splitk = ns;
+                int q[7];
+                if (mdx_gemm_query(&c, q) != MDX_OK) continue;
+                if (q[0] != bm || q[1] != bn || q[2] != ns) continue;      // clamped to something another trial covers
+                const long f = form(q);
+                if (std::find(seen.begin(), seen.end(), f) != seen.end()) continue;
+                seen.push_back(f);
+                float t = 0.f;
+                if (measure(c, &t) != MDX_OK) continue;
+                if (t < t_best) {
+                    t_best = t;
+                    best[0] = bm, best[1] = bn, best[2] = ns, best[3] = 0;
+                }
+            }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!(t_best < t_auto * 0.98f)) {
+        best[0] = best[1] = best[2] = best[3] = 0;
+        t_best = t_auto;
+    }
+    for (int i = 0; i < 4; ++i) best4[i] = best[i];
+    if (us2) us2[0] = t_auto, us2[1] = t_best;
     return MDX_OK;
 }

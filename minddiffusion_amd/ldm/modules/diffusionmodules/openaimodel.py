@@ -958,6 +958,18 @@ class UNetModel:
             # a fused head whose input tensor's producer cannot emit column statistics in its final launch form: plan again
             # with the unfused GroupNorm / proj_in / qkv launches (plans are built once per shape)
             return self._plan(B, H, W, _fuse_head=False)
+        # ---- first-use tuning (off by default): a resolution / batch the tile table was not measured at runs the cost model's
+        # tiles, 10-20 % off on some shapes; with the option on, every such launch form is timed once per shape (ops.tune_cache)
+        if ops.get_option("unet_tune_first_use"):
+            tws = ops.new_gemm_workspace(256 << 20, dev)
+            for d in descs:
+                d.workspace, d.workspace_bytes = tws.data_ptr(), tws.numel() * 4
+            P.tuned_shapes = ops.tune_untuned(descs)
+            torch.cuda.synchronize()
+            del tws
+            ops.release_tune_scratch()
+            for d in descs:
+                d.workspace, d.workspace_bytes = P.gemm_ws.data_ptr(), P.gemm_ws.numel() * 4
         # the statistics epilogue is part of the tile table's launch-variant key: a wired producer may resolve to another row
         # (another split) than the one the shared workspace was sized for -- size it again and grow it if needed
         need2 = max([ops.gemm_workspace_bytes(d) for d in descs] + [0])

@@ -34,7 +34,10 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
             # GroupNorm + SiLU inside the consuming 3x3 conv at levels with at least this many output rows (0 = never)
             # (mdx_gemm_desc.gn_colstats).  Measured round 3 at UNet batch 2: 7 GroupNorm launches fewer (-0.10 ms) but the convs'
             # in-LDS normalisation pass costs as much (+0.10 ms): 4.603 -> 4.641 ms per step.  Off.
-            "unet_gn_conv_fuse": int(os.environ.get("MDX_UNET_GN_CONV_FUSE", "0"))}
+            "unet_gn_conv_fuse": int(os.environ.get("MDX_UNET_GN_CONV_FUSE", "0")),
+            # 1 = when a plan is built, launches whose shape the measured tile table (csrc/gemm_tuned.inc) does not list are timed
+            # once on the device (mdx_gemm_tune, a few ms per distinct shape) and keep the fastest form; answers live in tune_cache
+            "unet_tune_first_use": int(os.environ.get("MDX_UNET_TUNE_FIRST_USE", "0"))}
 
 
 def set_option(name, value):
@@ -359,8 +362,9 @@ def gemm_workspace_bytes(desc):
 
 
 def new_gemm_workspace(nbytes, device):
-    """A split-K workspace for mdx_gemm_f16: fp32, ZERO-filled -- its first MDX_GEMM_WS_HEAD bytes are the tiles' arrival
-    counters of the in-kernel split-K reduce, which must start at zero (include/mdx.h, mdx_gemm_desc.workspace)."""
+    """A split-K workspace for mdx_gemm_f16 (fp32).  Needs no initialisation -- the arrival counters of the in-kernel split-K
+    reduce are library-owned (include/mdx.h, mdx_gemm_desc.workspace); zero-filled anyway so that a partial read before it is
+    written would at least be deterministic."""
     return torch.zeros(max(int(nbytes), 16) // 4 + 1, dtype=f32, device=device)
 
 
@@ -382,6 +386,72 @@ def account_gemm_launches(meta):
         q = gemm_query(d)
         m["launches"] = 2 if (q[2] > 1 and not q[6] and not d.defer_reduce) else 1
         m["info"] = m["info"].split(" split=")[0] + f" split={q[2] if q[2] > 1 else 0}" + ("i" if q[6] else "")
+
+
+# First-use tuning (include/mdx.h mdx_gemm_tune): the user-side cache.  key = gemm_shape_key(desc) -> (tile_m, tile_n, splitk,
+# stages, us of the library's choice, us of the best form).  save_tune_cache / load_tune_cache keep it across processes.
+tune_cache = {}
+_tune_flush = {}
+
+
+def gemm_shape_key(d):
+    """What a launch form depends on: problem shape + launch variant (the tile table's key, gemm.hip tuned_variant())."""
+    var = ((1 if d.c2 > 0 else 0) | (d.epilogue << 1) | (8 if d.n_split else 0) | (16 if d.ln_stats else 0)
+           | (32 if d.stats_out else 0) | (64 if d.out_mode == 1 else 0) | (128 if d.colstats_out else 0)
+           | (256 if d.residual else 0) | (512 if d.rowbias else 0) | (1024 if d.skip_w else 0) | (2048 if d.gn_gamma else 0))
+    return (d.B * d.H * d.W, d.N, d.ksize * d.ksize * (d.c1 + d.c2), d.ksize, d.stride, d.upsample, var)
+
+
+def gemm_tune(desc, reps=5, cold=True):
+    """mdx_gemm_tune on the current stream: (tile_m, tile_n, splitk, stages, us_auto, us_best); zeros = keep the library's
+    choice.  cold: a 512 MiB fill evicts L2 / Infinity Cache before every timed launch (weights arrive cold, as in a UNet
+    evaluation).  SYNCHRONISES; overwrites desc.out."""
+    flush, nbytes = None, 0
+    if cold:
+        dev = torch.cuda.current_device()
+        if dev not in _tune_flush:
+            _tune_flush[dev] = torch.empty(512 << 20, dtype=torch.uint8, device=f"cuda:{dev}")
+        flush, nbytes = ctypes.c_void_p(_tune_flush[dev].data_ptr()), _tune_flush[dev].numel()
+    best, us = (ctypes.c_int * 4)(), (ctypes.c_float * 2)()
+    _lib.check(_lib.load().mdx_gemm_tune(ctypes.byref(desc), _stream(), flush, nbytes, int(reps), best, us), "mdx_gemm_tune")
+    return tuple(int(v) for v in best) + (float(us[0]), float(us[1]))
+
+
+def tune_untuned(descs, reps=5):
+    """First-use pass of a planner: every descriptor whose shape neither the tile table nor tune_cache knows is measured once
+    (descriptors tied to their launch form -- colstats_out, defer_reduce, w_frag -- and forced ones are left alone); the
+    cached form is applied to every descriptor of that shape.  Returns the number of shapes measured."""
+    measured = 0
+    for d in descs:
+        if (d.colstats_out or d.defer_reduce or d.w_frag or d.skip_w or d.gn_gamma or d.tile_m or d.tile_n or d.splitk
+                or d.stages):
+            continue
+        key = gemm_shape_key(d)
+        if key not in tune_cache:
+            if gemm_query(d)[4]:        # the measured table has this shape
+                continue
+            tune_cache[key] = gemm_tune(d, reps)
+            measured += 1
+        tm, tn, sk, stg = tune_cache[key][:4]
+        d.tile_m, d.tile_n, d.splitk, d.stages = tm, tn, sk, stg
+    return measured
+
+
+def release_tune_scratch():
+    _tune_flush.clear()
+
+
+def save_tune_cache(path):
+    import json
+    with open(path, "w") as f:
+        json.dump([[list(k), list(v)] for k, v in sorted(tune_cache.items())], f)
+
+
+def load_tune_cache(path):
+    import json
+    with open(path) as f:
+        for k, v in json.load(f):
+            tune_cache[tuple(k)] = tuple(v)
 
 
 def gemm_run(desc):

@@ -420,7 +420,7 @@ def test_unet_plan_folds_layernorm_into_its_gemms(monkeypatch):
 
 def test_tuned_table_drives_the_split_choice():
     """mdx_gemm_workspace_bytes (host only, no launch) must follow csrc/gemm_tuned.inc for the shapes it lists: 0 when the entry
-    says one split, else MDX_GEMM_WS_HEAD bytes of arrival counters + splitk partials of the tile-padded output (which cover the
+    says one split, else the MDX_GEMM_WS_HEAD reserved bytes + splitk partials of the tile-padded output (which cover the
     [M][N] slabs of the reduce-kernel form as well)."""
     from minddiffusion_amd import _lib, ops
     lib = _lib.load()
@@ -450,7 +450,7 @@ def test_tuned_table_drives_the_split_choice():
 def test_split_k_form_is_decided_on_the_host():
     """mdx_gemm_query (host only): a split launch of at most 4 splits with a row-major output reduces in the kernel (7th output),
     deeper splits, transposed outputs and deferred reduces keep the [split][M][N] slabs + reduce kernel; the workspace the
-    library asks for covers the counters (MDX_GEMM_WS_HEAD) and the tile-padded partials; a workspace that is too small for a
+    library asks for covers the reserved head (MDX_GEMM_WS_HEAD) and the tile-padded partials; a workspace that is too small for a
     forced split is an error, not a silent fallback."""
     from minddiffusion_amd import _lib, ops
     lib = _lib.load()

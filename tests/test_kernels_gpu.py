@@ -204,8 +204,8 @@ def test_gemm_splitk_workspace_reuse(ops):
         d = ops.make_gemm_desc(a, w, N, M, 1, 1, K, out, N, bias=bv, splitk=sk)
         need = max(need, ops.gemm_workspace_bytes(d), sk * M * N * 4)
         descs.append((d, out))
-    ws = torch.full((need // 4,), float("nan"), dtype=torch.float32, device=DEV)   # stale garbage must not leak
-    ws[:4096] = 0       # ... except the arrival counters (MDX_GEMM_WS_HEAD bytes), which the caller hands over zeroed
+    ws = torch.full((need // 4,), float("nan"), dtype=torch.float32, device=DEV)   # stale garbage must not leak; the arrival
+    # counters are library-owned (include/mdx.h), so the WHOLE workspace may hold garbage
     for d, _ in descs:
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     first = None
@@ -227,8 +227,8 @@ def test_gemm_splitk_ticket_stress(ops):
     """In-kernel split-K reduce (csrc/gemm.hip splitk_last_block_reduce: write-through partials, one relaxed agent-scope
     ticket per tile, the last arriver sums in split order) under stress: three problems that ALL take the in-kernel form
     (2, 3 and 4 splits; many tiles; row statistics / GEGLU epilogues on top) rotate through ONE workspace whose partial area
-    is NaN-poisoned before every round and whose ticket head the LIBRARY zeroes (a torch.empty workspace: not pre-zeroed by
-    the caller), 400 eager rounds + 300 replays of a two-round hipGraph (2 800 launches of the in-kernel form in all).  A
+    is NaN-poisoned before every round -- head included, the arrival counters are library-owned, and the workspace comes from
+    torch's caching allocator, i.e. at an address earlier tests have used -- 400 eager rounds + 300 replays of a two-round hipGraph (2 800 launches of the in-kernel form in all).  A
     visibility bug -- a partial read before its writer's stores landed, a stale line, a ticket seen early -- would surface as a
     NaN from the poisoned area or as a changed bit: every round must be bit-identical to the first, and the first must agree
     with the same problems run through the separate reduce kernel (gemm_splitk_fixup_max = 0; same split order, but its
@@ -272,7 +272,7 @@ def test_gemm_splitk_ticket_stress(ops):
         refs = [(o.clone(), None if st is None else st.clone()) for _, o, st in ref_descs]
     finally:
         ops.set_option("gemm_splitk_fixup_max", 4)
-    ws = torch.empty(need // 4 + 1, dtype=torch.float32, device=DEV)      # NOT zeroed: the library owns the ticket head
+    ws = torch.empty(need // 4 + 1, dtype=torch.float32, device=DEV)      # NOT zeroed: the library owns the arrival counters
     ws.fill_(float("nan"))
     descs = build(ws)
     for d, _, _ in descs:
@@ -295,7 +295,7 @@ def test_gemm_splitk_ticket_stress(ops):
             if st is not None:
                 assert torch.equal(st, fst), f"{tag}: row statistics changed between launches"
     for rep in range(400):
-        ws[4096:].fill_(float("nan"))       # stale partials of the previous round must never be read
+        ws.fill_(float("nan"))              # stale partials of the previous round must never be read
         one_round()
         if rep % 50 == 49:
             torch.cuda.synchronize()
@@ -311,7 +311,8 @@ def test_gemm_splitk_ticket_stress(ops):
             same(f"graph replay {rep}")
     torch.cuda.synchronize()
     same("end")
-    assert bool((ws[:4096].view(torch.int32) == 0).all()), "arrival counters not back at zero"
+    # the library never writes the reserved head of the workspace any more
+    assert bool(torch.isnan(ws[:4096]).all()), "the reserved workspace head was written"
 
 
 def test_gemm_two_source_1x1(ops):
