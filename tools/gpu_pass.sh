@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box pass (run from the repo root through gpurun): stages selected by name, outputs under gpurun_out/<tag>/.
-#   tools/gpu_pass.sh <tag> tests bench configs prof pmc opprof
+#   tools/gpu_pass.sh <tag> tests bench configs prof profcfg pmc pmc_mfma opprof
 set -u
 export TMPDIR=/tmp
 TAG=${1:-r02}; shift
@@ -52,6 +52,13 @@ PY
         echo "pmc mfma attempt $attempt failed"
       done
       python tools/pmc_mfma.py $(find gpurun_out/pmc/MFMA -name '*_results.db' | head -1) "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph --no-other-configs (the timed configuration launched eagerly: rocprofv3 --pmc segfaults on hipGraph replay)" ${ATTN_PER_EVAL:-27} > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err; rm -rf gpurun_out/pmc/MFMA; cat $OUT/pmc_mfma.json | head -70; tail -3 $OUT/pmc_mfma.err ;;
+    profcfg)     # kernel traces of the other BASELINE configs (one unit each)
+      for cfg in wukong_512_plms sd2_768 glide_256; do
+        timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_cfg -o $TAG -- python bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline > $OUT/${cfg}_prof.log 2>&1
+        DB=$(find gpurun_out/prof_cfg -name "*_results.db" | head -1)
+        [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $OUT/${cfg}_kernel_stats.md
+        rm -rf gpurun_out/prof_cfg; head -8 $OUT/${cfg}_kernel_stats.md | cut -c1-160
+      done ;;
     opprof)
       timeout 200 python tools/op_profile.py --batch 2 --top 400 > $OUT/op_profile_b2.txt 2>&1; head -8 $OUT/op_profile_b2.txt ;;
     *) echo "unknown stage $stage" ;;

@@ -133,7 +133,9 @@ def main():
         best = (t_auto, 0, 0, 0, 0)
         bns = [128] if d0.epilogue == ops.EPI_GEGLU else ([64] if N < 128 else [128, 64])
         halo256 = halo and d0.H % 16 == 0
-        for bm in (([128, 256] if halo256 else [128]) if halo else [128, 64]):
+        # 8x8 images take the two-samples-per-tile HALO kernel whenever they are eligible (gemm.hip lookup_tuned drops 64-row
+        # rows for them), so 64-row generic tiles are not candidates there
+        for bm in (([128, 256] if halo256 else [128]) if (halo or halo8) else [128, 64]):
             for bn in bns:
                 for ns in NS_CANDIDATES:
                     if ns > 1 and (kt // ns < 2 or ns * M * N * 4 > big_ws.numel() * 4):
