@@ -131,7 +131,7 @@ _ENV_OPTIONS = {
     "MDX_GEMM_CFG": ("gemm_ring", lambda v: int(v.split(",")[-1])), "MDX_GEMM_HALO": ("gemm_halo", int),
     "MDX_GEMM_HALO8": ("gemm_halo8", int), "MDX_GEMM_SPLITK_FIXUP_MAX": ("gemm_splitk_fixup_max", int),
     "MDX_GEMM_SPREAD": ("gemm_spread", int), "MDX_HALO_NSB": ("halo_nsb", int), "MDX_GN_MIN_BLOCKS": ("gn_min_blocks", int),
-    "MDX_GN_FUSED": ("gn_fused", int),
+    "MDX_GN_FUSED": ("gn_fused", int), "MDX_GN_COL_CHUNKS": ("gn_col_chunks", int),
 }
 
 

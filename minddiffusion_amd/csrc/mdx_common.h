@@ -63,6 +63,7 @@ enum MdxOpt {
     MDX_OPT_HALO_NSB,            // 0 = auto | 2 | 3: weight ring depth of the HALO kernel
     MDX_OPT_GN_MIN_BLOCKS,       // GroupNorm: narrow the column blocks until the grid has this many blocks (512)
     MDX_OPT_GN_FUSED,            // 1: small tensors use the one-launch GroupNorm
+    MDX_OPT_GN_COL_CHUNKS,       // column-statistics GroupNorm: a column block spans at least this many 16-byte chunks of a pixel row (4)
     MDX_OPT_COUNT
 };
 int mdx_opt(int id);

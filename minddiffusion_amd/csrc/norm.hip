@@ -159,6 +159,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
             const float2* src = base + (size_t)b * nrb * cx + cc;
             float su = 0.f, sq = 0.f;
             int k = 0;
+            // Up to thirty-two partials in flight per thread: with minimal column blocks only chs (40 at C = 320) of the 256 threads fold,
+            // and four loads at a time made this prologue a chain of nrb / 4 L2 round trips (8 at the 64 x 64 level) in front of
+            // a kernel that streams its slab in a few microseconds.  Same order of additions as before: same bits.
+            for (; k + 32 <= nrb; k += 32) {
+                float2 v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v[u] = src[(size_t)(k + u) * cx];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    su += v[u].x;
+                    sq += v[u].y;
+                }
+            }
+            for (; k + 16 <= nrb; k += 16) {
+                float2 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(k + u) * cx];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    su += v[u].x;
+                    sq += v[u].y;
+                }
+            }
             for (; k + 4 <= nrb; k += 4) {
                 const float2 v0 = src[(size_t)k * cx], v1 = src[(size_t)(k + 1) * cx], v2 = src[(size_t)(k + 2) * cx],
                              v3 = src[(size_t)(k + 3) * cx];
@@ -284,7 +307,23 @@ __device__ __forceinline__ f16x8 gn_slab_load(const MdxSplitInfo& sp, int b, int
     }
     const size_t slab = (size_t)sp.M * sp.N;
     const float* base = sp.ws + (size_t)m * sp.N + n;
-    for (int z = 0; z < sp.nsplit; ++z) {
+    // four slabs' loads in flight per thread (a runtime-trip loop of load-then-add made this a chain of nsplit L2 round trips:
+    // 10-20 at the 8 x 8 level); the additions stay in slab order, so the sum keeps its bits
+    int z = 0;
+    for (; z + 4 <= sp.nsplit; z += 4) {
+        float4 a[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const float4*>(base + (size_t)(z + u) * slab);
+            c[u] = *reinterpret_cast<const float4*>(base + (size_t)(z + u) * slab + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f[0] += a[u].x; f[1] += a[u].y; f[2] += a[u].z; f[3] += a[u].w;
+            f[4] += c[u].x; f[5] += c[u].y; f[6] += c[u].z; f[7] += c[u].w;
+        }
+    }
+    for (; z < sp.nsplit; ++z) {
         const float4 s0 = *reinterpret_cast<const float4*>(base + (size_t)z * slab);
         const float4 s1 = *reinterpret_cast<const float4*>(base + (size_t)z * slab + 4);
         f[0] += s0.x; f[1] += s0.y; f[2] += s0.z; f[3] += s0.w; f[4] += s1.x; f[5] += s1.y; f[6] += s1.z; f[7] += s1.w;
@@ -608,7 +647,11 @@ static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const 
         const int lcm = p.cpg / gcd_i(p.cpg, 8) * 8;
         const int L = lcm / 8;
         MDX_REQUIRE(L <= 64, "mdx_groupnorm_colstats_f16: %d channels per group is not supported", p.cpg);
-        int cw = L * ((4 + L - 1) / L);      // >= 64 bytes per pixel row
+        int minc = mdx_opt(MDX_OPT_GN_COL_CHUNKS);
+        if (minc < 1) minc = 1;
+        if (minc > 64) minc = 64;
+        int cw = L * ((minc + L - 1) / L);   // >= 16 * gn_col_chunks bytes per pixel row (default 64)
+        if (cw > 64) cw = L * (64 / L);      // (<= 64 chunk columns per block: one per thread row)
         if (cw > p.CC) cw = p.CC;
         p.cw = cw;
         p.ncb = (p.CC + cw - 1) / cw;
