@@ -32,6 +32,9 @@ def check(name, got, ref, rel_l2=None, max_abs=None, max_rel=None, abs_q=None, *
     """Log and assert.  Tolerances are stated at the call site (fp16 storage / fp32 accumulate vs fp32 oracle)."""
     m = metrics(got, ref)
     rec = dict(name=name, **m, tol_rel_l2=rel_l2, tol_max_abs=max_abs, tol_max_rel=max_rel, **extra)
+    if abs_q is not None:  # (quantile, bound): robust to the few elements a clipped / chaotic trajectory flips
+        rec["abs_quantile"] = float(np.quantile(np.abs(to_np(got).astype(np.float64) - to_np(ref).astype(np.float64)), abs_q[0]))
+        rec["tol_abs_quantile"] = [float(abs_q[0]), float(abs_q[1])]
     try:
         os.makedirs(os.path.dirname(LOG), exist_ok=True)
         with open(LOG, "a") as f:
@@ -47,8 +50,8 @@ def check(name, got, ref, rel_l2=None, max_abs=None, max_rel=None, abs_q=None, *
     if max_rel is not None:  # max |d| relative to the largest reference magnitude
         assert m["max_abs"] <= max_rel * max(m["ref_max"], 1e-30), \
             f"{name}: max_abs {m['max_abs']:.3e} > {max_rel:.1e} * ref_max {m['ref_max']:.3e}"
-    if abs_q is not None:  # (quantile, bound): robust to the few elements a clipped / chaotic trajectory flips
-        qv = float(np.quantile(np.abs(to_np(got).astype(np.float64) - to_np(ref).astype(np.float64)), abs_q[0]))
+    if abs_q is not None:
+        qv = rec["abs_quantile"]
         assert qv <= abs_q[1], f"{name}: |d| quantile {abs_q[0]} = {qv:.3e} > {abs_q[1]:.1e}"
     return m
 
