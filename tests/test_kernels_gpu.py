@@ -315,6 +315,31 @@ def test_gemm_splitk_ticket_stress(ops):
     assert bool(torch.isnan(ws[:4096]).all()), "the reserved workspace head was written"
 
 
+def test_gemm_release_counters(ops):
+    """include/mdx.h mdx_gemm_release_counters: the library-owned arrival counters can be dropped (nothing in flight) and are
+    allocated again by the next in-kernel split-K launch -- same bits before and after, on an uninitialised workspace."""
+    from minddiffusion_amd import _lib
+    rng = np.random.RandomState(17)
+    M, N, K = 256, 640, 2560
+    a = dev16(h16(rng.standard_normal((M, K))))
+    w = pack_dense(h16(rng.standard_normal((N, K)) / math.sqrt(K)))
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ws = torch.full((16384 // 4 + 3 * 256 * 640 + 64,), float("nan"), dtype=torch.float32, device=DEV)
+    d = ops.make_gemm_desc(a, w, N, M, 1, 1, K, out, N, splitk=3, workspace=ws)
+    assert ops.gemm_query(d)[6] == 1
+    ops.gemm_run(d)
+    torch.cuda.synchronize()
+    first = out.clone()
+    _lib.check(_lib.load().mdx_gemm_release_counters(), "mdx_gemm_release_counters")
+    for _ in range(3):
+        out.zero_()
+        ops.gemm_run(d)
+        torch.cuda.synchronize()
+        assert torch.equal(out, first)
+    ref = torch.tensor(a.float().cpu().numpy() @ ops.unpack_gemm_weight(w, N, K).float().cpu().numpy().T)
+    check("gemm_release_counters_M256_N640_K2560_s3", out.float().cpu(), ref, rel_l2=1e-3)
+
+
 def test_gemm_two_source_1x1(ops):
     """ResBlock skip_connection on the (virtual) concat of h and the UNet skip tensor (openaimodel.py:174,568)."""
     rng = np.random.RandomState(5)
