@@ -549,11 +549,7 @@ class Text2ImUNet:
                     for op in P.main:
                         op()
                     torch.cuda.synchronize()
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        for op in P.main:
-                            op()
-                    P.graph = g
+                    P.graph = ops.capture_graph(P.main)
                 except Exception as e:  # pragma: no cover
                     P.graph, P.graph_failed = None, True
                     import warnings

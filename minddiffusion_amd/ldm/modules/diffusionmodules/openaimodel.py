@@ -1086,11 +1086,7 @@ class UNetModel:
             for op in body:  # warm-up outside capture
                 op()
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                for op in body:
-                    op()
-            P.graph = g
+            P.graph = ops.capture_graph(body)
             P.graph_ctx_len = P.ctx_len
         except Exception as e:  # pragma: no cover - depends on the runtime
             P.graph = None

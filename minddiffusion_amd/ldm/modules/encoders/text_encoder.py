@@ -165,11 +165,7 @@ class TextEncoder:
                     for op in P.main:
                         op()
                     torch.cuda.synchronize()
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        for op in P.main:
-                            op()
-                    P.graph = g
+                    P.graph = ops.capture_graph(P.main)
                 except Exception as e:  # pragma: no cover - depends on the runtime
                     P.graph, P.graph_failed = None, True
                     import warnings

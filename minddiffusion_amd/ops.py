@@ -57,6 +57,26 @@ def get_option(name):
     return int(out.value)
 
 
+def capture_graph(ops_list):
+    """Capture the calls of ops_list into one hipGraph and return it.  Python's cyclic garbage collector is held off for the
+    duration: a collection in the middle of a capture can finalise an OLDER plan (its graph, its buffers) -- hipGraphExecDestroy /
+    hipFree, calls the runtime refuses while a stream is capturing -- and an error inside a C++ destructor aborts the process
+    (seen once in round 3: a full test run died in a text-encoder capture while 40 earlier plans were waiting for the collector)."""
+    import gc
+    g = torch.cuda.CUDAGraph()
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(g):
+            for op in ops_list:
+                op()
+    finally:
+        if was_enabled:
+            gc.enable()
+    return g
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -300,10 +300,7 @@ def test_gemm_splitk_ticket_stress(ops):
         if rep % 50 == 49:
             torch.cuda.synchronize()
             same(f"eager round {rep}")
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        one_round()
-        one_round()
+    g = ops.capture_graph([one_round, one_round])      # (holds the cyclic GC off during the capture)
     for rep in range(300):
         g.replay()
         if rep % 100 == 99:
