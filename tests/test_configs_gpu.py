@@ -362,7 +362,7 @@ def test_first_use_tuner_at_a_resolution_the_tile_table_does_not_list():
     compiler picks kernels per shape).  A 768 x 512 image (96 x 64 latent, UNet batch 2) is not one of the benchmarked shapes, so
     most of its launches resolve through the cost model; with the option on the plan measures every such shape once (user-side
     cache ops.tune_cache) and must then be at least as fast per evaluation as the cost-model plan (3 % slack for timer and box
-    noise), with the same     result to the distance of two fp16 paths that tile / split differently."""
+    noise), with the same result to the distance of two fp16 paths that tile / split differently."""
     from minddiffusion_amd import ops
     from minddiffusion_amd.configs import SD2_UNET
     from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
