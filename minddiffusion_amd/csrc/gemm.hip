@@ -1990,6 +1990,11 @@ extern "C" int mdx_gemm_release_counters(void) {
         (void)hipSetDevice(c.first);
         (void)hipFree(c.second);
     }
+    for (auto& d : g_tickets.dev)
+        if (d.second.zero_stream) {
+            (void)hipSetDevice(d.first);
+            (void)hipStreamDestroy(d.second.zero_stream);
+        }
     (void)hipSetDevice(dv);
     g_tickets.chunks.clear();
     g_tickets.slot.clear();
