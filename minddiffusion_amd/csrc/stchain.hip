@@ -24,7 +24,8 @@
 //  * cross-attention: one (head, 32-query tile) per wave, K / V^T fragments straight from the cached context
 //    projections (L2-resident, 77 keys), S^T = K Q^T so a lane owns one query (softmax = one lane^32 exchange), P feeds
 //    PV from the S^T accumulator registers (key permutation trick of attention.hip).
-// Used where M / BM fills the chip (the 64 x 64 level at UNet batch 2; two levels at batch >= 8).
+// Built for C = 320 (heads x head dim 5 x 64 or 8 x 40): the 64 x 64 level of SDv2 / Wukong (96 x 96 at 768^2), where M / BM fills
+// the chip; at C = 640 / 1280 the per-block weight stream (13 / 52 MB) costs more than the launches it saves.
 #include "mdx_common.h"
 
 namespace {
