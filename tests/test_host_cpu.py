@@ -710,3 +710,49 @@ def test_library_options_replace_environment_variables():
     with pytest.raises(_lib.MdxError, match="unknown option"):
         ops.set_option("no_such_option", 1)
     assert lib.mdx_set_option(b"gemm_bm", 0) == 0
+
+
+def test_unet_plan_fuses_the_320_channel_transformer_blocks():
+    """Round 3, host side: at the level where a SpatialTransformer has 320 channels and the plan has >= 192 row blocks of 32 token
+    rows (64 x 64 latent, UNet batch 2) the planner emits THREE ops per block -- fused head (GroupNorm .. q|k|v), self-attention,
+    fused tail (to_out .. proj_out) -- instead of eleven (attention.py:83-84, 96-185, 212, 231-256); 640-channel blocks and plans
+    with too few rows keep the unfused launches; unet_st_head / unet_st_tail = 0 switch the fusion off.  Nothing is launched."""
+    from minddiffusion_amd import _lib, ops
+    from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from minddiffusion_amd.weights import synthetic_unet_params_numpy
+    cfg = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[1, 2], num_res_blocks=1,
+               channel_mult=[1, 2], num_head_channels=64, use_spatial_transformer=True, use_linear_in_transformer=True,
+               transformer_depth=1, context_dim=1024, legacy=False)
+    lib = _lib.load()
+
+    def build():
+        net = UNetModel(device="cpu", **cfg)
+        return net.load_state_dict(synthetic_unet_params_numpy(net.parameter_shapes(), 0))
+    launches = lambda P: sum(m["launches"] for m in P.meta)
+    kinds = lambda P: {k: sum(m["kind"] == k for m in P.meta) for k in ("gemm", "groupnorm", "attention")}
+    P = build()._plan(2, 64, 64)
+    blocks320 = 3                                   # one on the way down, two on the way up (num_res_blocks + 1)
+    assert len(P.tails) == blocks320 and len(P.heads_fused) == blocks320
+    for td in P.tails:
+        assert (td.C, td.heads, td.dim_head, td.tile_rows) == (320, 5, 64, 32) and td.B * td.tokens == 8192
+        assert lib.mdx_st_tail_supported(td.C, td.heads, td.dim_head, td.tokens, td.tile_rows) == 1
+    assert lib.mdx_st_tail_supported(640, 10, 64, 1024, 32) == 0 and lib.mdx_st_head_supported(640, 1024, 32) == 0
+    infos = [m["info"] for m in P.meta]
+    assert sum(i.startswith("st_head") for i in infos) == blocks320 and sum(i.startswith("st_tail") for i in infos) == blocks320
+    try:
+        ops.set_option("unet_st_tail", 0)
+        ops.set_option("unet_st_head", 0)
+        P0 = build()._plan(2, 64, 64)
+    finally:
+        ops.set_option("unet_st_tail", -1)
+        ops.set_option("unet_st_head", -1)
+    assert not P0.tails and not P0.heads_fused
+    k, k0 = kinds(P), kinds(P0)
+    # per fused block: 8 GEMMs (proj_in, q|k|v, to_out, q, to_out, ff1, ff2, proj_out) become 2, the GroupNorm and the
+    # cross-attention launch disappear
+    assert k0["gemm"] - k["gemm"] == 6 * blocks320 and k0["groupnorm"] - k["groupnorm"] == blocks320
+    assert k0["attention"] - k["attention"] == blocks320
+    assert launches(P0) - launches(P) == 8 * blocks320
+    # a 16 x 16 latent has 16 row blocks of 32 rows: far too few to fill the chip -> unfused
+    Ps = build()._plan(2, 16, 16)
+    assert not Ps.tails and not Ps.heads_fused
