@@ -756,3 +756,57 @@ def test_unet_plan_fuses_the_320_channel_transformer_blocks():
     # a 16 x 16 latent has 16 row blocks of 32 rows: far too few to fill the chip -> unfused
     Ps = build()._plan(2, 16, 16)
     assert not Ps.tails and not Ps.heads_fused
+
+
+def test_fused_transformer_weight_streams_follow_the_documented_layout():
+    """ops.pack_frag_weight / pack_st_tail / pack_st_head against an index-level restatement of DESIGN.md section 2: piece (column
+    tile ct, k-step s) holds, for lane l, W[32 ct + l % 32][16 s + 8 (l // 32) + 0..7] (the operand v_mfma_f32_32x32x16_f16 takes
+    from that lane); a wave's stream is its pieces of to_out1, to_q2, to_out2, then per hidden chunk the ff1 'a' and 'gate' pieces
+    of a k-step side by side followed by the chunk's ff2 pieces, then proj_out -- and the library's stream-size entry points agree
+    with the packers (the kernels bound their buffer loads by these sizes).  Host only."""
+    from minddiffusion_amd import _lib, ops
+    lib = _lib.load()
+    rng = np.random.RandomState(12)
+    C = 64                                           # layout rules do not depend on C; the kernels themselves need 320
+    NW, KS = C // 32, C // 16
+    mk = lambda n, k: torch.tensor(rng.standard_normal((n, k)).astype(np.float16))
+    w = mk(96, 48)
+    f = ops.pack_frag_weight(w)
+    assert f.shape == (3, 3, 512)
+    for ct, s, lane, e in [(0, 0, 0, 0), (2, 1, 37, 5), (1, 2, 63, 7), (2, 0, 31, 3), (0, 2, 32, 0)]:
+        assert f[ct, s, lane * 8 + e] == w[32 * ct + lane % 32, 16 * s + 8 * (lane // 32) + e]
+    wo1, wq2, wo2, wpo = (mk(C, C) for _ in range(4))
+    w1, w2 = mk(8 * C, C), mk(C, 4 * C)
+    vecs = [torch.tensor(rng.standard_normal(n).astype(np.float32)) for n in (C, C, C, C, C, C, 8 * C, C, C)]
+    stream, vec = ops.pack_st_tail(wo1, wq2, wo2, w1, w2, wpo, *vecs)
+    assert stream.shape == (NW, 16 * KS, 512) and vec.numel() == 16 * C
+    assert torch.equal(vec, torch.cat(vecs))
+    piece = lambda W, wave, s: ops.pack_frag_weight(W)[wave, s]
+    for wave in range(NW):
+        pos = 0
+        for W in (wo1, wq2, wo2):                    # three C x C units, KS pieces each
+            for s in range(KS):
+                assert torch.equal(stream[wave, pos], piece(W, wave, s))
+                pos += 1
+        for c in range(4):                           # hidden chunk c: columns [cC, cC + C) of 'a' and of 'gate'
+            a_rows, g_rows = w1[c * C:(c + 1) * C], w1[4 * C + c * C:4 * C + (c + 1) * C]
+            for s in range(KS):
+                assert torch.equal(stream[wave, pos], piece(a_rows, wave, s))
+                assert torch.equal(stream[wave, pos + 1], piece(g_rows, wave, s))
+                pos += 2
+            for s in range(KS):                      # ff2 over this chunk's K range
+                assert torch.equal(stream[wave, pos], piece(w2[:, c * C:(c + 1) * C], wave, s))
+                pos += 1
+        for s in range(KS):
+            assert torch.equal(stream[wave, pos], piece(wpo, wave, s))
+            pos += 1
+        assert pos == 16 * KS
+    hs, hv = ops.pack_st_head(wo1, wq2, wo2, wpo, *vecs[:5])
+    assert hs.shape == (NW, 4 * KS, 512) and hv.numel() == 5 * C
+    for wave in range(NW):
+        for u, W in enumerate((wo1, wq2, wo2, wpo)):
+            for s in range(KS):
+                assert torch.equal(hs[wave, u * KS + s], piece(W, wave, s))
+    for c in (320, 640):                             # 16 C^2 (tail) / 4 C^2 (head) fp16 elements
+        assert lib.mdx_st_tail_stream_bytes(c) == 16 * c * c * 2 and lib.mdx_st_head_stream_bytes(c) == 4 * c * c * 2
+    assert stream.numel() * 2 == 16 * C * C * 2 and hs.numel() * 2 == 4 * C * C * 2
