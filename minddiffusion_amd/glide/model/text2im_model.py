@@ -340,12 +340,27 @@ class Text2ImUNet:
                  out_mode=out_mode, out_bs=out_bs)
             return out
 
-        def conv3(src, cin, cout, wt, bias, h, wd, upsample=0, residual=None):
+        def conv3(src, cin, cout, wt, bias, h, wd, upsample=0, residual=None, skip=None):
+            """skip = (x, x2, c1, c2, packed 1x1 weights): the ResBlock's skip_connection rides on this launch as extra K tiles
+            (mdx_gemm_desc.skip_w, as in the latent-diffusion planner); `bias` then holds the sum of both convs' biases."""
             ho, wo = (2 * h, 2 * wd) if upsample else (h, wd)
             out = A.get((B, ho * wo, cout))
+            kw = {}
+            if skip is not None:
+                kw = dict(skip_a=skip[0], skip_a2=skip[1], skip_c1=skip[2], skip_c2=skip[3], skip_w=skip[4])
             gemm(a=src, w=wt, N=cout, B=B, H=h, W=wd, c1=cin, out=out, out_ld=cout, bias=bias, residual=residual,
-                 residual_ld=cout if residual is not None else 0, ksize=3, upsample=upsample)
+                 residual_ld=cout if residual is not None else 0, ksize=3, upsample=upsample, **kw)
+            if skip is not None:
+                meta[-1]["flops"] += 2 * B * ho * wo * cout * (skip[2] + skip[3])
+                meta[-1]["info"] += f" +skip1x1 K={skip[2] + skip[3]}"
             return out, ho, wo
+
+        def skip_fusable(a2, c1, c2, cout, ho, wo, wt):
+            """unet.py:214-218 `skip_connection(x) + h`: can the 1x1 conv ride on conv2 (whole 64-channel K tiles, HALO kernel)?"""
+            if not ops.get_option("unet_skip_fuse") or c1 % 64 or c2 % 64 or cout % 64:
+                return False
+            probe = ops.make_gemm_desc(a=a2, w=wt, N=cout, B=B, H=ho, W=wo, c1=cout, out=a2, out_ld=cout, ksize=3)
+            return ops.gemm_query(probe)[3] == 1
 
         # ---- text transformer (text2im_model.py:88-99, xf.py:36-154): every step, on all B rows
         x_tok = A.get((B, ctx, xw))
@@ -412,6 +427,13 @@ class Text2ImUNet:
             A.release(hbuf)
             if cin != cout:
                 c2 = 0 if x2 is None else x2.shape[2]
+                if mode not in ("up", "down") and skip_fusable(a2, cin - c2, c2, cout, ho, wo, w[pre + "conv2.w"]):
+                    if (pre + "conv2skip.b") not in w:
+                        w[pre + "conv2skip.b"] = (w[pre + "conv2.b"] + w[pre + "skip.b"]).contiguous()
+                    out, _, _ = conv3(a2, cout, cout, w[pre + "conv2.w"], w[pre + "conv2skip.b"], ho, wo,
+                                      skip=(x, x2, cin - c2, c2, w[pre + "skip.w"]))
+                    A.release(a2)
+                    return out, ho, wo
                 skip = dense(x, B, hw, cin, cout, w[pre + "skip.w"], bias=w[pre + "skip.b"], src2=x2, c2=c2)
             else:
                 assert x2 is None
