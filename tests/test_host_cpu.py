@@ -810,3 +810,26 @@ def test_fused_transformer_weight_streams_follow_the_documented_layout():
     for c in (320, 640):                             # 16 C^2 (tail) / 4 C^2 (head) fp16 elements
         assert lib.mdx_st_tail_stream_bytes(c) == 16 * c * c * 2 and lib.mdx_st_head_stream_bytes(c) == 4 * c * c * 2
     assert stream.numel() * 2 == 16 * C * C * 2 and hs.numel() * 2 == 4 * C * C * 2
+
+
+def test_bench_uses_the_committed_pmc_passes_only_for_the_launch_mix_they_were_taken_on():
+    """bench.py attaches `roofline.traffic` and per-family `mfma_busy` from the rocprofv3 PMC passes committed under profiles/
+    (counters cannot be read inside the timed process).  The files carry their own GEMM-family launch count per evaluation; a
+    build whose plan issues another count (a different launch mix) must get nulls and the reason, not stale numbers."""
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = json.load(open(os.path.join(root, "profiles", bench.PMC_FILE)))
+    n = doc["families"]["gemm"]["launches_per_eval"] + doc["families"]["splitk_reduce"]["launches_per_eval"]
+    per_launch, note = bench.pmc_traffic(round(n))
+    assert per_launch and 1e6 < per_launch < 1e9 and bench.PMC_FILE in note
+    total = sum(doc["families"][k][f] for k in ("gemm", "splitk_reduce") for f in ("read_MB_per_eval", "write_MB_per_eval"))
+    assert abs(per_launch * n - total * 1e6) <= n
+    stale, why = bench.pmc_traffic(round(n) + 40)
+    assert stale is None and "stale" in why
+    roof = {"families": {"gemm": {}, "attention": {}, "groupnorm": {}}}
+    bench.pmc_mfma_busy(roof, round(n))
+    assert 0.0 < roof["mfma_busy"] < 1.0 and 0.0 < roof["families"]["attention"]["mfma_busy"] < 1.0
+    roof2 = {"families": {"gemm": {}}}
+    bench.pmc_mfma_busy(roof2, round(n) + 40)
+    assert "mfma_busy" not in roof2 and "stale" in roof2["mfma_busy_note"]
