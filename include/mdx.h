@@ -407,6 +407,8 @@ int mdx_vae_gaussian_sample_f32(const void* moments, int ld, const float* noise,
 
 /* ---- probes used by tests to pin hardware layout assumptions (not on the hot path) */
 int mdx_probe_mfma_32x32x16_f16(const void* a, const void* b, float* c, mdx_stream_t s);
+/* Same for v_mfma_f32_16x16x32_f16 (the conv8p core): a, b = 64 lanes x 8 halves, c = 64 lanes x 4 floats. */
+int mdx_probe_mfma_16x16x32_f16(const void* a, const void* b, float* c, mdx_stream_t s);
 /* streaming-bandwidth probe of the HBM/L2 -> LDS DMA path (mode 0) vs plain vector loads (mode 1) */
 int mdx_probe_dma_stream(const void* src, size_t bytes_per_block, int nblocks, int waves, int per, int ns, int mode,
                          int stride_tiles, float* sink, mdx_stream_t s);

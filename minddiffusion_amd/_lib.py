@@ -120,6 +120,7 @@ SIGNATURES = {
     "mdx_vae_gaussian_sample_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mdx_softmax_rows_f16": (c_int, [c_void_p, c_long, c_int, c_int, c_float, c_void_p]),
     "mdx_probe_mfma_32x32x16_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdx_probe_mfma_16x16x32_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdx_probe_gemm_trace": (c_int, [c_void_p, c_size_t]),
     "mdx_probe_l2_stream": (c_int, [c_void_p, c_size_t, ctypes.c_uint, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mdx_probe_dma_stream": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -132,6 +133,7 @@ _ENV_OPTIONS = {
     "MDX_GEMM_HALO8": ("gemm_halo8", int), "MDX_GEMM_SPLITK_FIXUP_MAX": ("gemm_splitk_fixup_max", int),
     "MDX_GEMM_SPREAD": ("gemm_spread", int), "MDX_HALO_NSB": ("halo_nsb", int), "MDX_GN_MIN_BLOCKS": ("gn_min_blocks", int),
     "MDX_GN_FUSED": ("gn_fused", int), "MDX_GN_COL_CHUNKS": ("gn_col_chunks", int),
+    "MDX_GEMM_CONV8P": ("gemm_conv8p", int), "MDX_GEMM_CONV8P_MIN_M": ("gemm_conv8p_min_m", int),
 }
 
 

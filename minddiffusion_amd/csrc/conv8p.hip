@@ -1,0 +1,430 @@
+// conv8p: the 256-pixel, eight-wave, phase-staggered 3x3 conv core for gfx950 (MI355X) -- round 4.
+//
+//   out[m][n] = sum_{tap, c} A[pixel(m) + tap][c] * W[n][tap, c]   (+ conv1x1 skip tiles) + bias + time-embedding row + residual
+//
+// Replaces nn.Conv2d 3x3 / stride 1 / pad 1 of the ResBlocks (openaimodel.py:136-138, 159-163, 174, 201-205) wherever the launch
+// has M >= 8192 output pixels and the image tiles into 16 x 16 patches -- UNet batch >= 8 at the 64 x 64 / 32 x 32 (96 x 96 /
+// 48 x 48) levels, i.e. BASELINE configs 2-4.  The 128-row HALO kernel of rounds 1-3 (gemm.hip) keeps every other launch.
+//
+// Why another kernel.  The 128 x {64,128} tiles run four waves in lockstep: wait -> barrier -> DMA issue -> ds_read -> MFMA, one
+// barrier pair per K step, and measure 37-40 % of the MFMA peak.  This core follows the guide's 8-phase
+// recipe (cdna_hip_programming.md section 5, T2-T5) re-derived for a HALO conv:
+//   * M tile = one 16 x 16 pixel patch.  Per 64-channel chunk its 18 x 18 halo (324 rows x 128 B, zero padding from the buffer
+//     bounds check) is DMA'd into LDS ONCE and serves all nine taps; weights stream per tap (BN x 128 B) through a 3-stage ring.
+//     Per tap a CU moves BN x 128 B of weights + 4.6 KB of halo for 2 x 256 x BN x 64 FLOP: 19 B / clk at BN = 160.
+//   * EIGHT waves = 4 (M) x 2 (N), wave tile 64 pixels x BN/2 channels on `v_mfma_f32_16x16x32_f16` (BN = 160: 4 x 5 tiles, 80
+//     accumulator registers, 0.45 KB of LDS reads per MFMA).  The two waves that share a SIMD belong to different N halves and
+//     run HALF A PHASE APART (the N = 1 half takes one extra barrier up front): while one half issues its MFMAs, the other
+//     issues its `ds_read_b128`s -- the matrix pipe of a SIMD always has one wave feeding it and the LDS always has one half
+//     reading.  `s_setprio 1` around the MFMA burst lets the arbiter prefer the computing wave (T5: only pays with such a
+//     role split).
+//   * A phase = one tap (K = 64): 2 x (4 + BN/32) `ds_read_b128` -> `s_waitcnt vmcnt(0)` -> barrier -> DMA issue (weights of tap
+//     t + 2, one halo slice of the next chunk) -> 8 x BN/32 MFMAs -> barrier.  Every DMA batch gets a whole phase of flight time
+//     (issued at the start of an MFMA burst, waited for at the end of the NEXT read burst), and at that wait it is the ONLY
+//     batch outstanding, so the count is exact without per-wave bookkeeping.
+//   * Hazards under the half-phase stagger (barriers numbered globally; N = 0 half: reads of phase p between barriers 2p-1 and
+//     2p, MFMAs between 2p and 2p+1; N = 1 half one barrier later):
+//       RAW  a wave waits for its own DMAs before ARRIVING at barrier X; data may be read after barrier X.  Batch issued in
+//            phase p is waited for in the read burst of phase p+1 (before barriers 2p+2 / 2p+3), first read in phase p+2
+//            (after barriers 2p+3 / 2p+4).
+//       WAR  the last `ds_read` of a stage in phase p has returned when its wave passes `lgkmcnt(0)` behind barrier 2p (2p+1);
+//            every wave arrives at barrier 2p+2 after that, and the refill is issued behind barrier 2p+2 (2p+3).
+//   * LDS image and swizzle as in gemm.hip (lane-linear DMA destination, XOR on the SOURCE offset and again on the read):
+//     halo pieces keyed on the halo column, weight tiles pre-swizzled on the host -- the packed weights of
+//     ops.pack_conv_weight are used AS IS.  A 16 x 16 x 32 operand fragment is 16 consecutive rows x 4 k-quarters: conflict-free
+//     under the (row >> 1) & 7 key (2-way on 2 of 16 lanes for the kx = 1 taps).
+//   * ResBlock skip_connection (mdx_gemm_desc.skip_w) as extra dense K tiles after the taps, plain two-stage loop.
+//   * Epilogue: accumulators (C^T: lane = pixel, 4 consecutive channels per register group) -> fp16 staging tile in LDS ->
+//     16-byte coalesced stores with bias + per-sample time-embedding row + residual, and the GroupNorm column statistics of the
+//     patch (mdx_gemm_desc.colstats_out; rows per block = 256).
+#include "gemm_internal.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int C8_NT = 512;
+constexpr int C8_HINST = 41;                      // 324 halo rows / 8 rows per DMA instruction, rounded up
+constexpr int C8_HALO_BYTES = C8_HINST * 1024;    // 41 984
+constexpr int C8_RING = 2 * C8_HALO_BYTES;
+
+template <int BN>
+constexpr size_t c8_lds_bytes() {
+    const size_t main_loop = (size_t)C8_RING + 3u * BN * 128u;
+    const size_t epi = 256u * (BN + 8u) * 2u;
+    return main_loop > epi ? main_loop : epi;
+}
+
+template <int BN>
+__global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
+    constexpr int NJ = BN / 32;              // 16-column MFMA tiles per wave (a wave owns BN / 2 columns)
+    constexpr int B_BYTES = BN * 128;
+    constexpr int BINST = BN / 8;            // DMA instructions per weight tile (8 rows of 128 B each)
+    constexpr int BJ = (BINST + 7) / 8;      // ... per wave (the last round may be partial: wave-uniform guard)
+    static_assert(BN % 32 == 0 && BN >= 64 && BN <= 192, "BN: 64 .. 192 in steps of 32 (LDS: two halos + three weight tiles)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3;                 // patch rows 4 wm .. 4 wm + 3
+    const int wn = wave >> 2;                // column half; ALSO the stagger group (waves w and w + 4 share a SIMD)
+    const int l15 = lane & 15, q = lane >> 4;
+
+    // XCD-aware tile order (gemm.hip): block b runs on XCD b % 8; every XCD takes a contiguous run of tile ids, ids run fastest
+    // along M, so the blocks of one XCD share their weight tiles in that XCD's L2
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int tile_id = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile_id >= ntiles) return;
+    const int tile_n = tile_id / p.tiles_m;
+    const int tile_m = tile_id - tile_n * p.tiles_m;
+    const int n0 = tile_n * BN;
+    const int pw = p.W >> 4, ph = p.H >> 4;
+    const int pb = tile_m / (ph * pw);
+    const int prem = tile_m - pb * (ph * pw);
+    const int py0 = (prem / pw) * 16, px0 = (prem - (prem / pw) * pw) * 16;
+
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(p.a2 ? p.a2 : p.a, p.a2 ? p.a2_bytes : p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+
+    // ---- halo loader: piece id = qh * 8 + wave covers halo rows 8 id .. 8 id + 7 (lane / 8), 16-byte position lane % 8 holds
+    // logical chunk (lane % 8) ^ ((halo column >> 1) & 7)
+    const int lrow = lane >> 3, lchk = lane & 7;
+    int hal_pix[6];
+    unsigned hal_cb[6];
+#pragma unroll
+    for (int qh = 0; qh < 6; ++qh) {
+        const int hp = (qh * 8 + wave) * 8 + lrow;
+        const int hr = hp / 18, hc = hp - hr * 18;
+        const int y = py0 - 1 + hr, x = px0 - 1 + hc;
+        const bool ok = hp < 324 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        hal_pix[qh] = ok ? (pb * p.H + y) * p.W + x : -1;
+        hal_cb[qh] = (unsigned)((lchk ^ ((hc >> 1) & 7)) * 16);
+    }
+    auto dma_halo = [&](int qh, int chunk, int hb) {
+        if (qh * 8 + wave >= C8_HINST) return;                 // wave-uniform
+        int ci0 = chunk * 64;
+        const bool second = ci0 >= p.c1;
+        const unsigned cs2 = (unsigned)(second ? p.c2 : p.c1) * 2u;
+        if (second) ci0 -= p.c1;
+        const unsigned off = hal_pix[qh] >= 0 ? (unsigned)hal_pix[qh] * cs2 + (unsigned)(ci0 * 2) + hal_cb[qh] : MDX_OOB;
+        void* dst = smem + hb * C8_HALO_BYTES + (qh * 8 + wave) * 1024;
+        if (second)
+            dma16(rs_a2, dst, off);
+        else
+            dma16(rs_a, dst, off);
+    };
+    // ---- weight loader: piece idx = jb * 8 + wave covers tile rows 8 idx .. 8 idx + 7; the storage is tile-major and
+    // pre-swizzled ([N / 64 panels][K / 64 tiles][64 rows][8 chunks][8]): every piece is 1 KiB of contiguous memory
+    unsigned b_off[BJ];
+#pragma unroll
+    for (int jb = 0; jb < BJ; ++jb) {
+        const int n = n0 + (jb * 8 + wave) * 8 + lrow;
+        b_off[jb] = (unsigned)(((size_t)(n >> 6) * p.kt64) * 8192 + ((n & 63) * 8 + lchk) * 16);
+    }
+    auto dma_b = [&](int kt, int stage) {
+#pragma unroll
+        for (int jb = 0; jb < BJ; ++jb) {
+            if (jb * 8 + wave >= BINST) continue;              // wave-uniform
+            dma16(rs_w, smem + C8_RING + stage * B_BYTES + (jb * 8 + wave) * 1024, b_off[jb] + (unsigned)kt * 8192u);
+        }
+    };
+
+    f32x4v acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addresses.  A: lane (l15, q) of row tile i reads halo pixel (4 wm + i + ky) * 18 + l15 + kx, logical chunk
+    // 4 s + q.  B: row wn * BN/2 + 16 j + l15 of the weight tile, same chunk; its key (row >> 1) & 7 = (l15 >> 1) & 7.
+    const int a_lane = ((wm * 4) * 18 + l15) * 128;
+    const int b_lane = C8_RING + (wn * (BN / 2) + l15) * 128;
+    int axor[3][2], bxor[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bxor[s] = ((s * 4 + q) ^ ((l15 >> 1) & 7)) << 4;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) axor[kx][s] = ((s * 4 + q) ^ (((l15 + kx) >> 1) & 7)) << 4;
+    }
+
+    // bias + this sample's time-embedding row: one value per column for the whole patch -- fetched before the K loop
+    // (epilogue thread -> 8 columns at n0 + (tid % CPR) * 8)
+    constexpr int CPR = BN / 8;               // 16-byte chunks per staged row
+    constexpr int RPP = C8_NT / CPR;          // rows per store pass (the last RPP * CPR .. 511 threads idle in the store loop)
+    const int e_chunk = tid % CPR, e_r0 = tid / CPR;
+    const int e_n = n0 + e_chunk * 8;
+    const bool e_act = e_r0 < RPP && e_n < p.N;
+    float bb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bb[e] = 0.f;
+    if (e_act) {
+        if (p.bias) {
+            const float4* b4 = reinterpret_cast<const float4*>(p.bias + e_n);
+            const float4 x0 = b4[0], x1 = b4[1];
+            bb[0] = x0.x; bb[1] = x0.y; bb[2] = x0.z; bb[3] = x0.w; bb[4] = x1.x; bb[5] = x1.y; bb[6] = x1.z; bb[7] = x1.w;
+        }
+        if (p.rowbias) {
+            const float4* r4 = reinterpret_cast<const float4*>(p.rowbias + (size_t)pb * p.rowbias_ld + e_n);
+            const float4 x0 = r4[0], x1 = r4[1];
+            bb[0] += x0.x; bb[1] += x0.y; bb[2] += x0.z; bb[3] += x0.w; bb[4] += x1.x; bb[5] += x1.y; bb[6] += x1.z; bb[7] += x1.w;
+        }
+    }
+
+    const int nchunks = p.cin >> 6;
+    const int nt = nchunks * 9;
+
+    // ---- prologue: the first chunk's halo, the weights of taps 0 and 1
+#pragma unroll
+    for (int qh = 0; qh < 6; ++qh) dma_halo(qh, 0, 0);
+    dma_b(0, 0);
+    dma_b(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wn == 1) __builtin_amdgcn_s_barrier();          // the N = 1 half runs one barrier (half a phase) behind
+
+    int t = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const int hb = c & 1;
+        const bool more = c + 1 < nchunks;
+        const char* abase = smem + hb * C8_HALO_BYTES + a_lane;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++t) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const char* ap = abase + (ky * 18 + kx) * 128;
+            const char* bp = smem + b_lane + (tap % 3) * B_BYTES;
+            f16x8 af[2][4], bf[2][NJ];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bf[s][j] = *reinterpret_cast<const f16x8*>(bp + j * 2048 + bxor[s]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[s][i] = *reinterpret_cast<const f16x8*>(ap + i * (18 * 128) + axor[kx][s]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the batch issued one phase ago (this wave's share of it)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nt) dma_b(t + 2, (tap + 2) % 3);
+            if (more && tap < 6) dma_halo(tap, c + 1, hb ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (wn == 0) __builtin_amdgcn_s_barrier();          // both halves level again; every wave is done with the halos and the ring
+
+    if (p.skip_w) {
+        // ---- ResBlock skip_connection (openaimodel.py:174, 201-205): conv1x1 over the block's RAW input as extra dense K tiles
+        // of the same accumulators.  A tiles = the patch's 256 pixels x 64 channels (32 KB, in the halo area), weight tiles in
+        // the ring area; two stages, one barrier per tile, all waves in step.
+        const __amdgpu_buffer_rsrc_t rs_s1 = make_rsrc(p.skip_a, p.skip_a_bytes);
+        const __amdgpu_buffer_rsrc_t rs_s2 = make_rsrc(p.skip_a2 ? p.skip_a2 : p.skip_a, p.skip_a2 ? p.skip_a2_bytes : p.skip_a_bytes);
+        const __amdgpu_buffer_rsrc_t rs_sw = make_rsrc(p.skip_w, p.skip_w_bytes);
+        int s_pix[4];
+        unsigned s_cb[4];
+#pragma unroll
+        for (int qa = 0; qa < 4; ++qa) {
+            const int r = (qa * 8 + wave) * 8 + lrow;
+            s_pix[qa] = (pb * p.H + py0 + (r >> 4)) * p.W + px0 + (r & 15);
+            s_cb[qa] = (unsigned)((lchk ^ ((r >> 1) & 7)) * 16);
+        }
+        unsigned sb_off[BJ];
+#pragma unroll
+        for (int jb = 0; jb < BJ; ++jb) {
+            const int n = n0 + (jb * 8 + wave) * 8 + lrow;
+            sb_off[jb] = (unsigned)(((size_t)(n >> 6) * p.skip_kt) * 8192 + ((n & 63) * 8 + lchk) * 16);
+        }
+        auto stage_skip = [&](int kt, int st) {
+            int ci0 = kt * 64;
+            const bool second = ci0 >= p.skip_c1;
+            const unsigned cs2 = (unsigned)(second ? p.skip_c2 : p.skip_c1) * 2u;
+            if (second) ci0 -= p.skip_c1;
+#pragma unroll
+            for (int qa = 0; qa < 4; ++qa) {
+                const unsigned off = (unsigned)s_pix[qa] * cs2 + (unsigned)(ci0 * 2) + s_cb[qa];
+                void* dst = smem + st * C8_HALO_BYTES + (qa * 8 + wave) * 1024;
+                if (second)
+                    dma16(rs_s2, dst, off);
+                else
+                    dma16(rs_s1, dst, off);
+            }
+#pragma unroll
+            for (int jb = 0; jb < BJ; ++jb) {
+                if (jb * 8 + wave >= BINST) continue;
+                dma16(rs_sw, smem + C8_RING + st * B_BYTES + (jb * 8 + wave) * 1024, sb_off[jb] + (unsigned)kt * 8192u);
+            }
+        };
+        const int sa_lane = (wm * 64 + l15) * 128;
+        stage_skip(0, 0);
+        for (int kt = 0; kt < p.skip_kt; ++kt) {
+            const int st = kt & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();        // tile kt has landed for everyone; everyone is done reading stage st ^ 1
+            if (kt + 1 < p.skip_kt) stage_skip(kt + 1, st ^ 1);
+            const char* ap = smem + st * C8_HALO_BYTES + sa_lane;
+            const char* bp = smem + b_lane + st * B_BYTES;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f16x8 af[4], bf[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const f16x8*>(bp + j * 2048 + bxor[s]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f16x8*>(ap + i * 2048 + bxor[s]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();     // (nothing is in flight: plain barrier) the staging tile overwrites the halos / ring
+
+    // ---- epilogue.  C^T accumulators: lane (l15, q) of tile (i, j) holds pixel row 64 wm + 16 i + l15, channels
+    // wn BN/2 + 16 j + 4 q .. + 3.
+    constexpr int SLD = BN + 8;
+    f16* stg = reinterpret_cast<f16*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int m_l = wm * 64 + i * 16 + l15;
+            const int n_l = wn * (BN / 2) + j * 16 + 4 * q;
+            *reinterpret_cast<f16x4*>(&stg[m_l * SLD + n_l]) = cvt4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    __syncthreads();
+    const bool colstats = p.colstats_out != nullptr;
+    float cs[8], cq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
+    const int mbase = (pb * p.H + py0) * p.W + px0;
+    constexpr int NPASS = (256 + RPP - 1) / RPP;
+    if (e_act) {
+        f16x8 res_n = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.residual && e_r0 < 256)
+            res_n = *reinterpret_cast<const f16x8*>(p.residual + (size_t)(mbase + (e_r0 >> 4) * p.W + (e_r0 & 15)) * p.residual_ld + e_n);
+#pragma unroll 4
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int row = e_r0 + pass * RPP;
+            if (row >= 256) break;
+            const int m = mbase + (row >> 4) * p.W + (row & 15);
+            const f16x8 res = res_n;
+            const int row2 = row + RPP;
+            if (p.residual && row2 < 256)
+                res_n = *reinterpret_cast<const f16x8*>(p.residual + (size_t)(mbase + (row2 >> 4) * p.W + (row2 & 15)) * p.residual_ld + e_n);
+            const f16x8 v = *reinterpret_cast<const f16x8*>(&stg[row * SLD + e_chunk * 8]);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[e] + bb[e];
+                if (p.residual) f += (float)res[e];
+                o[e] = (f16)f;
+            }
+            *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + e_n) = o;
+            if (colstats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float tv = (float)o[e];    // statistics of the fp16 values actually stored
+                    cs[e] += tv;
+                    cq[e] += tv * tv;
+                }
+            }
+        }
+    }
+    if (colstats) {      // (block-uniform) fold the RPP row lanes of every column in a fixed order: deterministic
+        __syncthreads();                                  // every thread is done reading the staged tile
+        float* part = reinterpret_cast<float*>(smem);     // [RPP][BN][2]
+        if (e_r0 < RPP) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                part[((size_t)e_r0 * BN + e_chunk * 8 + e) * 2] = cs[e];
+                part[((size_t)e_r0 * BN + e_chunk * 8 + e) * 2 + 1] = cq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN * 2) {
+            const int cc = tid >> 1;
+            float a = 0.f;
+            for (int r = 0; r < RPP; ++r) a += part[((size_t)r * BN + cc) * 2 + (tid & 1)];
+            if (n0 + cc < p.N) p.colstats_out[((size_t)tile_m * p.N + n0 + cc) * 2 + (tid & 1)] = a;
+        }
+    }
+}
+
+template <int BN>
+void c8_launch(const GemmParams& p, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = c8_lds_bytes<BN>();
+    static bool attr_set[64] = {};
+    int dv = 0;
+    (void)hipGetDevice(&dv);
+    if (dv >= 0 && dv < 64 && !attr_set[dv]) {        // hipFuncSetAttribute is per device
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[dv] = true;
+    }
+    hipLaunchKernelGGL((conv8p_kernel<BN>), grid, dim3(C8_NT), lds, st, p);
+}
+
+}  // namespace
+
+// Shapes the core handles: 3x3 / stride 1 / pad 1, channel counts in whole 64-channel chunks (two-source concat: the first
+// source too), images tiling into 16 x 16 patches, plain row-major output (bias / time-embedding row / residual / column statistics /
+// fused skip 1x1), tile-major weights.
+bool mdx_conv8p_eligible(const GemmParams& p) {
+    if (!(p.ksize == 3 && p.stride == 1 && !p.upsample && p.pad == 1)) return false;
+    if (p.cin % 64 != 0 || (p.c2 > 0 && p.c1 % 64 != 0) || p.cin < 64) return false;
+    if (p.H % 16 != 0 || p.W % 16 != 0) return false;
+    if (p.out_mode != MDX_OUT_ROWMAJOR || p.epilogue != MDX_EPI_NONE || p.n_split || p.ln_stats || p.stats_out || p.out_bs ||
+        p.gn_cs)
+        return false;
+    if (p.N % 8 != 0 || p.N < 64) return false;
+    return true;
+}
+
+// N tile: the widest of 160 / 192 / 128 that wastes no columns, else the one that wastes the fewest.
+int mdx_conv8p_pick_bn(const GemmParams& p, int bn_hint) {
+    if (bn_hint == 128 || bn_hint == 160 || bn_hint == 192) return bn_hint;
+    static const int cand[3] = {160, 192, 128};
+    int best = 128;
+    double best_eff = 0.0;
+    for (int bn : cand) {
+        const int tiles = (p.N + bn - 1) / bn;
+        const double eff = (double)p.N / ((double)tiles * bn);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best = bn;
+        }
+    }
+    return best;
+}
+
+int mdx_conv8p_launch(GemmParams& p, int bn, hipStream_t st) {
+    p.tiles_m = p.B * (p.H >> 4) * (p.W >> 4);
+    p.tiles_n = (p.N + bn - 1) / bn;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    p.tiles_per_xcd = (ntiles + 7) / 8;
+    p.nsplit = 1;
+    const dim3 grid(8 * p.tiles_per_xcd);
+    if (bn == 160)
+        c8_launch<160>(p, grid, st);
+    else if (bn == 192)
+        c8_launch<192>(p, grid, st);
+    else if (bn == 128)
+        c8_launch<128>(p, grid, st);
+    else {
+        mdx_set_error("mdx_gemm_f16: conv8p has no %d-column tile", bn);
+        return MDX_E_INVALID;
+    }
+    return MDX_OK;
+}

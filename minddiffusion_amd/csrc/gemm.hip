@@ -23,6 +23,7 @@
 //  * choose_tiling picks the tile height and the split-K factor per shape from a measured cost model;
 //    split-K = fp32 slabs + a fused reduce/epilogue kernel (fixed slab order: deterministic).
 #include "mdx_common.h"
+#include "gemm_internal.h"
 
 #include <stdlib.h>
 
@@ -34,130 +35,6 @@
 
 namespace {
 
-struct GemmParams {
-    const f16* a;
-    const f16* a2;
-    const f16* w;
-    const float* bias;
-    const float* rowbias;
-    const f16* residual;
-    f16* out;
-    f16* out2;       // transposed destination of the columns n >= n_split (0 = none): q|k row-major + V^T in ONE launch
-    float* ws;
-    unsigned* tickets;       // in-kernel split-K reduce: one arrival counter per output tile (library-owned, ticket_slot()), else null
-    int c1, c2, cin;
-    int rowbias_ld, residual_ld, out_ld, out2_ld, n_split;
-    // LayerNorm folded into the GEMMs around it (mdx.h): the PRODUCER of the token stream writes per-row {sum, sumsq}
-    // partials of the fp16 values it stores, one pair per N tile; the CONSUMER multiplies the raw tokens by gamma (.) W
-    // and turns acc into rstd * (acc - mean * S[n]) in the accumulator registers before the usual epilogue.
-    float* stats_out;        // producer: [M][N / 64][2]
-    float* colstats_out;     // GroupNorm statistics for the consumer: [row block][N][2] (mdx.h)
-    const float* ln_stats;   // consumer: [M][ln_nt][2] written by the producer
-    const float* ln_s;       // consumer: S[n] = sum_k (gamma (.) W)[n][k], fp32 [N]
-    int ln_nt;
-    int bn_hint;             // mdx_gemm_desc.tile_n
-    int st_hint;             // mdx_gemm_desc.stages
-    int spread;              // gemm_kernel: 1-D grid of (tile, split) items dealt round-robin to the XCDs
-    float ln_eps;
-    long out_bs;   // element stride between samples of a row-major output (0 = dense [M][out_ld])
-    int B, H, W, Ho, Wo, HoWo, M, N, K;
-    int ksize, stride, upsample, pad;
-    int epilogue, out_mode;
-    int ktiles, ktiles_per_split, nsplit;
-    int tiles_m, tiles_n, tiles_per_xcd, n_fastest;
-    int kt64;   // 64-wide K tiles in the packed weight storage
-    unsigned a_bytes, a2_bytes, w_bytes;
-    int bk;
-    unsigned long long* trace;   // diagnostics: per-block phase timestamps (mdx_probe_gemm_trace), else null
-    // GroupNorm (+ SiLU) of the conv's INPUT applied inside the conv (mdx_gemm_desc.gn_colstats)
-    const float* gn_cs;
-    const float* gn_gamma;
-    const float* gn_beta;
-    int gn_nrb, gn_silu;
-    float gn_eps;
-    // ResBlock skip_connection fused into conv2 (mdx_gemm_desc.skip_w): extra 1x1 K tiles over the block's raw input
-    const f16* skip_a;
-    const f16* skip_a2;
-    const f16* skip_w;
-    int skip_c1, skip_c2, skip_kt, skip_kt_per_split;
-    unsigned skip_a_bytes, skip_a2_bytes, skip_w_bytes;
-};
-
-
-__device__ __forceinline__ f16x4 cvt4(float a, float b, float c, float d) {
-    f16x4 v;
-    v[0] = (f16)a;
-    v[1] = (f16)b;
-    v[2] = (f16)c;
-    v[3] = (f16)d;
-    return v;
-}
-
-// Fused epilogue for 8 consecutive output columns of one row (fp32 in, fp16 out), in two halves so that callers can
-// issue the global loads (time-embedding row, residual) EARLY -- before the LDS staging barrier / the slab loads --
-// and pay their latency once, overlapped, instead of once per dependent step.
-struct Row8Extras {
-    float4 r0, r1;   // per-sample row bias
-    f16x8 res;       // residual
-};
-
-__device__ __forceinline__ Row8Extras epilogue_prefetch_row8(const GemmParams& p, int m, int n) {
-    Row8Extras x;
-    if (p.rowbias) {
-        const int b = m / p.HoWo;
-        const float4* rb = reinterpret_cast<const float4*>(p.rowbias + (size_t)b * p.rowbias_ld + n);
-        x.r0 = rb[0];
-        x.r1 = rb[1];
-    }
-    if (p.residual) x.res = *reinterpret_cast<const f16x8*>(p.residual + (size_t)m * p.residual_ld + n);
-    return x;
-}
-
-__device__ __forceinline__ f16x8 epilogue_apply_row8(const GemmParams& p, float (&f)[8], int m, int n, const Row8Extras& x) {
-    if (p.rowbias) {
-        f[0] += x.r0.x; f[1] += x.r0.y; f[2] += x.r0.z; f[3] += x.r0.w;
-        f[4] += x.r1.x; f[5] += x.r1.y; f[6] += x.r1.z; f[7] += x.r1.w;
-    }
-    if (p.residual) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += (float)x.res[e];
-    }
-    f16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (f16)f[e];
-    size_t row = (size_t)m * p.out_ld;
-    if (p.out_bs) {
-        const int b = m / p.HoWo;
-        row = (size_t)b * p.out_bs + (size_t)(m - b * p.HoWo) * p.out_ld;
-    }
-    *reinterpret_cast<f16x8*>(p.out + row + n) = o;
-    return o;
-}
-
-__device__ __forceinline__ void epilogue_store_row8(const GemmParams& p, float (&f)[8], int m, int n) {
-    const Row8Extras x = epilogue_prefetch_row8(p, m, n);
-    epilogue_apply_row8(p, f, m, n, x);
-}
-
-// Diagnostics (mdx_probe_gemm_trace): block `bid` records the 100 MHz realtime counter at phase `slot`.
-// Compiled in only with -DMDX_GEMM_TRACE (libmdx_trace.so, `make trace`); the product library carries no trace code.
-__device__ __forceinline__ void trace_mark(const GemmParams& p, int slot) {
-#ifdef MDX_GEMM_TRACE
-    if (p.trace && threadIdx.x == 0)
-        p.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
-#endif
-}
-
-// Row maps: tile-local output row -> global output row m.
-struct LinearRows {
-    int m0;
-    __device__ __forceinline__ int operator()(int row) const { return m0 + row; }
-};
-// HALO conv tiles are 8 x 16 pixel patches: row = py*16 + px
-struct PatchRows {
-    int base, W;   // base = (b*H + y0)*W + x0
-    __device__ __forceinline__ int operator()(int row) const { return base + (row >> 4) * W + (row & 15); }
-};
 
 // The row-major epilogue's bias columns of this thread, fetched BEFORE the K loop: biases are cold in HBM (1.7 GB of
 // weights stream through the caches between two uses), and a 1-3 us miss at the start of the epilogue was the largest
@@ -1872,6 +1749,8 @@ extern "C" int mdx_probe_gemm_trace(void* buf, size_t bytes) {
 // ~65 GB/s one block can pull, so the in-kernel form only beats the reduce launch it replaces for few splits (measured at UNet
 // batch 2, profiles/r02_l_splitk_fixup.txt: 4 splits -1.7 us, 3 splits -1.4 us, 5 splits 0 ... +1.7 us, 10 splits +7 us,
 // 20 splits +8 us per launch); deeper splits, transposed outputs and deferred reduces keep the [split][M][N] slabs + reduce kernel.
+static bool conv8p_wanted(const mdx_gemm_desc* d, const GemmParams& p);
+
 static bool fixup_eligible(const mdx_gemm_desc* d, const GemmParams& p, int bm, int bn, int ns) {
     const int max_ns = mdx_opt(MDX_OPT_GEMM_SPLITK_FIXUP_MAX);
     if (ns > max_ns) return false;
@@ -1893,6 +1772,7 @@ static size_t split_bytes(const mdx_gemm_desc* d, const GemmParams& p, int bm, i
 extern "C" size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d) {
     GemmParams p{};
     if (fill_params(d, p) != MDX_OK) return 0;
+    if (conv8p_wanted(d, p)) return 0;
     const GemmCfg c = pick_cfg(p);
     const Tiling tl = choose_tiling(p, c.bn, d->splitk, d->tile_m);
     if (tl.ns <= 1) return 0;
@@ -1919,6 +1799,7 @@ struct Resolved {
     int stages;      // LDS ring depth forced by the descriptor or the tile table (0 = the occupancy rule)
     bool halo, tuned;
     bool fixup;      // split-K reduced by the last block of each tile (no reduce launch)
+    bool c8;         // the 256-pixel eight-wave conv core (conv8p.hip); implies halo, tile_m 256, no split
 };
 
 // Arrival counters of the in-kernel split-K reduce.  They used to sit in the first MDX_GEMM_WS_HEAD bytes of the caller's
@@ -2002,7 +1883,38 @@ extern "C" int mdx_gemm_release_counters(void) {
     return MDX_OK;
 }
 
+// The eight-wave 256-pixel conv core takes a launch when the descriptor forces it (tile_m = 256 with stages = 8) or, by default,
+// when the shape is eligible and has at least gemm_conv8p_min_m output pixels (UNet batch >= 8 at the two largest levels): below
+// that a 256 x 160 tile grid cannot fill 256 CUs and the 128-row HALO tiles with split-K win.
+static bool conv8p_wanted(const mdx_gemm_desc* d, const GemmParams& p) {
+    if (!mdx_opt(MDX_OPT_GEMM_CONV8P) || d->w_frag || d->defer_reduce || d->splitk > 1 || d->asym_pad) return false;
+    if (mdx_opt(MDX_OPT_GEMM_BM) || !mdx_opt(MDX_OPT_GEMM_HALO)) return false;
+    if (!mdx_conv8p_eligible(p)) return false;
+    if (d->tile_m == 256 && d->stages == 8) return true;
+    if (d->tile_m != 0 || d->stages != 0) return false;
+    if (d->tile_n != 0 && d->tile_n != 128 && d->tile_n != 160 && d->tile_n != 192) return false;
+    return p.M >= mdx_opt(MDX_OPT_GEMM_CONV8P_MIN_M);
+}
+
 static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
+    r.c8 = false;
+    if (conv8p_wanted(d, p)) {
+        r.c = GemmCfg{256, mdx_conv8p_pick_bn(p, d->tile_n), 64, 3};
+        r.bn = r.c.bn;
+        r.ns = 1;
+        r.stages = 8;
+        r.halo = true;
+        r.tuned = false;
+        r.fixup = false;
+        r.c8 = true;
+        p.bk = 64;
+        p.ktiles = (p.K + 63) / 64;
+        p.nsplit = 1;
+        p.ktiles_per_split = p.ktiles;
+        p.skip_kt_per_split = p.skip_w ? p.skip_kt : 0;
+        p.tickets = nullptr;
+        return MDX_OK;
+    }
     r.c = pick_cfg(p);
     const int bn = r.bn = r.c.bn;
     p.bk = r.c.bk;
@@ -2133,6 +2045,12 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         MDX_REQUIRE((p.M + rows - 1) / rows <= d->colstats_cap,
                     "mdx_gemm_f16: colstats_out holds %d row blocks, this launch writes %d (%d rows each)", d->colstats_cap,
                     (p.M + rows - 1) / rows, rows);
+    }
+    if (rs.c8) {
+        rc = mdx_conv8p_launch(p, bn, st);
+        if (rc != MDX_OK) return rc;
+        MDX_LAUNCH_CHECK("mdx_gemm_f16(conv8p)");
+        return MDX_OK;
     }
     MDX_REQUIRE(!d->defer_reduce || ns > 1, "mdx_gemm_f16: defer_reduce set but the launch does not split K");
     MDX_REQUIRE(!rs.fixup || ((uintptr_t)p.ws % 16 == 0), "mdx_gemm_f16: workspace must be 16-byte aligned");

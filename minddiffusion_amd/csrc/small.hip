@@ -19,8 +19,8 @@ extern "C" const char* mdx_last_error(void) { return g_err; }
 // ------------------------------------------------------------------ library options
 static const char* const g_opt_names[MDX_OPT_COUNT] = {"gemm_tuned", "gemm_bm", "gemm_bn", "gemm_ring", "gemm_halo", "gemm_halo8",
                                                         "gemm_splitk_fixup_max", "gemm_spread", "halo_nsb", "gn_min_blocks",
-                                                        "gn_fused", "gn_col_chunks"};
-static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1, 4};
+                                                        "gn_fused", "gn_col_chunks", "gemm_conv8p", "gemm_conv8p_min_m"};
+static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1, 4, 1, 8192};
 
 int mdx_opt(int id) { return g_opt[id]; }
 
@@ -193,6 +193,16 @@ __global__ void probe_mfma_kernel(const f16* a, const f16* b, float* c) {
     for (int r = 0; r < 16; ++r) c[lane * 16 + r] = acc[r];
 }
 
+__global__ void probe_mfma16_kernel(const f16* a, const f16* b, float* c) {
+    const int lane = threadIdx.x;
+    const f16x8 av = *reinterpret_cast<const f16x8*>(a + lane * 8);
+    const f16x8 bv = *reinterpret_cast<const f16x8*>(b + lane * 8);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[lane * 4 + r] = acc[r];
+}
+
 inline int grid_for(size_t total) {
     size_t b = (total + 255) / 256;
     return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -287,6 +297,13 @@ extern "C" int mdx_probe_mfma_32x32x16_f16(const void* a, const void* b, float* 
     MDX_REQUIRE(a && b && c, "mdx_probe_mfma_32x32x16_f16: null pointer");
     hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const f16*)a, (const f16*)b, c);
     MDX_LAUNCH_CHECK("mdx_probe_mfma_32x32x16_f16");
+    return MDX_OK;
+}
+
+extern "C" int mdx_probe_mfma_16x16x32_f16(const void* a, const void* b, float* c, mdx_stream_t s) {
+    MDX_REQUIRE(a && b && c, "mdx_probe_mfma_16x16x32_f16: null pointer");
+    hipLaunchKernelGGL(probe_mfma16_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const f16*)a, (const f16*)b, c);
+    MDX_LAUNCH_CHECK("mdx_probe_mfma_16x16x32_f16");
     return MDX_OK;
 }
 

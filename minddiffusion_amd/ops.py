@@ -561,6 +561,12 @@ def probe_mfma(a, b):
     return c
 
 
+def probe_mfma16(a, b):
+    c = torch.empty((64, 4), dtype=f32, device=a.device)
+    _lib.check(_lib.load().mdx_probe_mfma_16x16x32_f16(_ptr(a), _ptr(b), _ptr(c), _stream()), "mdx_probe_mfma16")
+    return c
+
+
 def pack_b_operand(src2d, out=None):
     """Row-major fp16 activation matrix [rows, K] (any row stride) -> packed B operand of mdx_gemm_f16."""
     rows, K = src2d.shape
