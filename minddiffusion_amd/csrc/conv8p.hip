@@ -42,6 +42,8 @@
 namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+constexpr int C8_TICKET_SLOTS = MDX_GEMM_WS_HEAD / 4;     // floats (= ticket slots) reserved at the head of the workspace
 
 constexpr int C8_NT = 512;
 constexpr int C8_HINST = 41;                      // 324 halo rows / 8 rows per DMA instruction, rounded up
@@ -55,13 +57,15 @@ constexpr size_t c8_lds_bytes() {
     return main_loop > epi ? main_loop : epi;
 }
 
-template <int BN>
+template <int BN, int PH>
 __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     constexpr int NJ = BN / 32;              // 16-column MFMA tiles per wave (a wave owns BN / 2 columns)
     constexpr int B_BYTES = BN * 128;
     constexpr int BINST = BN / 8;            // DMA instructions per weight tile (8 rows of 128 B each)
     constexpr int BJ = (BINST + 7) / 8;      // ... per wave (the last round may be partial: wave-uniform guard)
     static_assert(BN % 32 == 0 && BN >= 64 && BN <= 192, "BN: 64 .. 192 in steps of 32 (LDS: two halos + three weight tiles)");
+    constexpr int Q = 4 * NJ;                // 16-byte accumulator pieces per thread (tail-split partials)
+    constexpr unsigned PART = (unsigned)Q * C8_NT * 16u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -73,9 +77,24 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
 
     // XCD-aware tile order (gemm.hip): block b runs on XCD b % 8; every XCD takes a contiguous run of tile ids, ids run fastest
     // along M, so the blocks of one XCD share their weight tiles in that XCD's L2
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int tile_id = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
-    if (tile_id >= ntiles) return;
+    // The first c8_full tiles (a multiple of 256) run whole; each of the remaining c8_rem tiles is split c8_split ways along the
+    // 64-channel chunks so that the last, partly filled round still puts a block on every CU (the splits of one tile sit on one
+    // XCD: their partials meet in that XCD's L2).
+    int tile_id, split = 0, nsplit = 1;
+    {
+        const int bid = blockIdx.x;
+        if (bid < p.c8_full) {
+            tile_id = (bid & 7) * (p.c8_full >> 3) + (bid >> 3);
+        } else {
+            const int b2 = bid - p.c8_full;
+            const int jx = b2 >> 3;
+            const int r = (b2 & 7) + 8 * (jx / p.c8_split);
+            if (r >= p.c8_rem) return;
+            split = jx - (jx / p.c8_split) * p.c8_split;
+            nsplit = p.c8_split;
+            tile_id = p.c8_full + r;
+        }
+    }
     const int tile_n = tile_id / p.tiles_m;
     const int tile_m = tile_id - tile_n * p.tiles_m;
     const int n0 = tile_n * BN;
@@ -91,16 +110,14 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     // ---- halo loader: piece id = qh * 8 + wave covers halo rows 8 id .. 8 id + 7 (lane / 8), 16-byte position lane % 8 holds
     // logical chunk (lane % 8) ^ ((halo column >> 1) & 7)
     const int lrow = lane >> 3, lchk = lane & 7;
-    int hal_pix[6];
-    unsigned hal_cb[6];
+    int hal_pk[6];           // (source pixel index << 3) | physical->logical chunk of this lane, or -1 outside the image
 #pragma unroll
     for (int qh = 0; qh < 6; ++qh) {
         const int hp = (qh * 8 + wave) * 8 + lrow;
         const int hr = hp / 18, hc = hp - hr * 18;
         const int y = py0 - 1 + hr, x = px0 - 1 + hc;
         const bool ok = hp < 324 && y >= 0 && y < p.H && x >= 0 && x < p.W;
-        hal_pix[qh] = ok ? (pb * p.H + y) * p.W + x : -1;
-        hal_cb[qh] = (unsigned)((lchk ^ ((hc >> 1) & 7)) * 16);
+        hal_pk[qh] = ok ? ((((pb * p.H + y) * p.W + x) << 3) | (lchk ^ ((hc >> 1) & 7))) : -1;
     }
     auto dma_halo = [&](int qh, int chunk, int hb) {
         if (qh * 8 + wave >= C8_HINST) return;                 // wave-uniform
@@ -108,7 +125,8 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
         const bool second = ci0 >= p.c1;
         const unsigned cs2 = (unsigned)(second ? p.c2 : p.c1) * 2u;
         if (second) ci0 -= p.c1;
-        const unsigned off = hal_pix[qh] >= 0 ? (unsigned)hal_pix[qh] * cs2 + (unsigned)(ci0 * 2) + hal_cb[qh] : MDX_OOB;
+        const unsigned off = hal_pk[qh] >= 0 ? (unsigned)(hal_pk[qh] >> 3) * cs2 + (unsigned)(ci0 * 2) + (unsigned)((hal_pk[qh] & 7) << 4)
+                                             : MDX_OOB;
         void* dst = smem + hb * C8_HALO_BYTES + (qh * 8 + wave) * 1024;
         if (second)
             dma16(rs_a2, dst, off);
@@ -149,83 +167,70 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
         for (int kx = 0; kx < 3; ++kx) axor[kx][s] = ((s * 4 + q) ^ (((l15 + kx) >> 1) & 7)) << 4;
     }
 
-    // bias + this sample's time-embedding row: one value per column for the whole patch -- fetched before the K loop
-    // (epilogue thread -> 8 columns at n0 + (tid % CPR) * 8)
-    constexpr int CPR = BN / 8;               // 16-byte chunks per staged row
-    constexpr int RPP = C8_NT / CPR;          // rows per store pass (the last RPP * CPR .. 511 threads idle in the store loop)
-    const int e_chunk = tid % CPR, e_r0 = tid / CPR;
-    const int e_n = n0 + e_chunk * 8;
-    const bool e_act = e_r0 < RPP && e_n < p.N;
-    float bb[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bb[e] = 0.f;
-    if (e_act) {
-        if (p.bias) {
-            const float4* b4 = reinterpret_cast<const float4*>(p.bias + e_n);
-            const float4 x0 = b4[0], x1 = b4[1];
-            bb[0] = x0.x; bb[1] = x0.y; bb[2] = x0.z; bb[3] = x0.w; bb[4] = x1.x; bb[5] = x1.y; bb[6] = x1.z; bb[7] = x1.w;
-        }
-        if (p.rowbias) {
-            const float4* r4 = reinterpret_cast<const float4*>(p.rowbias + (size_t)pb * p.rowbias_ld + e_n);
-            const float4 x0 = r4[0], x1 = r4[1];
-            bb[0] += x0.x; bb[1] += x0.y; bb[2] += x0.z; bb[3] += x0.w; bb[4] += x1.x; bb[5] += x1.y; bb[6] += x1.z; bb[7] += x1.w;
-        }
-    }
+    const int nchunks_all = p.cin >> 6;
+    const int c_begin = nsplit > 1 ? split * p.c8_cps : 0;
+    const int c_end = nsplit > 1 ? min(nchunks_all, c_begin + p.c8_cps) : nchunks_all;
+    const int nt = c_end * 9;                // one past the last K tile of this block
 
-    const int nchunks = p.cin >> 6;
-    const int nt = nchunks * 9;
-
-    // ---- prologue: the first chunk's halo, the weights of taps 0 and 1
+    // ---- prologue: the first chunk's halo, the weights of its taps 0 and 1
 #pragma unroll
-    for (int qh = 0; qh < 6; ++qh) dma_halo(qh, 0, 0);
-    dma_b(0, 0);
-    dma_b(1, 1);
+    for (int qh = 0; qh < 6; ++qh) dma_halo(qh, c_begin, 0);
+    dma_b(c_begin * 9, 0);
+    dma_b(c_begin * 9 + 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wn == 1) __builtin_amdgcn_s_barrier();          // the N = 1 half runs one barrier (half a phase) behind
 
-    int t = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        const int hb = c & 1;
-        const bool more = c + 1 < nchunks;
+    int t = c_begin * 9;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int hb = (c - c_begin) & 1;
+        const bool more = c + 1 < c_end;
         const char* abase = smem + hb * C8_HALO_BYTES + a_lane;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap, ++t) {
             const int ky = tap / 3, kx = tap - ky * 3;
             const char* ap = abase + (ky * 18 + kx) * 128;
             const char* bp = smem + b_lane + (tap % 3) * B_BYTES;
-            f16x8 af[2][4], bf[2][NJ];
+            // PH = 2: one phase per tap (both 32-deep k-steps read before the barrier); PH = 1: one phase per k-step (half the
+            // fragment registers, twice the barriers).  The DMA batch of the tap is issued / waited for in its first phase.
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int sub = 0; sub < 2 / PH; ++sub) {
+                f16x8 af[PH][4], bf[PH][NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) bf[s][j] = *reinterpret_cast<const f16x8*>(bp + j * 2048 + bxor[s]);
+                for (int u = 0; u < PH; ++u) {
+                    const int s = sub * PH + u;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[s][i] = *reinterpret_cast<const f16x8*>(ap + i * (18 * 128) + axor[kx][s]);
+                    for (int j = 0; j < NJ; ++j) bf[u][j] = *reinterpret_cast<const f16x8*>(bp + j * 2048 + bxor[s]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[u][i] = *reinterpret_cast<const f16x8*>(ap + i * (18 * 128) + axor[kx][s]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (sub == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the batch issued one tap ago (this wave's share)
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (sub == 0) {
+                    if (t + 2 < nt) dma_b(t + 2, (tap + 2) % 3);
+                    if (more && tap < 6) dma_halo(tap, c + 1, hb ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int u = 0; u < PH; ++u)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[u][j], af[u][i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
             }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the batch issued one phase ago (this wave's share of it)
-            __builtin_amdgcn_s_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < nt) dma_b(t + 2, (tap + 2) % 3);
-            if (more && tap < 6) dma_halo(tap, c + 1, hb ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
         }
     }
     if (wn == 0) __builtin_amdgcn_s_barrier();          // both halves level again; every wave is done with the halos and the ring
 
-    if (p.skip_w) {
+    if (p.skip_w && split == nsplit - 1) {      // (block-uniform) the last split -- the one with the fewest chunks -- takes the skip tiles
         // ---- ResBlock skip_connection (openaimodel.py:174, 201-205): conv1x1 over the block's RAW input as extra dense K tiles
         // of the same accumulators.  A tiles = the patch's 256 pixels x 64 channels (32 KB, in the halo area), weight tiles in
         // the ring area; two stages, one barrier per tile, all waves in step.
@@ -291,6 +296,75 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
         }
     }
     __syncthreads();     // (nothing is in flight: plain barrier) the staging tile overwrites the halos / ring
+
+    if (nsplit > 1) {
+        // ---- tail split: park the fp32 accumulators in register layout ([tile][split][piece][thread] 16-byte pieces), take a
+        // ticket; the block that draws the last one sums all partials in split order (its own included: deterministic) and goes on
+        // to the epilogue.  Hand-off as in gemm.hip splitk_last_block_reduce (write-through stores, drained by every wave, one
+        // relaxed agent-scope ticket, sc1 loads on the reading side; no placement assumption).
+        const int tl = tile_id - p.c8_full;
+        char* base = reinterpret_cast<char*>(p.ws + C8_TICKET_SLOTS) + (size_t)tl * nsplit * PART;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, (unsigned)nsplit * PART);
+        const unsigned toff = (unsigned)tid * 16u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, acc[i][j]), rs,
+                                                       (unsigned)split * PART + (unsigned)(i * NJ + j) * (C8_NT * 16u) + toff, 0, /*sc1*/ 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.tickets + tl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old >= (unsigned)nsplit) __builtin_trap();
+            *flag = old == (unsigned)nsplit - 1u;
+        }
+        __syncthreads();
+        const bool last = *flag != 0;
+        __syncthreads();
+        if (!last) return;
+        if (tid == 0) __hip_atomic_store(p.tickets + tl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        constexpr int QH = Q / 2;            // two batches of loads per partial: Q / 2 x 4 registers in flight beside the accumulators
+        for (int z = 0; z < nsplit; ++z) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4v v[QH];
+#pragma unroll
+                for (int qq = 0; qq < QH; ++qq)
+                    v[qq] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)z * PART + (unsigned)(h * QH + qq) * (C8_NT * 16u) + toff, 0, 16);
+#pragma unroll
+                for (int qq = 0; qq < QH; ++qq) acc[(h * QH + qq) / NJ][(h * QH + qq) % NJ] += __builtin_bit_cast(f32x4v, v[qq]);
+            }
+        }
+    }
+
+    // bias + this sample's time-embedding row: one value per column for the whole patch (epilogue thread -> 8 columns at
+    // n0 + (tid % CPR) * 8); loaded here, used after the staging barrier
+    constexpr int CPR = BN / 8;               // 16-byte chunks per staged row
+    constexpr int RPP = C8_NT / CPR;          // rows per store pass (threads RPP * CPR .. 511 idle in the store loop)
+    const int e_chunk = tid % CPR, e_r0 = tid / CPR;
+    const int e_n = n0 + e_chunk * 8;
+    const bool e_act = e_r0 < RPP && e_n < p.N;
+    float bb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bb[e] = 0.f;
+    if (e_act) {
+        if (p.bias) {
+            const float4* b4 = reinterpret_cast<const float4*>(p.bias + e_n);
+            const float4 x0 = b4[0], x1 = b4[1];
+            bb[0] = x0.x; bb[1] = x0.y; bb[2] = x0.z; bb[3] = x0.w; bb[4] = x1.x; bb[5] = x1.y; bb[6] = x1.z; bb[7] = x1.w;
+        }
+        if (p.rowbias) {
+            const float4* r4 = reinterpret_cast<const float4*>(p.rowbias + (size_t)pb * p.rowbias_ld + e_n);
+            const float4 x0 = r4[0], x1 = r4[1];
+            bb[0] += x0.x; bb[1] += x0.y; bb[2] += x0.z; bb[3] += x0.w; bb[4] += x1.x; bb[5] += x1.y; bb[6] += x1.z; bb[7] += x1.w;
+        }
+    }
 
     // ---- epilogue.  C^T accumulators: lane (l15, q) of tile (i, j) holds pixel row 64 wm + 16 i + l15, channels
     // wn BN/2 + 16 j + 4 q .. + 3.
@@ -363,17 +437,17 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     }
 }
 
-template <int BN>
+template <int BN, int PH>
 void c8_launch(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t lds = c8_lds_bytes<BN>();
     static bool attr_set[64] = {};
     int dv = 0;
     (void)hipGetDevice(&dv);
     if (dv >= 0 && dv < 64 && !attr_set[dv]) {        // hipFuncSetAttribute is per device
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel<BN, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dv] = true;
     }
-    hipLaunchKernelGGL((conv8p_kernel<BN>), grid, dim3(C8_NT), lds, st, p);
+    hipLaunchKernelGGL((conv8p_kernel<BN, PH>), grid, dim3(C8_NT), lds, st, p);
 }
 
 }  // namespace
@@ -392,39 +466,109 @@ bool mdx_conv8p_eligible(const GemmParams& p) {
     return true;
 }
 
-// N tile: the widest of 160 / 192 / 128 that wastes no columns, else the one that wastes the fewest.
+// How many ways the tiles of a partly filled round are split: as many as still puts <= 256 blocks on the chip, at most 4 (the last
+// arriver reads every partial: ~3.5 us per 160 KB), no empty split, and nothing when the round is >= 3/4 full anyway.
+static int c8_tail_split(int rem, int chunks) {
+    if (rem == 0 || rem >= 192 || chunks < 2) return 1;
+    int s = 256 / rem;
+    if (s > 4) s = 4;
+    if (s > chunks) s = chunks;
+    while (s > 1 && (chunks + s - 1) / s * (s - 1) >= chunks) --s;      // every split owns >= 1 chunk
+    return s;
+}
+
+// Time model of a launch with N tile `bn`, microseconds (fitted to tools/conv8p_bench.py on MI355X, profiles/r04_conv8p_bench.txt):
+// a tap of a 256 x 160 tile costs 1.06 us with every CU busy; 128- and 192-column tiles run at the same rate per FLOP, 96- / 64-column
+// tiles at 0.88 / 0.72 of it (halo DMA and LDS reads amortised over fewer MFMAs); rounds of 256 tiles; the partly filled last round
+// is split along K and costs its share of the K loop plus 3.5 us per partial the last arriver reads.
+static double c8_time_us(const GemmParams& p, int bn) {
+    const int patches = p.B * (p.H >> 4) * (p.W >> 4);
+    const int tn = (p.N + bn - 1) / bn;
+    const long tiles = (long)patches * tn;
+    const int chunks = p.cin >> 6;
+    const int skip_kt = p.skip_w ? p.skip_kt : 0;
+    const double eff = bn >= 128 ? 1.0 : (bn == 96 ? 0.88 : 0.72);
+    const double tap = 1.06 * ((double)bn / 160.0) / eff;
+    const double epi = 3.0;
+    const double whole = (chunks * 9 + skip_kt) * tap + epi;
+    const long full = tiles / 256;
+    const int rem = (int)(tiles % 256);
+    double t = (double)full * whole;
+    if (rem) {
+        const int s = c8_tail_split(rem, chunks);
+        if (s == 1)
+            t += whole;
+        else
+            t += (((chunks + s - 1) / s) * 9 + skip_kt) * tap + epi + 3.5 * (s - 1) * ((double)bn / 160.0);
+    }
+    return t;
+}
+
 int mdx_conv8p_pick_bn(const GemmParams& p, int bn_hint) {
-    if (bn_hint == 128 || bn_hint == 160 || bn_hint == 192) return bn_hint;
-    static const int cand[3] = {160, 192, 128};
-    int best = 128;
-    double best_eff = 0.0;
+    if (bn_hint == 64 || bn_hint == 96 || bn_hint == 128 || bn_hint == 160 || bn_hint == 192) return bn_hint;
+    static const int cand[5] = {160, 192, 128, 96, 64};
+    int best = 160;
+    double best_t = 1e30;
     for (int bn : cand) {
-        const int tiles = (p.N + bn - 1) / bn;
-        const double eff = (double)p.N / ((double)tiles * bn);
-        if (eff > best_eff + 1e-9) {
-            best_eff = eff;
+        if (bn == 64 && p.N > 64) continue;
+        const double t = c8_time_us(p, bn);
+        if (t < best_t * 0.985) {        // later candidates must win clearly
+            best_t = t;
             best = bn;
         }
     }
     return best;
 }
 
-int mdx_conv8p_launch(GemmParams& p, int bn, hipStream_t st) {
+// Tiles the launch would have with its best N tile (the automatic route wants >= 128: below that even a 4-way tail split leaves
+// CUs idle and the 128-row tiles with their own split-K win -- measured at UNet batch 2).
+int mdx_conv8p_tiles(const GemmParams& p) {
+    int bn = mdx_conv8p_pick_bn(p, 0);
+    if (bn < 128) bn = 128;       // counted in tiles of at least 128 columns: 128 narrow tiles are half the work of 128 wide ones
+    return p.B * (p.H >> 4) * (p.W >> 4) * ((p.N + bn - 1) / bn);
+}
+
+size_t mdx_conv8p_plan(GemmParams& p, int bn, size_t workspace_bytes, bool have_workspace, bool query_only) {
     p.tiles_m = p.B * (p.H >> 4) * (p.W >> 4);
     p.tiles_n = (p.N + bn - 1) / bn;
     const int ntiles = p.tiles_m * p.tiles_n;
-    p.tiles_per_xcd = (ntiles + 7) / 8;
     p.nsplit = 1;
-    const dim3 grid(8 * p.tiles_per_xcd);
-    if (bn == 160)
-        c8_launch<160>(p, grid, st);
-    else if (bn == 192)
-        c8_launch<192>(p, grid, st);
-    else if (bn == 128)
-        c8_launch<128>(p, grid, st);
-    else {
-        mdx_set_error("mdx_gemm_f16: conv8p has no %d-column tile", bn);
-        return MDX_E_INVALID;
+    p.c8_full = ntiles;
+    p.c8_rem = 0;
+    p.c8_split = 1;
+    p.c8_cps = p.cin >> 6;
+    p.tiles_per_xcd = (ntiles + 7) / 8;
+    const int chunks = p.cin >> 6;
+    const int rem = ntiles % 256;
+    int s = c8_tail_split(rem, chunks);
+    const size_t part = (size_t)(4 * (bn / 32)) * C8_NT * 16;
+    const size_t need = s > 1 ? (size_t)MDX_GEMM_WS_HEAD + (size_t)rem * s * part : 0;
+    if (s > 1 && !query_only && (!have_workspace || workspace_bytes < need)) s = 1;      // no room for the partials: run the tail unsplit
+    if (s == 1) {
+        if (ntiles % 8) {                 // the XCD-contiguous order of the whole tiles wants a multiple of 8: the odd tiles go to the tail, unsplit
+            p.c8_full = ntiles & ~7;
+            p.c8_rem = ntiles - p.c8_full;
+        }
+        return 0;
+    }
+    p.c8_full = ntiles - rem;
+    p.c8_rem = rem;
+    p.c8_split = s;
+    p.c8_cps = (chunks + s - 1) / s;
+    return need;
+}
+
+int mdx_conv8p_launch(const GemmParams& p, int bn, hipStream_t st) {
+    const dim3 grid(p.c8_full + ((p.c8_rem + 7) / 8) * 8 * p.c8_split);
+    switch (bn) {
+        case 64: c8_launch<64, 2>(p, grid, st); break;
+        case 96: c8_launch<96, 2>(p, grid, st); break;
+        case 128: c8_launch<128, 2>(p, grid, st); break;
+        case 160: if (p.st_hint == 9) c8_launch<160, 1>(p, grid, st); else c8_launch<160, 2>(p, grid, st); break;
+        case 192: c8_launch<192, 1>(p, grid, st); break;      // 96 accumulator + 80 fragment registers do not fit two waves per SIMD
+        default:
+            mdx_set_error("mdx_gemm_f16: conv8p has no %d-column tile", bn);
+            return MDX_E_INVALID;
     }
     return MDX_OK;
 }

@@ -1772,7 +1772,7 @@ static size_t split_bytes(const mdx_gemm_desc* d, const GemmParams& p, int bm, i
 extern "C" size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d) {
     GemmParams p{};
     if (fill_params(d, p) != MDX_OK) return 0;
-    if (conv8p_wanted(d, p)) return 0;
+    if (conv8p_wanted(d, p)) return mdx_conv8p_plan(p, mdx_conv8p_pick_bn(p, d->tile_n), 0, false, true);
     const GemmCfg c = pick_cfg(p);
     const Tiling tl = choose_tiling(p, c.bn, d->splitk, d->tile_m);
     if (tl.ns <= 1) return 0;
@@ -1884,16 +1884,17 @@ extern "C" int mdx_gemm_release_counters(void) {
 }
 
 // The eight-wave 256-pixel conv core takes a launch when the descriptor forces it (tile_m = 256 with stages = 8) or, by default,
-// when the shape is eligible and has at least gemm_conv8p_min_m output pixels (UNet batch >= 8 at the two largest levels): below
-// that a 256 x 160 tile grid cannot fill 256 CUs and the 128-row HALO tiles with split-K win.
+// when the shape is eligible, has at least gemm_conv8p_min_m output pixels and at least 128 tiles (UNet batch >= 8 down to the
+// 16 x 16 level): below that even a 4-way tail split cannot fill 256 CUs and the 128-row HALO tiles with their own split-K win
+// (tools/conv8p_bench.py at UNet batch 2: 462 vs 603 TF/s).
 static bool conv8p_wanted(const mdx_gemm_desc* d, const GemmParams& p) {
     if (!mdx_opt(MDX_OPT_GEMM_CONV8P) || d->w_frag || d->defer_reduce || d->splitk > 1 || d->asym_pad) return false;
     if (mdx_opt(MDX_OPT_GEMM_BM) || !mdx_opt(MDX_OPT_GEMM_HALO)) return false;
     if (!mdx_conv8p_eligible(p)) return false;
-    if (d->tile_m == 256 && d->stages == 8) return true;
+    if (d->tile_m == 256 && (d->stages == 8 || d->stages == 9)) return true;      // 9: one phase per 32-deep k-step (A/B form)
     if (d->tile_m != 0 || d->stages != 0) return false;
-    if (d->tile_n != 0 && d->tile_n != 128 && d->tile_n != 160 && d->tile_n != 192) return false;
-    return p.M >= mdx_opt(MDX_OPT_GEMM_CONV8P_MIN_M);
+    if (d->tile_n != 0 && d->tile_n != 64 && d->tile_n != 96 && d->tile_n != 128 && d->tile_n != 160 && d->tile_n != 192) return false;
+    return p.M >= mdx_opt(MDX_OPT_GEMM_CONV8P_MIN_M) && mdx_conv8p_tiles(p) >= 128;
 }
 
 static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
@@ -1909,10 +1910,10 @@ static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
         r.c8 = true;
         p.bk = 64;
         p.ktiles = (p.K + 63) / 64;
-        p.nsplit = 1;
         p.ktiles_per_split = p.ktiles;
         p.skip_kt_per_split = p.skip_w ? p.skip_kt : 0;
         p.tickets = nullptr;
+        (void)mdx_conv8p_plan(p, r.bn, d->workspace_bytes, d->workspace != nullptr, false);
         return MDX_OK;
     }
     r.c = pick_cfg(p);
@@ -2047,6 +2048,11 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
                     (p.M + rows - 1) / rows, rows);
     }
     if (rs.c8) {
+        if (p.c8_split > 1) {       // tail tiles split along K: partials in the workspace, library-owned arrival counters
+            MDX_REQUIRE((uintptr_t)p.ws % 16 == 0, "mdx_gemm_f16: workspace must be 16-byte aligned");
+            const int trc = ticket_slot(d->workspace, &p.tickets);
+            if (trc != MDX_OK) return trc;
+        }
         rc = mdx_conv8p_launch(p, bn, st);
         if (rc != MDX_OK) return rc;
         MDX_LAUNCH_CHECK("mdx_gemm_f16(conv8p)");

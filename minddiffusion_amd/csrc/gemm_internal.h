@@ -52,6 +52,9 @@ struct GemmParams {
     const f16* skip_w;
     int skip_c1, skip_c2, skip_kt, skip_kt_per_split;
     unsigned skip_a_bytes, skip_a2_bytes, skip_w_bytes;
+    // conv8p (conv8p.hip): the first c8_full tiles run whole, each of the remaining c8_rem tiles is split c8_split ways along the
+    // 64-channel chunks (c8_cps chunks per split) so that the last, partly filled round of 256-CU work still covers the chip
+    int c8_full, c8_rem, c8_split, c8_cps;
 };
 
 }  // namespace mdx_int
@@ -60,7 +63,12 @@ using mdx_int::GemmParams;
 // 8-phase 256-pixel conv core (conv8p.hip): eligibility + launch, called from mdx_gemm_f16 / mdx_gemm_query (gemm.hip)
 bool mdx_conv8p_eligible(const GemmParams& p);
 int mdx_conv8p_pick_bn(const GemmParams& p, int bn_hint);
-int mdx_conv8p_launch(GemmParams& p, int bn, hipStream_t st);
+int mdx_conv8p_tiles(const GemmParams& p);
+// plans the tile / tail-split geometry into p (c8_*, tiles_m, tiles_n) given the caller's workspace; returns the workspace bytes
+// the planned launch needs (0 = none).  query_only: the ideal plan (sizing); otherwise a missing / too small workspace makes the
+// plan fall back to unsplit tiles.
+size_t mdx_conv8p_plan(GemmParams& p, int bn, size_t workspace_bytes, bool have_workspace, bool query_only);
+int mdx_conv8p_launch(const GemmParams& p, int bn, hipStream_t st);
 
 namespace {
 

@@ -65,7 +65,7 @@ enum MdxOpt {
     MDX_OPT_GN_FUSED,            // 1: small tensors use the one-launch GroupNorm
     MDX_OPT_GN_COL_CHUNKS,       // column-statistics GroupNorm: a column block spans at least this many 16-byte chunks of a pixel row (4)
     MDX_OPT_GEMM_CONV8P,         // 1: eligible 3x3 convs with M >= gemm_conv8p_min_m run on the 256-pixel 8-wave core (conv8p.hip)
-    MDX_OPT_GEMM_CONV8P_MIN_M,   // smallest M the 8-wave conv core is chosen for automatically (8192)
+    MDX_OPT_GEMM_CONV8P_MIN_M,   // smallest M the 8-wave conv core is chosen for automatically (4096; it also needs >= 128 tiles)
     MDX_OPT_COUNT
 };
 int mdx_opt(int id);

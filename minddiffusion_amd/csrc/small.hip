@@ -20,7 +20,7 @@ extern "C" const char* mdx_last_error(void) { return g_err; }
 static const char* const g_opt_names[MDX_OPT_COUNT] = {"gemm_tuned", "gemm_bm", "gemm_bn", "gemm_ring", "gemm_halo", "gemm_halo8",
                                                         "gemm_splitk_fixup_max", "gemm_spread", "halo_nsb", "gn_min_blocks",
                                                         "gn_fused", "gn_col_chunks", "gemm_conv8p", "gemm_conv8p_min_m"};
-static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1, 4, 1, 8192};
+static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1, 4, 1, 4096};
 
 int mdx_opt(int id) { return g_opt[id]; }
 

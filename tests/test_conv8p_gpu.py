@@ -75,6 +75,8 @@ def test_mfma_16x16x32_layout(ops):
     (1, 48, 48, 320, 320, 160),     # the 768-pixel level-1 geometry (3 x 3 patches), five chunks
     (2, 16, 32, 64, 640, 128),      # forced 128-column tiles, five N tiles
     (1, 64, 64, 64, 64, 0),         # 16 patches: interior + all borders; N = 64 (half an N tile)
+    (1, 16, 32, 128, 192, 96),      # 96-column tiles
+    (2, 16, 16, 64, 136, 64),       # 64-column tiles, N tail
 ])
 def test_conv8p_vs_oracle(ops, B, H, W, Cin, Cout, tile_n):
     rng = np.random.RandomState(Cin + Cout + H + W)
@@ -86,7 +88,7 @@ def test_conv8p_vs_oracle(ops, B, H, W, Cin, Cout, tile_n):
     out = torch.full((B * H * W, Cout), float("nan"), dtype=torch.float16, device=DEV)
     d = ops.make_gemm_desc(xd, wp, Cout, B, H, W, Cin, out, Cout, bias=bd, ksize=3, tile_m=256, stages=8, tile_n=tile_n)
     q = ops.gemm_query(d)
-    assert q[0] == 256 and q[2] == 1 and q[3] == 1 and q[5] == 256 and q[1] in (128, 160, 192), q
+    assert q[0] == 256 and q[2] == 1 and q[3] == 1 and q[5] == 256 and q[1] in (64, 96, 128, 160, 192), q
     ops.gemm_run(d)
     torch.cuda.synchronize()
     check(f"conv8p_B{B}_{H}x{W}_{Cin}to{Cout}_bn{q[1]}", from_nhwc(out.float().cpu().numpy(), B, H, W), ref, rel_l2=1e-3)
@@ -177,3 +179,63 @@ def test_conv8p_benchmarked_shapes_race_screen(ops, B, H, Cin, Cout):
         assert torch.equal(outs[i], firsts[i]), f"launch {rep}: output changed"
     old = ops.gemm(x, ws[0], Cout, B, H, H, Cin, bias=bd, ksize=3, tile_m=128)
     check(f"conv8p_default_route_vs_halo128_B{B}_{H}x{H}_{Cin}to{Cout}", firsts[0], old, rel_l2=5e-4)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,tile_n,skip", [
+    (9, 48, 48, 320, 320, 0, 0),       # 81 patches x 2 N tiles = 162 tiles: all of them in the tail, split 1 way (162 > 128) .. see plan
+    (2, 64, 64, 320, 320, 160, 0),     # 32 x 2 = 64 tiles: no whole round, every tile split 4 ways (5 chunks -> 2 + 2 + 1 ... 3 splits)
+    (8, 48, 48, 640, 640, 160, 0),     # 72 x 4 = 288 tiles (BASELINE config 3, level 1): 256 whole + 32 split 4 ways
+    (8, 48, 48, 640, 640, 160, 320),   # ... with the fused skip tiles riding on the last split
+    (1, 16, 16, 512, 160, 160, 0),     # ONE tile split 4 ways (8 chunks)
+    (3, 16, 16, 128, 160, 160, 64),    # 3 tiles x 2 splits of one chunk each + skip
+])
+def test_conv8p_tail_split(ops, B, H, W, Cin, Cout, tile_n, skip):
+    """Tile counts that do not fill whole rounds of 256 CUs: the tiles of the last round are split along the 64-channel chunks and
+    reduced by the last-arriving block (fp32 partials in the workspace, library-owned tickets).  Against the 128-row HALO kernel
+    and, run twice more on a NaN-poisoned workspace, bit-stable."""
+    rng = np.random.RandomState(B + H + Cin + skip)
+    x = dev16(h16(rng.standard_normal((B, H * W, Cin))))
+    w = pack_conv(h16(rng.standard_normal((Cout, Cin, 3, 3)) / math.sqrt(9 * Cin)))
+    bd = dev32(rng.standard_normal(Cout).astype(np.float32))
+    kw = {}
+    if skip:
+        xs = dev16(h16(rng.standard_normal((B, H * W, skip))))
+        wsk = pack_conv(h16(rng.standard_normal((Cout, skip, 1, 1)) / math.sqrt(skip)))
+        kw = dict(skip_a=xs, skip_c1=skip, skip_w=wsk)
+    nrb = B * (H // 16) * (W // 16)
+    cs = torch.zeros((nrb, Cout, 2), dtype=torch.float32, device=DEV)
+    out = torch.full((B * H * W, Cout), float("nan"), dtype=torch.float16, device=DEV)
+    d = ops.make_gemm_desc(x, w, Cout, B, H, W, Cin, out, Cout, bias=bd, ksize=3, tile_m=256, stages=8, tile_n=tile_n,
+                           colstats_out=cs, **kw)
+    need = ops.gemm_workspace_bytes(d)
+    ws = ops.new_gemm_workspace(max(need, 1 << 16), DEV)
+    ws.fill_(float("nan"))
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    assert ops.gemm_query(d)[0] == 256
+    ops.gemm_run(d)
+    torch.cuda.synchronize()
+    first, cs_first = out.clone(), cs.clone()
+    ops.set_option("gemm_conv8p", 0)
+    try:
+        old = ops.gemm(x, w, Cout, B, H, W, Cin, bias=bd, ksize=3, **kw)
+    finally:
+        ops.set_option("gemm_conv8p", 1)
+    check(f"conv8p_tail_split_B{B}_{H}x{W}_{Cin}to{Cout}_skip{skip}_need{need >> 10}K", first, old, rel_l2=5e-4)
+    o = first.float().reshape(B, H // 16, 16, W // 16, 16, Cout).permute(0, 1, 3, 2, 4, 5).reshape(nrb, 256, Cout)
+    check(f"conv8p_tail_split_colstats_B{B}_{Cin}", cs_first[:, :, 0], o.sum(1), rel_l2=1e-5)
+    for _ in range(3):
+        ws.fill_(float("nan"))
+        out.fill_(float("nan"))
+        ops.gemm_run(d)
+        assert torch.equal(out, first) and torch.equal(cs, cs_first)
+
+
+def test_conv8p_phase_per_kstep_form_is_bit_identical(ops):
+    """stages = 9: one phase per 32-deep k-step (the form the 192-column tile always uses) -- same products in the same order."""
+    rng = np.random.RandomState(3)
+    B, H, W, Cin, Cout = 2, 32, 32, 192, 320
+    x = dev16(h16(rng.standard_normal((B, H * W, Cin))))
+    w = pack_conv(h16(rng.standard_normal((Cout, Cin, 3, 3)) / math.sqrt(9 * Cin)))
+    a = ops.gemm(x, w, Cout, B, H, W, Cin, ksize=3, tile_m=256, stages=8, tile_n=160)
+    b = ops.gemm(x, w, Cout, B, H, W, Cin, ksize=3, tile_m=256, stages=9, tile_n=160)
+    assert torch.equal(a, b)

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--out", default=None)
     ap.add_argument("--bns", default="0", help="comma list of conv8p N tiles to try (0 = the library's pick)")
+    ap.add_argument("--extra", default="", help="comma list of stages:tile_n forms (stages 9 = one phase per k-step)")
     args = ap.parse_args()
     from minddiffusion_amd import ops
     dev = torch.device("cuda:0")
@@ -67,11 +68,16 @@ def main():
         forms = {"old": dict(), }
         for bn in [int(x) for x in args.bns.split(",")]:
             forms[f"c8_bn{bn}"] = dict(tile_m=256, stages=8, tile_n=bn)
+        for x in [x for x in args.extra.split(",") if x]:       # e.g. "9:160" = one phase per k-step at BN 160
+            st, bn = x.split(":")
+            forms[f"c8_st{st}_bn{bn}"] = dict(tile_m=256, stages=int(st), tile_n=int(bn))
         timings = {k: [] for k in forms}
         descs = {}
         wsp = None
-        ops.set_option("gemm_conv8p", 0)
+        def route(k):       # the "old" arm is the library's choice with the eight-wave core switched off
+            ops.set_option("gemm_conv8p", 0 if k == "old" else 1)
         for k, kw in forms.items():
+            route(k)
             descs[k] = [ops.make_gemm_desc(a, w, cout, B, H, W, cin, out, cout, bias=bias, ksize=3, rowbias=emb, rowbias_ld=cout,
                                            colstats_out=cst, **skw, **kw) for w in ws]
             need = ops.gemm_workspace_bytes(descs[k][0])
@@ -82,12 +88,15 @@ def main():
                 if wsp is not None:
                     d.workspace, d.workspace_bytes = wsp.data_ptr(), wsp.numel() * 4
         try:
-            qs = {k: ops.gemm_query(descs[k][0]) for k in forms}
+            qs = {}
             for k in forms:
+                route(k)
+                qs[k] = ops.gemm_query(descs[k][0])
                 ops.gemm_run(descs[k][0])
             torch.cuda.synchronize()
             for r in range(args.rounds):
                 for k in forms:
+                    route(k)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for i in range(args.iters):
