@@ -200,7 +200,16 @@ typedef struct mdx_gemm_desc {
                              resolve to the HALO kernel only; set tile_m = 128.  Results are bit-identical to the tile-major form. */
     int stages;           /* 0 = auto; 2 .. 6 forces the depth of the LDS ring the K tiles are DMA'd through (same purpose; 64-row
                              tiles up to 6, 128-row tiles up to 5, HALO weight ring 2 | 3); 10 | 11 = depth 2 | 3 with EIGHT
-                             waves per block (generic kernel, tile_m = 128 only) */
+                             waves per block (generic kernel, tile_m = 128 only); 8 | 9 with tile_m = 256 = the eight-wave cores
+                             (conv8p.hip / gemm8p.hip; 9: one phase per 32-deep k-step) */
+    const void* w_sub;    /* upsample = 1 only, optional: the SUB-PIXEL weights of the nearest-2x + 3x3 conv (openaimodel.py:57-60).
+                             For output parity (dy, dx) the conv is a 2 x 2 conv of the low-resolution source with pre-summed taps --
+                             rows {y-1+dy, y+dy}: dy = 0 -> {w[0], w[1]+w[2]}, dy = 1 -> {w[0]+w[1], w[2]}; columns likewise -- packed like
+                             a conv weight of logical shape [4 N][Cin][2][2], parity-major rows (ops.pack_subpixel_conv_weight).  When set
+                             and the shape suits the eight-wave conv core (Cin % 64 == 0, N % 64 == 0, H % 16 == 0, W % 16 == 0, single
+                             source) the launch computes 4 Cin instead of 9 Cin products per output on the un-upsampled tensor; otherwise
+                             `w` and the upsampling gather are used.  The summed taps are rounded to fp16 once: results differ from the
+                             nine-product form by fp16 rounding of the weights (parity-tested against the oracle at the usual 1e-3). */
 } mdx_gemm_desc;
 
 #define MDX_GEMM_WS_HEAD 16384 /* reserved bytes at the head of mdx_gemm_desc.workspace (the arrival counters' former home; their size) */

@@ -37,7 +37,7 @@ class GemmDesc(ctypes.Structure):
         ("gn_colstats", c_void_p), ("gn_gamma", c_void_p), ("gn_beta", c_void_p), ("gn_nrb", c_int), ("gn_silu", c_int),
         ("gn_eps", c_float),
         ("skip_a", c_void_p), ("skip_a2", c_void_p), ("skip_c1", c_int), ("skip_c2", c_int), ("skip_w", c_void_p),
-        ("w_frag", c_int), ("stages", c_int),
+        ("w_frag", c_int), ("stages", c_int), ("w_sub", c_void_p),
     ]
 
 
@@ -134,6 +134,8 @@ _ENV_OPTIONS = {
     "MDX_GEMM_SPREAD": ("gemm_spread", int), "MDX_HALO_NSB": ("halo_nsb", int), "MDX_GN_MIN_BLOCKS": ("gn_min_blocks", int),
     "MDX_GN_FUSED": ("gn_fused", int), "MDX_GN_COL_CHUNKS": ("gn_col_chunks", int),
     "MDX_GEMM_CONV8P": ("gemm_conv8p", int), "MDX_GEMM_CONV8P_MIN_M": ("gemm_conv8p_min_m", int),
+    "MDX_GEMM_DENSE8P": ("gemm_dense8p", int), "MDX_GEMM_DENSE8P_MIN_M": ("gemm_dense8p_min_m", int),
+    "MDX_GEMM_SUBPIXEL_MIN_TILES": ("gemm_subpixel_min_tiles", int),
 }
 
 

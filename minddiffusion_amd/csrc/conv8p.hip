@@ -57,7 +57,12 @@ constexpr size_t c8_lds_bytes() {
     return main_loop > epi ? main_loop : epi;
 }
 
-template <int BN, int PH>
+// TAPS = 9: the 3x3 conv.  TAPS = 4: the SUB-PIXEL form of Upsample's nearest-2x + 3x3 conv (openaimodel.py:57-60): for each of the
+// four output parities (dy, dx) the conv is a 2 x 2 conv of the LOW-resolution tensor with pre-summed taps (ops.pack_subpixel_conv_weight):
+// rows {y - 1 + dy, y + dy}, columns {x - 1 + dx, x + dx} -- 4 Cin instead of 9 Cin multiply-adds per output and a gather on the
+// un-upsampled tensor.  An M tile is (low-resolution 16 x 16 patch, parity): the same halo, taps (dy + a, dx + b), weight rows
+// parity * N + n, and an epilogue row map that interleaves the parities into the 2H x 2W output (pixel shuffle).
+template <int BN, int PH, int TAPS>
 __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     constexpr int NJ = BN / 32;              // 16-column MFMA tiles per wave (a wave owns BN / 2 columns)
     constexpr int B_BYTES = BN * 128;
@@ -99,8 +104,10 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     const int tile_m = tile_id - tile_n * p.tiles_m;
     const int n0 = tile_n * BN;
     const int pw = p.W >> 4, ph = p.H >> 4;
-    const int pb = tile_m / (ph * pw);
-    const int prem = tile_m - pb * (ph * pw);
+    const int patch = TAPS == 4 ? tile_m >> 2 : tile_m;
+    const int par_dy = TAPS == 4 ? (tile_m >> 1) & 1 : 0, par_dx = TAPS == 4 ? tile_m & 1 : 0;
+    const int pb = patch / (ph * pw);
+    const int prem = patch - pb * (ph * pw);
     const int py0 = (prem / pw) * 16, px0 = (prem - (prem / pw) * pw) * 16;
 
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a, p.a_bytes);
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     unsigned b_off[BJ];
 #pragma unroll
     for (int jb = 0; jb < BJ; ++jb) {
-        const int n = n0 + (jb * 8 + wave) * 8 + lrow;
+        const int n = (TAPS == 4 ? (par_dy * 2 + par_dx) * p.N : 0) + n0 + (jb * 8 + wave) * 8 + lrow;
         b_off[jb] = (unsigned)(((size_t)(n >> 6) * p.kt64) * 8192 + ((n & 63) * 8 + lchk) * 16);
     }
     auto dma_b = [&](int kt, int stage) {
@@ -164,33 +171,38 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     for (int s = 0; s < 2; ++s) {
         bxor[s] = ((s * 4 + q) ^ ((l15 >> 1) & 7)) << 4;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) axor[kx][s] = ((s * 4 + q) ^ (((l15 + kx) >> 1) & 7)) << 4;
+        for (int kx = 0; kx < 3; ++kx) axor[kx][s] = ((s * 4 + q) ^ (((l15 + kx + (TAPS == 4 ? par_dx : 0)) >> 1) & 7)) << 4;
     }
+    // (TAPS = 4: axor[b][s] is keyed on the halo column offset dx + b, b = 0 | 1; entry [2] is unused)
 
     const int nchunks_all = p.cin >> 6;
     const int c_begin = nsplit > 1 ? split * p.c8_cps : 0;
     const int c_end = nsplit > 1 ? min(nchunks_all, c_begin + p.c8_cps) : nchunks_all;
-    const int nt = c_end * 9;                // one past the last K tile of this block
+    const int nt = c_end * TAPS;             // one past the last K tile of this block
 
     // ---- prologue: the first chunk's halo, the weights of its taps 0 and 1
 #pragma unroll
     for (int qh = 0; qh < 6; ++qh) dma_halo(qh, c_begin, 0);
-    dma_b(c_begin * 9, 0);
-    dma_b(c_begin * 9 + 1, 1);
+    dma_b(c_begin * TAPS, 0);
+    dma_b(c_begin * TAPS + 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wn == 1) __builtin_amdgcn_s_barrier();          // the N = 1 half runs one barrier (half a phase) behind
 
-    int t = c_begin * 9;
+    int t = c_begin * TAPS;
+    int rd = 0;                              // ring stage of K tile t (TAPS = 9: tap % 3, static; TAPS = 4: rotates across chunks)
+    const int par_off = (par_dy * 18 + par_dx) * 128;
     for (int c = c_begin; c < c_end; ++c) {
         const int hb = (c - c_begin) & 1;
         const bool more = c + 1 < c_end;
-        const char* abase = smem + hb * C8_HALO_BYTES + a_lane;
+        const char* abase = smem + hb * C8_HALO_BYTES + a_lane + (TAPS == 4 ? par_off : 0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap, ++t) {
-            const int ky = tap / 3, kx = tap - ky * 3;
+        for (int tap = 0; tap < TAPS; ++tap, ++t) {
+            const int ky = TAPS == 9 ? tap / 3 : tap >> 1, kx = TAPS == 9 ? tap - ky * 3 : tap & 1;
             const char* ap = abase + (ky * 18 + kx) * 128;
-            const char* bp = smem + b_lane + (tap % 3) * B_BYTES;
+            const int st_r = TAPS == 9 ? tap % 3 : rd;
+            const int st_w = TAPS == 9 ? (tap + 2) % 3 : (rd == 0 ? 2 : rd - 1);
+            const char* bp = smem + b_lane + st_r * B_BYTES;
             // PH = 2: one phase per tap (both 32-deep k-steps read before the barrier); PH = 1: one phase per k-step (half the
             // fragment registers, twice the barriers).  The DMA batch of the tap is issued / waited for in its first phase.
 #pragma unroll
@@ -210,8 +222,15 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 if (sub == 0) {
-                    if (t + 2 < nt) dma_b(t + 2, (tap + 2) % 3);
-                    if (more && tap < 6) dma_halo(tap, c + 1, hb ^ 1);
+                    if (t + 2 < nt) dma_b(t + 2, st_w);
+                    if constexpr (TAPS == 9) {
+                        if (more && tap < 6) dma_halo(tap, c + 1, hb ^ 1);
+                    } else {
+                        if (more && tap < 3) {      // six halo slices per wave over the first three of the four taps
+                            dma_halo(2 * tap, c + 1, hb ^ 1);
+                            dma_halo(2 * tap + 1, c + 1, hb ^ 1);
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_s_setprio(1);
@@ -226,11 +245,12 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
             }
+            if constexpr (TAPS != 9) rd = rd == 2 ? 0 : rd + 1;
         }
     }
     if (wn == 0) __builtin_amdgcn_s_barrier();          // both halves level again; every wave is done with the halos and the ring
 
-    if (p.skip_w && split == nsplit - 1) {      // (block-uniform) the last split -- the one with the fewest chunks -- takes the skip tiles
+    if (TAPS == 9 && p.skip_w && split == nsplit - 1) {      // (block-uniform) the last split -- the one with the fewest chunks -- takes the skip tiles
         // ---- ResBlock skip_connection (openaimodel.py:174, 201-205): conv1x1 over the block's RAW input as extra dense K tiles
         // of the same accumulators.  A tiles = the patch's 256 pixels x 64 channels (32 KB, in the halo area), weight tiles in
         // the ring area; two stages, one barrier per tile, all waves in step.
@@ -383,21 +403,25 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     float cs[8], cq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
-    const int mbase = (pb * p.H + py0) * p.W + px0;
+    // output row of patch pixel (py, px): plain = the pixel itself; sub-pixel = pixel (2 (py0 + py) + dy, 2 (px0 + px) + dx) of the 2H x 2W image
+    const int rw = TAPS == 4 ? 2 * p.W : p.W;                  // output row pitch in pixels
+    const int rsx = TAPS == 4 ? 2 : 1;                         // pixel step along x
+    const int mbase = TAPS == 4 ? (pb * 2 * p.H + 2 * py0 + par_dy) * rw + 2 * px0 + par_dx : (pb * p.H + py0) * p.W + px0;
+    const int rsy = TAPS == 4 ? 2 * rw : rw;                   // pixel step along y
     constexpr int NPASS = (256 + RPP - 1) / RPP;
     if (e_act) {
         f16x8 res_n = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
         if (p.residual && e_r0 < 256)
-            res_n = *reinterpret_cast<const f16x8*>(p.residual + (size_t)(mbase + (e_r0 >> 4) * p.W + (e_r0 & 15)) * p.residual_ld + e_n);
+            res_n = *reinterpret_cast<const f16x8*>(p.residual + (size_t)(mbase + (e_r0 >> 4) * rsy + (e_r0 & 15) * rsx) * p.residual_ld + e_n);
 #pragma unroll 4
         for (int pass = 0; pass < NPASS; ++pass) {
             const int row = e_r0 + pass * RPP;
             if (row >= 256) break;
-            const int m = mbase + (row >> 4) * p.W + (row & 15);
+            const int m = mbase + (row >> 4) * rsy + (row & 15) * rsx;
             const f16x8 res = res_n;
             const int row2 = row + RPP;
             if (p.residual && row2 < 256)
-                res_n = *reinterpret_cast<const f16x8*>(p.residual + (size_t)(mbase + (row2 >> 4) * p.W + (row2 & 15)) * p.residual_ld + e_n);
+                res_n = *reinterpret_cast<const f16x8*>(p.residual + (size_t)(mbase + (row2 >> 4) * rsy + (row2 & 15) * rsx) * p.residual_ld + e_n);
             const f16x8 v = *reinterpret_cast<const f16x8*>(&stg[row * SLD + e_chunk * 8]);
             f16x8 o;
 #pragma unroll
@@ -437,17 +461,17 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     }
 }
 
-template <int BN, int PH>
+template <int BN, int PH, int TAPS = 9>
 void c8_launch(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t lds = c8_lds_bytes<BN>();
     static bool attr_set[64] = {};
     int dv = 0;
     (void)hipGetDevice(&dv);
     if (dv >= 0 && dv < 64 && !attr_set[dv]) {        // hipFuncSetAttribute is per device
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel<BN, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel<BN, PH, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[dv] = true;
     }
-    hipLaunchKernelGGL((conv8p_kernel<BN, PH>), grid, dim3(C8_NT), lds, st, p);
+    hipLaunchKernelGGL((conv8p_kernel<BN, PH, TAPS>), grid, dim3(C8_NT), lds, st, p);
 }
 
 }  // namespace
@@ -456,7 +480,8 @@ void c8_launch(const GemmParams& p, dim3 grid, hipStream_t st) {
 // source too), images tiling into 16 x 16 patches, plain row-major output (bias / time-embedding row / residual / column statistics /
 // fused skip 1x1), tile-major weights.
 bool mdx_conv8p_eligible(const GemmParams& p) {
-    if (!(p.ksize == 3 && p.stride == 1 && !p.upsample && p.pad == 1)) return false;
+    if (!(p.ksize == 3 && p.stride == 1 && p.pad == 1)) return false;
+    if (p.upsample && (!p.w_sub || p.c2 > 0 || p.skip_w || p.N % 64 != 0)) return false;      // nearest-2x + conv: the sub-pixel form only
     if (p.cin % 64 != 0 || (p.c2 > 0 && p.c1 % 64 != 0) || p.cin < 64) return false;
     if (p.H % 16 != 0 || p.W % 16 != 0) return false;
     if (p.out_mode != MDX_OUT_ROWMAJOR || p.epilogue != MDX_EPI_NONE || p.n_split || p.ln_stats || p.stats_out || p.out_bs ||
@@ -482,7 +507,8 @@ static int c8_tail_split(int rem, int chunks) {
 // tiles at 0.88 / 0.72 of it (halo DMA and LDS reads amortised over fewer MFMAs); rounds of 256 tiles; the partly filled last round
 // is split along K and costs its share of the K loop plus 3.5 us per partial the last arriver reads.
 static double c8_time_us(const GemmParams& p, int bn) {
-    const int patches = p.B * (p.H >> 4) * (p.W >> 4);
+    const int taps = p.upsample ? 4 : 9;
+    const int patches = p.B * (p.H >> 4) * (p.W >> 4) * (p.upsample ? 4 : 1);
     const int tn = (p.N + bn - 1) / bn;
     const long tiles = (long)patches * tn;
     const int chunks = p.cin >> 6;
@@ -490,7 +516,7 @@ static double c8_time_us(const GemmParams& p, int bn) {
     const double eff = bn >= 128 ? 1.0 : (bn == 96 ? 0.88 : 0.72);
     const double tap = 1.06 * ((double)bn / 160.0) / eff;
     const double epi = 3.0;
-    const double whole = (chunks * 9 + skip_kt) * tap + epi;
+    const double whole = (chunks * taps + skip_kt) * tap + epi;
     const long full = tiles / 256;
     const int rem = (int)(tiles % 256);
     double t = (double)full * whole;
@@ -499,7 +525,7 @@ static double c8_time_us(const GemmParams& p, int bn) {
         if (s == 1)
             t += whole;
         else
-            t += (((chunks + s - 1) / s) * 9 + skip_kt) * tap + epi + 3.5 * (s - 1) * ((double)bn / 160.0);
+            t += (((chunks + s - 1) / s) * taps + skip_kt) * tap + epi + 3.5 * (s - 1) * ((double)bn / 160.0);
     }
     return t;
 }
@@ -511,6 +537,7 @@ int mdx_conv8p_pick_bn(const GemmParams& p, int bn_hint) {
     double best_t = 1e30;
     for (int bn : cand) {
         if (bn == 64 && p.N > 64) continue;
+        if (p.upsample && p.N % bn != 0) continue;       // sub-pixel: an N tile stays inside one parity's weight rows
         const double t = c8_time_us(p, bn);
         if (t < best_t * 0.985) {        // later candidates must win clearly
             best_t = t;
@@ -524,12 +551,13 @@ int mdx_conv8p_pick_bn(const GemmParams& p, int bn_hint) {
 // CUs idle and the 128-row tiles with their own split-K win -- measured at UNet batch 2).
 int mdx_conv8p_tiles(const GemmParams& p) {
     int bn = mdx_conv8p_pick_bn(p, 0);
-    if (bn < 128) bn = 128;       // counted in tiles of at least 128 columns: 128 narrow tiles are half the work of 128 wide ones
-    return p.B * (p.H >> 4) * (p.W >> 4) * ((p.N + bn - 1) / bn);
+    if (bn < 128 && !p.upsample) bn = 128;       // counted in tiles of at least 128 columns: 128 narrow tiles are half the work of 128 wide ones
+    return p.B * (p.H >> 4) * (p.W >> 4) * (p.upsample ? 4 : 1) * ((p.N + bn - 1) / bn);
 }
 
 size_t mdx_conv8p_plan(GemmParams& p, int bn, size_t workspace_bytes, bool have_workspace, bool query_only) {
-    p.tiles_m = p.B * (p.H >> 4) * (p.W >> 4);
+    p.c8_sub = p.upsample ? 1 : 0;
+    p.tiles_m = p.B * (p.H >> 4) * (p.W >> 4) * (p.c8_sub ? 4 : 1);
     p.tiles_n = (p.N + bn - 1) / bn;
     const int ntiles = p.tiles_m * p.tiles_n;
     p.nsplit = 1;
@@ -558,8 +586,24 @@ size_t mdx_conv8p_plan(GemmParams& p, int bn, size_t workspace_bytes, bool have_
     return need;
 }
 
-int mdx_conv8p_launch(const GemmParams& p, int bn, hipStream_t st) {
+int mdx_conv8p_launch(const GemmParams& pin, int bn, hipStream_t st) {
+    GemmParams p = pin;
     const dim3 grid(p.c8_full + ((p.c8_rem + 7) / 8) * 8 * p.c8_split);
+    if (p.c8_sub) {       // sub-pixel form: the per-parity weights, four taps per chunk
+        p.w = p.w_sub;
+        p.w_bytes = p.w_sub_bytes;
+        p.kt64 = (p.cin >> 6) * 4;
+        switch (bn) {
+            case 64: c8_launch<64, 2, 4>(p, grid, st); break;
+            case 128: c8_launch<128, 2, 4>(p, grid, st); break;
+            case 160: c8_launch<160, 2, 4>(p, grid, st); break;
+            case 192: c8_launch<192, 1, 4>(p, grid, st); break;
+            default:
+                mdx_set_error("mdx_gemm_f16: the sub-pixel conv8p form has no %d-column tile", bn);
+                return MDX_E_INVALID;
+        }
+        return MDX_OK;
+    }
     switch (bn) {
         case 64: c8_launch<64, 2>(p, grid, st); break;
         case 96: c8_launch<96, 2>(p, grid, st); break;

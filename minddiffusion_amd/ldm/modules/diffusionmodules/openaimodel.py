@@ -371,6 +371,12 @@ class UNetModel:
             elif kind == "up" and self.conv_resample:
                 w[pre + "w"] = self._pack_conv(P[pre + "conv.conv.weight"])
                 w[pre + "b"] = self._dev(P[pre + "conv.conv.bias"], f32)
+                if layer[1] % 64 == 0 and ops.get_option("unet_subpixel_upsample"):
+                    # sub-pixel form of nearest-2x + conv (mdx_gemm_desc.w_sub): 4 Cin instead of 9 Cin products per output; the
+                    # library uses it where the eight-wave conv core applies and falls back to `w` + the upsampling gather elsewhere
+                    wt = P[pre + "conv.conv.weight"]
+                    wt = wt if isinstance(wt, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(wt))
+                    w[pre + "wsub"] = ops.pack_subpixel_conv_weight(wt.to(self.device))
         w["emb.w"] = torch.cat(emb_w, 0).contiguous()
         w["emb.b"] = torch.cat(emb_b, 0).contiguous()
         self._emb_total = off
@@ -500,7 +506,7 @@ class UNetModel:
         ctx_kv = {}
 
         def conv3(src, cin, cout, wt, bias, h, wd, stride=1, upsample=0, rowbias=None, residual=None, src2=None, c2=0,
-                  skip=None, gn=None):
+                  skip=None, gn=None, wsub=None):
             """skip = (x, x2, c1, c2, packed 1x1 weights): the ResBlock's skip_connection rides on this launch as extra K
             tiles (mdx_gemm_desc.skip_w); `bias` then holds the sum of both convs' biases."""
             hs, ws_ = (2 * h, 2 * wd) if upsample else (h, wd)
@@ -511,6 +517,8 @@ class UNetModel:
                 kw = dict(skip_a=skip[0], skip_a2=skip[1], skip_c1=skip[2], skip_c2=skip[3], skip_w=skip[4])
             if gn is not None:      # GroupNorm + SiLU of `src` inside the conv; the statistics pointer is wired after planning
                 kw.update(gn_gamma=gn[0], gn_beta=gn[1], gn_eps=gn[2], gn_silu=1)
+            if wsub is not None:
+                kw["w_sub"] = wsub
             add_gemm(main, a=src, w=wt, N=cout, B=B, H=h, W=wd, c1=cin - c2, out=out, out_ld=cout, a2=src2, c2=c2,
                      bias=bias, rowbias=rowbias, rowbias_ld=self._emb_total if rowbias is not None else 0,
                      residual=residual, residual_ld=cout if residual is not None else 0, ksize=3, stride=stride,
@@ -835,7 +843,7 @@ class UNetModel:
                 return new, h // 2, wd // 2
             if kind == "up":            # Upsample openaimodel.py:33-60 (the nearest-2x is folded into the conv's gather)
                 if self.conv_resample:
-                    return conv3(cur, layer[1], layer[1], w[pre + "w"], w[pre + "b"], h, wd, upsample=1)
+                    return conv3(cur, layer[1], layer[1], w[pre + "w"], w[pre + "b"], h, wd, upsample=1, wsub=w.get(pre + "wsub"))
                 new = A.get((B, 4 * h * wd, layer[1]))
                 emit(lambda cur=cur, new=new: ops.upsample_nearest2x(cur, B, h, wd, layer[1], out=new), "small")
                 return new, 2 * h, 2 * wd

@@ -37,7 +37,10 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
             "unet_gn_conv_fuse": int(os.environ.get("MDX_UNET_GN_CONV_FUSE", "0")),
             # 1 = when a plan is built, launches whose shape the measured tile table (csrc/gemm_tuned.inc) does not list are timed
             # once on the device (mdx_gemm_tune, a few ms per distinct shape) and keep the fastest form; answers live in tune_cache
-            "unet_tune_first_use": int(os.environ.get("MDX_UNET_TUNE_FIRST_USE", "0"))}
+            "unet_tune_first_use": int(os.environ.get("MDX_UNET_TUNE_FIRST_USE", "0")),
+            # 1 = Upsample convs carry the sub-pixel weights (mdx_gemm_desc.w_sub: 4 Cin instead of 9 Cin products per output on the
+            # un-upsampled tensor); the library uses them wherever the eight-wave conv core applies
+            "unet_subpixel_upsample": int(os.environ.get("MDX_UNET_SUBPIXEL_UPSAMPLE", "1"))}
 
 
 def set_option(name, value):
@@ -299,6 +302,32 @@ def pack_conv_weight(w4d, cin_pad=None, cout_pad=None):
     return pack_gemm_weight(conv_weight_k_order(w4d, cin_pad, cout_pad))
 
 
+def subpixel_conv_weight(w4d):
+    """[Cout, Cin, 3, 3] of a conv that follows a nearest-2x upsample (Upsample.construct, openaimodel.py:57-60) -> the four
+    2 x 2 convs of the LOW-resolution tensor it is equal to, [4 Cout, Cin, 2, 2] (parity (dy, dx) major): output pixel
+    (2y + dy, 2x + dx) reads upsampled rows 2y + dy + ky - 1, i.e. source rows {y - 1, y, y} (dy = 0) or {y, y, y + 1} (dy = 1), so the
+    taps that fall on one source row are summed (fp32, rounded to fp16 once by the packer): rows {w0, w1 + w2} / {w0 + w1, w2},
+    columns likewise.  4 Cin instead of 9 Cin products per output."""
+    w = w4d.to(torch.float32)
+    rows = {0: (w[:, :, 0], w[:, :, 1] + w[:, :, 2]), 1: (w[:, :, 0] + w[:, :, 1], w[:, :, 2])}       # [Cout, Cin, 3 (kx)] each
+    out = []
+    for dy in (0, 1):
+        for dx in (0, 1):
+            taps = []
+            for a in (0, 1):
+                r = rows[dy][a]
+                cols = (r[:, :, 0], r[:, :, 1] + r[:, :, 2]) if dx == 0 else (r[:, :, 0] + r[:, :, 1], r[:, :, 2])
+                taps.append(torch.stack(cols, -1))                                                     # [Cout, Cin, 2 (b)]
+            out.append(torch.stack(taps, 2))                                                           # [Cout, Cin, 2 (a), 2 (b)]
+    return torch.cat(out, 0)
+
+
+def pack_subpixel_conv_weight(w4d):
+    """mdx_gemm_desc.w_sub (include/mdx.h): the packed per-parity 2 x 2 weights, logical [4 Cout][4 Cin] in the conv K order."""
+    assert w4d.shape[0] % 64 == 0 and w4d.shape[1] % 64 == 0
+    return pack_conv_weight(subpixel_conv_weight(w4d))
+
+
 def pack_conv_weight_frag(w4d):
     """[Cout, Cin, 3, 3] -> the MFMA-fragment-major packing of mdx_gemm_desc.w_frag (Cout % 64 == 0, Cin % 64 == 0)."""
     co, ci = w4d.shape[0], w4d.shape[1]
@@ -323,7 +352,7 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
                    out_mode=OUT_ROWMAJOR, splitk=0, workspace=None, out_bs=0, out2=None, out2_ld=0, n_split=0, asym_pad=0,
                    stats_out=None, ln_stats=None, ln_s=None, ln_eps=1e-5, tile_m=0, tile_n=0, colstats_out=None, stages=0,
                    w_frag=0, skip_a=None, skip_a2=None, skip_c1=0, skip_c2=0, skip_w=None, gn_colstats=None, gn_nrb=0,
-                   gn_gamma=None, gn_beta=None, gn_eps=1e-5, gn_silu=1):
+                   gn_gamma=None, gn_beta=None, gn_eps=1e-5, gn_silu=1, w_sub=None):
     d = GemmDesc()
     d.a = a.data_ptr()
     d.a2 = 0 if a2 is None else a2.data_ptr()
@@ -361,6 +390,7 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
     d.skip_w = 0 if skip_w is None else skip_w.data_ptr()
     d.colstats_out = 0 if colstats_out is None else colstats_out.data_ptr()
     d.colstats_cap = 0 if colstats_out is None else int(colstats_out.shape[0])
+    d.w_sub = 0 if w_sub is None else w_sub.data_ptr()
     return d
 
 

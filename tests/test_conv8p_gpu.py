@@ -239,3 +239,39 @@ def test_conv8p_phase_per_kstep_form_is_bit_identical(ops):
     a = ops.gemm(x, w, Cout, B, H, W, Cin, ksize=3, tile_m=256, stages=8, tile_n=160)
     b = ops.gemm(x, w, Cout, B, H, W, Cin, ksize=3, tile_m=256, stages=9, tile_n=160)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,cs", [(1, 16, 16, 64, 64, False), (2, 32, 16, 128, 320, True), (2, 32, 32, 640, 640, True),
+                                                (8, 48, 48, 128, 128, False)])
+def test_conv8p_subpixel_upsample_conv(ops, B, H, W, Cin, Cout, cs):
+    """mdx_gemm_desc.w_sub: nearest-2x + conv3x3 (Upsample.construct, openaimodel.py:57-60) as four 2 x 2 convs of the low-resolution
+    tensor with pre-summed taps (one fp16 rounding of the summed weights instead of separate products: within the usual 1e-3 of the
+    fp32 oracle), pixel-shuffled by the epilogue; against the oracle and against the upsampling-gather form it replaces; column
+    statistics of the interleaved row blocks."""
+    rng = np.random.RandomState(B + H + Cin + Cout)
+    x = h16(rng.standard_normal((B, Cin, H, W)))
+    w = h16(rng.standard_normal((Cout, Cin, 3, 3)) / math.sqrt(9 * Cin))
+    bv = rng.standard_normal(Cout).astype(np.float32)
+    ref = O.conv2d(O.upsample_nearest2x(torch.tensor(x)), torch.tensor(w), torch.tensor(bv), stride=1, padding=1)
+    xd, wp, bd = dev16(nhwc(x)), pack_conv(w), dev32(bv)
+    wsub = ops.pack_subpixel_conv_weight(torch.tensor(w).to(DEV))
+    M = B * 4 * H * W
+    out = torch.full((M, Cout), float("nan"), dtype=torch.float16, device=DEV)
+    cst = torch.full((M // 256, Cout, 2), float("nan"), dtype=torch.float32, device=DEV) if cs else None
+    d = ops.make_gemm_desc(xd, wp, Cout, B, H, W, Cin, out, Cout, bias=bd, ksize=3, upsample=1, w_sub=wsub, tile_m=256, stages=8,
+                           colstats_out=cst)
+    need = ops.gemm_workspace_bytes(d)
+    ws = ops.new_gemm_workspace(max(need, 1 << 16), DEV)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    q = ops.gemm_query(d)
+    assert q[0] == 256 and q[3] == 1, q
+    ops.gemm_run(d)
+    torch.cuda.synchronize()
+    check(f"conv8p_subpixel_B{B}_{H}x{W}_{Cin}to{Cout}", from_nhwc(out.float().cpu().numpy(), B, 2 * H, 2 * W), ref, rel_l2=1e-3)
+    old = ops.gemm(xd, wp, Cout, B, H, W, Cin, bias=bd, ksize=3, upsample=1)
+    check(f"conv8p_subpixel_vs_gather_form_B{B}_{H}x{W}_{Cin}to{Cout}", out, old, rel_l2=1e-3)
+    if cs:      # per sample the row blocks partition the output pixels: the per-sample column sums must match
+        nb = M // 256 // B
+        o = out.float().reshape(B, 4 * H * W, Cout)
+        check("conv8p_subpixel_colstats_sum", cst[:, :, 0].reshape(B, nb, Cout).sum(1), o.sum(1), rel_l2=1e-5)
+        check("conv8p_subpixel_colstats_sumsq", cst[:, :, 1].reshape(B, nb, Cout).sum(1), (o * o).sum(1), rel_l2=1e-5)

@@ -833,3 +833,25 @@ def test_bench_uses_the_committed_pmc_passes_only_for_the_launch_mix_they_were_t
     roof2 = {"families": {"gemm": {}}}
     bench.pmc_mfma_busy(roof2, round(n) + 40)
     assert "mfma_busy" not in roof2 and "stale" in roof2["mfma_busy_note"]
+
+
+def test_subpixel_conv_weight_is_the_upsampled_conv():
+    """ops.subpixel_conv_weight (mdx_gemm_desc.w_sub): nearest-2x followed by a 3 x 3 conv, pad 1 (Upsample.construct,
+    openaimodel.py:57-60) equals, for each output parity (dy, dx), a 2 x 2 conv of the low-resolution tensor at rows
+    {y - 1 + dy, y + dy} / columns {x - 1 + dx, x + dx} with the taps that fall on one source pixel summed -- checked in float64
+    against torch's own upsample + conv, borders included."""
+    import torch.nn.functional as F
+    from minddiffusion_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 5, 6, 7, generator=g, dtype=torch.float64)
+    w = torch.randn(3, 5, 3, 3, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+    ws = ops.subpixel_conv_weight(w.to(torch.float32)).to(torch.float64).reshape(2, 2, 3, 5, 2, 2)
+    out = torch.zeros_like(ref)
+    xp = F.pad(x, (1, 1, 1, 1))
+    for dy in range(2):
+        for dx in range(2):
+            # taps (a, b) read padded rows y + dy + a, columns x + dx + b  (padded index = source index + 1)
+            o = F.conv2d(xp[:, :, dy:dy + 6 + 1, dx:dx + 7 + 1], ws[dy, dx])
+            out[:, :, dy::2, dx::2] = o
+    assert torch.allclose(out, ref, atol=1e-5), float((out - ref).abs().max())

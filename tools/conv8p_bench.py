@@ -32,6 +32,13 @@ SHAPES = [
     ("glide_l0_192_192", 16, 64, 64, 192, 192, 0),
     ("glide_l1_384_384", 16, 32, 32, 384, 384, 0),
     ("glide_sr_192_192", 8, 256, 256, 192, 192, 0),
+    # "up_": nearest-2x + conv (Upsample); B, H, W = the LOW-resolution source; conv8p forms run the sub-pixel weights
+    ("up_wk_32to64_640", 16, 32, 32, 640, 640, 0),
+    ("up_wk_16to32_1280", 16, 16, 16, 1280, 1280, 0),
+    ("up_sd768_48to96_640", 8, 48, 48, 640, 640, 0),
+    ("up_b2_32to64_640", 2, 32, 32, 640, 640, 0),
+    ("up_b2_16to32_1280", 2, 16, 16, 1280, 1280, 0),
+    ("up_glide_32to64_384", 16, 32, 32, 384, 384, 0),
     ("b2_l0_320_320", 2, 64, 64, 320, 320, 0),
     ("b2_l1_640_640", 2, 32, 32, 640, 640, 0),
 ]
@@ -52,13 +59,17 @@ def main():
     for name, B, H, W, cin, cout, skc in SHAPES:
         if args.only and not any(o in name for o in args.only.split(",")):
             continue
+        up = 1 if name.startswith("up_") else 0
         K = 9 * cin
-        M = B * H * W
+        M = B * H * W * (4 if up else 1)
         a = torch.randn(B, H * W, cin, device=dev, dtype=torch.float16)
         xs = torch.randn(B, H * W, skc, device=dev, dtype=torch.float16) if skc else None
         wbytes = cout * K * 2
         ncopy = max(2, min(8, (300 << 20) // wbytes + 1))
-        ws = [ops.pack_conv_weight(torch.randn(cout, cin, 3, 3, device=dev, dtype=torch.float16) * (K ** -0.5)) for _ in range(ncopy)]
+        raw = [torch.randn(cout, cin, 3, 3, device=dev, dtype=torch.float16) * (K ** -0.5) for _ in range(ncopy)]
+        ws = [ops.pack_conv_weight(r) for r in raw]
+        wsubs = [ops.pack_subpixel_conv_weight(r) for r in raw] if up else [None] * ncopy
+        del raw
         wsk = ops.pack_conv_weight(torch.randn(cout, skc, 1, 1, device=dev, dtype=torch.float16) * (skc ** -0.5)) if skc else None
         bias = torch.randn(cout, device=dev)
         emb = torch.randn(B, cout, device=dev)
@@ -79,7 +90,8 @@ def main():
         for k, kw in forms.items():
             route(k)
             descs[k] = [ops.make_gemm_desc(a, w, cout, B, H, W, cin, out, cout, bias=bias, ksize=3, rowbias=emb, rowbias_ld=cout,
-                                           colstats_out=cst, **skw, **kw) for w in ws]
+                                           colstats_out=cst, upsample=up, w_sub=None if k == "old" else wsub, **skw, **kw)
+                        for w, wsub in zip(ws, wsubs)]
             need = ops.gemm_workspace_bytes(descs[k][0])
             if need and (wsp is None or wsp.numel() * 4 < need):
                 wsp = ops.new_gemm_workspace(need, dev)
