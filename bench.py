@@ -399,15 +399,32 @@ def run_config(config, args, rank, world, device, steps, warmup, cpu):
     for _ in range(warmup):
         out = one_step()
     barrier()
+    D.reset_collective_stats()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = one_step()
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0          # this rank's own clock (before the closing barrier): per-rank rate below
     barrier()
     elapsed = time.perf_counter() - t0
+    dist_info = {"dist_backend": None, "rccl_world_size": 1, "broadcasts_per_step": 0, "broadcast_bytes": 0,
+                 "broadcast_ms": 0.0, "per_rank_units_per_s": None}
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # self-proving N > 1 record: the backend torch.distributed actually runs ("nccl" IS RCCL on ROCm), its world size, what
+        # the ONE collective per step moved and how long it took (HIP events around it, outside the trajectory), and the
+        # slowest / fastest rank's own rate
+        rates = torch.tensor([batch * steps / own], device=device, dtype=torch.float64)
+        lo, hi = rates.clone(), rates.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        cs = D.collective_stats
+        dist_info = {"dist_backend": torch.distributed.get_backend(), "rccl_world_size": torch.distributed.get_world_size(),
+                     "broadcasts_per_step": cs["broadcasts"] / steps, "broadcast_bytes": cs["bytes"] // max(cs["broadcasts"], 1),
+                     "broadcast_ms": round(cs["ms"] / max(cs["broadcasts"], 1), 4),
+                     "per_rank_units_per_s": {"min": round(float(lo.item()), 4), "max": round(float(hi.item()), 4)}}
     assert torch.isfinite(out).all()
 
     ms_per_step = elapsed / steps * 1e3
@@ -419,7 +436,7 @@ def run_config(config, args, rank, world, device, steps, warmup, cpu):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": cfg["workload"] + "; synthetic seeded weights + synthetic text conditioning",
                        "name": config, "global_batch": Bg, "parallelism": f"batch-shard x{world}",
-                       "hip_graph": None},
+                       "hip_graph": None, **dist_info},
         }
         if cfg["family"] == "ldm":
             # per-UNet-step ms: HIP events around apply_model (CFG batch = 2 x per-GPU batch), median of 20 warm calls

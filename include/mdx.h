@@ -222,8 +222,14 @@ typedef struct mdx_gemm_desc {
 #define MDX_OUT_TRANSPOSED 1 /* out[(b * N + n) * out_ld + tok]: V^T for mdx_attention_f16 */
 
 int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s);
-/* Frees the library-owned split-K arrival counters (nothing may be in flight); later launches allocate them again. */
+/* Frees the library-owned split-K arrival counters (nothing may be in flight); later launches allocate them again.  Every hipGraph
+ * captured with a split launch holds the address of its workspace's counters: destroy such graphs first. */
 int mdx_gemm_release_counters(void);
+/* Hands the counters of ONE workspace (16 KiB per distinct workspace address) back for reuse by the next workspace that needs a set:
+ * call it when a workspace is freed, so that a long-lived process that plans at many resolutions does not accumulate them.  Same
+ * precondition (nothing in flight, no live graph captured with this workspace).  Returns the number of sets released (0 = the
+ * workspace never carried a split launch).  The counters' device is taken from the workspace POINTER, not the calling thread. */
+int mdx_gemm_release_workspace(const void* workspace);
 /* Bytes of split-K workspace mdx_gemm_f16 wants for this problem under its auto heuristic (0 if none). */
 size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d);
 /* Host-only validation of a descriptor (no launch): MDX_OK or MDX_E_INVALID with mdx_last_error() set. */
@@ -306,6 +312,12 @@ typedef struct mdx_st_tail_desc {
     int tile_rows;        /* 32 | 64 */
     int warm;             /* 0 = no L2 warmer wave (A/B switch), anything else = default */
 } mdx_st_tail_desc;
+#define MDX_ST_DEBUG_COUNT_BARRIERS 100 /* debug_stage: run the whole chain WITHOUT the L2 warmer wave and write the number of block
+                                           barriers the compute waves executed (int32) to debug_out[0] */
+/* Barriers in the schedule the warmer wave walks beside the compute waves (hand-mirrored in csrc/stchain.hip): the two must agree
+ * or the product launch deadlocks; tests compare them. */
+int mdx_st_tail_sched_barriers(int C, int tile_rows);
+int mdx_st_head_sched_barriers(int C, int tile_rows);
 int mdx_st_tail_f16(const mdx_st_tail_desc* d, mdx_stream_t s);
 /* 1 if mdx_st_tail_f16 has a kernel for this shape (host only): C = 320 with 5 x 64 or 8 x 40 heads today. */
 int mdx_st_tail_supported(int C, int heads, int dim_head, int tokens_per_sample, int tile_rows);

@@ -88,6 +88,9 @@ SIGNATURES = {
     "mdx_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "mdx_gemm_f16": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
     "mdx_gemm_workspace_bytes": (c_size_t, [ctypes.POINTER(GemmDesc)]),
+    "mdx_gemm_release_workspace": (c_int, [c_void_p]),
+    "mdx_st_tail_sched_barriers": (c_int, [c_int, c_int]),
+    "mdx_st_head_sched_barriers": (c_int, [c_int, c_int]),
     "mdx_gemm_release_counters": (c_int, []),
     "mdx_gemm_tune": (c_int, [ctypes.POINTER(GemmDesc), c_void_p, c_void_p, c_size_t, c_int, ctypes.POINTER(c_int),
                               ctypes.POINTER(ctypes.c_float)]),

@@ -280,11 +280,10 @@ void launch_attn(const AttnParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t stage = (size_t)BKV * KCH * 16 + (size_t)DT * 32 * 128;
     constexpr size_t ostage = (size_t)4 * 32 * (DT * 32 + 8) * 2;
     constexpr size_t lds = (2 * stage > ostage ? 2 * stage : ostage);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static MdxPerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL(attn_kernel<D>, grid, dim3(256), lds, st, p);
 }

@@ -464,12 +464,9 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
 template <int BN, int PH, int TAPS = 9>
 void c8_launch(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t lds = c8_lds_bytes<BN>();
-    static bool attr_set[64] = {};
-    int dv = 0;
-    (void)hipGetDevice(&dv);
-    if (dv >= 0 && dv < 64 && !attr_set[dv]) {        // hipFuncSetAttribute is per device
+    static MdxPerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel<BN, PH, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[dv] = true;
     }
     hipLaunchKernelGGL((conv8p_kernel<BN, PH, TAPS>), grid, dim3(C8_NT), lds, st, p);
 }

@@ -1249,11 +1249,10 @@ void launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t ring = (size_t)NS * (BM + BN) * BK * 2;
     constexpr size_t epi = (size_t)(BM > BN ? BM : BN) * ((BM > BN ? BN : BM) + 8) * 2 + 4096;  // staged C tile
     constexpr size_t lds = ring > epi ? ring : epi;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static MdxPerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, BK, NS, SWAP, FASTK, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, NS, SWAP, FASTK, NW>), grid, dim3(NW * 64), lds, st, p);
 }
@@ -1304,11 +1303,10 @@ void launch_halo(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t lds0 = ring > epi ? ring : epi;
     constexpr size_t gn_tab_max = (BDIR || PW != 16) ? 0 : 640 * 8;      // {scale, shift} table of the fused input GroupNorm
     const size_t lds = lds0 + (p.gn_cs ? (size_t)p.cin * 8 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static MdxPerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW, BDIR, W4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds0 + gn_tab_max));
-        attr_set = true;
     }
     hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, NSB, SWAP, PW, BDIR, W4>), grid, dim3(BM * 2), lds, st, p);
 }
@@ -1434,20 +1432,26 @@ struct Resolved {
 struct TicketPools {
     std::mutex mu;
     std::map<std::pair<int, const void*>, unsigned*> slot;
-    struct Dev { char* next = nullptr; int left = 0; hipStream_t zero_stream = nullptr; };
+    struct Dev { char* next = nullptr; int left = 0; hipStream_t zero_stream = nullptr; std::vector<unsigned*> free_slots; };
     std::map<int, Dev> dev;
     std::vector<std::pair<int, void*>> chunks;
 };
 static TicketPools g_tickets;
 constexpr int TICKET_CHUNK_SLOTS = 64;
 
-static int ticket_slot(const void* ws, unsigned** out) {
+// The device a workspace lives on comes from the POINTER (hipPointerGetAttributes), not from the calling thread's current device: a
+// C caller that drives several GPUs from one thread gets the right pool either way.
+static int ticket_device_of(const void* ws) {
+    hipPointerAttribute_t at;
+    if (ws && hipPointerGetAttributes(&at, ws) == hipSuccess) return at.device;
+    (void)hipGetLastError();
     int dv = 0;
-    hipError_t e = hipGetDevice(&dv);
-    if (e != hipSuccess) {
-        mdx_set_error("mdx_gemm_f16: hipGetDevice failed: %s", hipGetErrorString(e));
-        return MDX_E_HIP;
-    }
+    (void)hipGetDevice(&dv);
+    return dv;
+}
+
+static int ticket_slot(const void* ws, unsigned** out) {
+    const int dv = ticket_device_of(ws);
     std::lock_guard<std::mutex> lk(g_tickets.mu);
     const auto key = std::make_pair(dv, ws);
     const auto it = g_tickets.slot.find(key);
@@ -1456,16 +1460,27 @@ static int ticket_slot(const void* ws, unsigned** out) {
         return MDX_OK;
     }
     TicketPools::Dev& d = g_tickets.dev[dv];
+    if (!d.free_slots.empty()) {        // a slot handed back by mdx_gemm_release_workspace: every launch left its counters zero
+        unsigned* s = d.free_slots.back();
+        d.free_slots.pop_back();
+        g_tickets.slot.emplace(key, s);
+        *out = s;
+        return MDX_OK;
+    }
     if (d.left == 0) {
         const size_t bytes = (size_t)TICKET_CHUNK_SLOTS * MDX_GEMM_WS_HEAD;
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != dv) (void)hipSetDevice(dv);
         hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
         (void)hipThreadExchangeStreamCaptureMode(&mode);
         void* mem = nullptr;
-        e = hipMalloc(&mem, bytes);
+        hipError_t e = hipMalloc(&mem, bytes);
         if (e == hipSuccess && !d.zero_stream) e = hipStreamCreateWithFlags(&d.zero_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMemsetAsync(mem, 0, bytes, d.zero_stream);
         if (e == hipSuccess) e = hipStreamSynchronize(d.zero_stream);
         (void)hipThreadExchangeStreamCaptureMode(&mode);
+        if (cur != dv) (void)hipSetDevice(cur);
         if (e != hipSuccess) {
             if (mem) (void)hipFree(mem);
             mdx_set_error("mdx_gemm_f16: allocating the split-K arrival counters failed: %s", hipGetErrorString(e));
@@ -1481,6 +1496,23 @@ static int ticket_slot(const void* ws, unsigned** out) {
     g_tickets.slot.emplace(key, s);
     *out = s;
     return MDX_OK;
+}
+
+// Hands the arrival counters of ONE workspace back for reuse (include/mdx.h): call it when the workspace is freed.  Nothing may be
+// in flight on it and every hipGraph captured with it must have been destroyed (a captured launch holds the counters' address).
+extern "C" int mdx_gemm_release_workspace(const void* workspace) {
+    std::lock_guard<std::mutex> lk(g_tickets.mu);
+    int n = 0;
+    for (auto it = g_tickets.slot.begin(); it != g_tickets.slot.end();) {
+        if (it->first.second == workspace) {
+            g_tickets.dev[it->first.first].free_slots.push_back(it->second);
+            it = g_tickets.slot.erase(it);
+            ++n;
+        } else {
+            ++it;
+        }
+    }
+    return n;
 }
 
 // Frees the arrival counters (nothing may be in flight).  Later launches allocate again.
@@ -1509,10 +1541,11 @@ extern "C" int mdx_gemm_release_counters(void) {
 // 16 x 16 level): below that even a 4-way tail split cannot fill 256 CUs and the 128-row HALO tiles with their own split-K win
 // (tools/conv8p_bench.py at UNet batch 2: 462 vs 603 TF/s).
 static bool conv8p_wanted(const mdx_gemm_desc* d, const GemmParams& p) {
-    if (!mdx_opt(MDX_OPT_GEMM_CONV8P) || d->w_frag || d->defer_reduce || d->splitk > 1 || d->asym_pad) return false;
+    if (d->w_frag || d->defer_reduce || d->splitk > 1 || d->asym_pad) return false;
     if (mdx_opt(MDX_OPT_GEMM_BM) || !mdx_opt(MDX_OPT_GEMM_HALO)) return false;
     if (!mdx_conv8p_eligible(p)) return false;
-    if (d->tile_m == 256 && (d->stages == 8 || d->stages == 9)) return true;      // 9: one phase per 32-deep k-step (A/B form)
+    if (d->tile_m == 256 && (d->stages == 8 || d->stages == 9)) return true;      // forced (9: one phase per 32-deep k-step)
+    if (!mdx_opt(MDX_OPT_GEMM_CONV8P)) return false;
     if (d->tile_m != 0 || d->stages != 0) return false;
     if (d->tile_n != 0 && d->tile_n != 64 && d->tile_n != 96 && d->tile_n != 128 && d->tile_n != 160 && d->tile_n != 192) return false;
     if (p.upsample) return mdx_conv8p_tiles(p) >= mdx_opt(MDX_OPT_GEMM_SUBPIXEL_MIN_TILES);      // 2.25x fewer FLOPs: pays from far fewer tiles
@@ -1522,10 +1555,11 @@ static bool conv8p_wanted(const mdx_gemm_desc* d, const GemmParams& p) {
 // The eight-wave 256 x 128 dense core: forced by tile_m = 256 with stages = 8, or automatic for M >= gemm_dense8p_min_m with at
 // least 128 tiles (the token GEMMs of the 32 x 32 / 16 x 16 levels at UNet batch >= 8).
 static bool gemm8p_wanted(const mdx_gemm_desc* d, const GemmParams& p) {
-    if (!mdx_opt(MDX_OPT_GEMM_DENSE8P) || d->w_frag || d->defer_reduce || d->splitk > 1) return false;
+    if (d->w_frag || d->defer_reduce || d->splitk > 1) return false;
     if (mdx_opt(MDX_OPT_GEMM_BM) || mdx_opt(MDX_OPT_GEMM_BN)) return false;
     if (!mdx_gemm8p_eligible(p)) return false;
-    if (d->tile_m == 256 && d->stages == 8) return true;
+    if (d->tile_m == 256 && d->stages == 8) return true;       // forced: independent of the option
+    if (!mdx_opt(MDX_OPT_GEMM_DENSE8P)) return false;
     if (d->tile_m != 0 || d->stages != 0 || (d->tile_n != 0 && d->tile_n != 128)) return false;
     return p.M >= mdx_opt(MDX_OPT_GEMM_DENSE8P_MIN_M) && mdx_gemm8p_tiles(p) >= 128;
 }

@@ -155,12 +155,9 @@ void g8_launch(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t ring = 3u * (G8_BM + BN) * 128u;
     constexpr size_t epi = (size_t)G8_BM * (BN + 8) * 2 + 4096;
     constexpr size_t lds = ring > epi ? ring : epi;
-    static bool attr_set[64] = {};
-    int dv = 0;
-    (void)hipGetDevice(&dv);
-    if (dv >= 0 && dv < 64 && !attr_set[dv]) {
+    static MdxPerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[dv] = true;
     }
     hipLaunchKernelGGL((gemm8p_kernel<BN>), grid, dim3(G8_NT), lds, st, p);
 }

@@ -73,6 +73,20 @@ enum MdxOpt {
 };
 int mdx_opt(int id);
 
+// hipFuncSetAttribute (the dynamic-LDS limit of a kernel) is PER DEVICE: one flag per (kernel instantiation, device), so that a C
+// caller that drives several GPUs from one process raises the limit on each of them (a process-wide `static bool` set it on the
+// first device only and the launch on the second failed with MDX_E_HIP).
+struct MdxPerDeviceOnce {
+    bool done[64] = {};
+    bool first() {       // true exactly once per device (devices >= 64: always true -- the attribute call is idempotent)
+        int dv = 0;
+        if (hipGetDevice(&dv) != hipSuccess || dv < 0 || dv >= 64) return true;
+        if (done[dv]) return false;
+        done[dv] = true;
+        return true;
+    }
+};
+
 // ---- device helpers
 // sigmoid(x) = 1 / (1 + 2^(-x log2 e)) on the raw transcendental units (v_exp_f32 + v_rcp_f32, 1 ulp each): an IEEE
 // division here costs ~10 VALU instructions per element and the epilogues / GroupNorm apply it to every output.

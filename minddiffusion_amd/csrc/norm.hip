@@ -679,11 +679,10 @@ static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const 
             p.nblk = 1;
             p.pix = HW;
             constexpr size_t lds = ((size_t)GNF_THREADS * 8 * 2 + (size_t)GNF_FOLD * 512 * 2 + 512 * 2 + 64 * 2 + 512 * 2) * sizeof(float);
-            static bool attr_set = false;
-            if (!attr_set) {
+            static MdxPerDeviceOnce attr_once;
+            if (attr_once.first()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr_set = true;
             }
             hipLaunchKernelGGL(gn_fused_kernel<false>, dim3(p.ncb, B), dim3(GNF_THREADS), lds, st, p, MdxSplitInfo{});
             MDX_LAUNCH_CHECK("mdx_groupnorm_f16(fused)");
@@ -752,11 +751,10 @@ extern "C" int mdx_groupnorm_from_splitk_f16(const mdx_gemm_desc* prod, const fl
     p.eps = eps;
     p.silu = silu;
     constexpr size_t lds = ((size_t)GNF_THREADS * 8 * 2 + (size_t)GNF_FOLD * 512 * 2 + 512 * 2 + 64 * 2 + 512 * 2) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static MdxPerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL(gn_fused_kernel<true>, dim3(p.ncb, sp.B), dim3(GNF_THREADS), lds, (hipStream_t)s, p, sp);
     MDX_LAUNCH_CHECK("mdx_groupnorm_from_splitk_f16");

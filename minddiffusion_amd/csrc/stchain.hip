@@ -56,6 +56,13 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Every block barrier of the compute waves goes through this macro: it also counts them (one SALU add), so that the barrier schedules
+// the warmer wave walks (make_sched / make_head_sched, hand-mirrored) can be CHECKED against what the compute waves execute:
+// debug_stage = MDX_ST_DEBUG_COUNT_BARRIERS runs the whole chain without the warmer and writes the count to debug_out
+// (tests/test_stchain_gpu.py::test_warmer_schedules_match_the_compute_waves).  A drift would deadlock the product launch.
+#define LDS_BARRIER() do { lds_barrier(); ++nbar; } while (0)
+constexpr int ST_COUNT_BARRIERS = 100;      // = MDX_ST_DEBUG_COUNT_BARRIERS (mdx.h)
+
 __device__ __forceinline__ u32x4 wload(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned piece) {
     return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, piece * 1024u, 0);
 }
@@ -207,6 +214,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTail
     float* vec = reinterpret_cast<float*>(smem + (2 + NH) * BUF);
     float2* part = reinterpret_cast<float2*>(vec + V::total);   // [NW][BM]
 
+    int nbar = 0;       // block barriers executed by this (compute) wave: LDS_BARRIER
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -242,13 +250,13 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTail
         for (int idx = tid; idx < V::total / 4; idx += NT)
             reinterpret_cast<float4*>(vec)[idx] = reinterpret_cast<const float4*>(p.vec)[idx];
     }
-    lds_barrier();
+    LDS_BARRIER();
 
     const int lane_row_off = l31 * LDB + hi * 16;           // A-fragment base of this lane inside a row buffer
     const int epi_off = l31 * LDB + (n0 + 4 * hi) * 2;      // this lane's first 4-column group of row l31 (tile 0, g = 0)
 
     auto dump = [&](const char* buf) {    // debug: LDS row buffer -> dbg rows (block-uniform call)
-        lds_barrier();
+        LDS_BARRIER();
         for (int idx = tid; idx < BM * CPR; idx += NT) {
             const int row = idx / CPR, ch = idx - row * CPR;
             *reinterpret_cast<f16x8*>(p.dbg + (size_t)(m0 + row) * C + ch * 8) =
@@ -280,7 +288,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTail
             sq += __shfl_xor(sq, 32, 64);
             if (hi == 0) part[wave * BM + i * 32 + l31] = make_float2(su, sq);
         }
-        lds_barrier();      // partials visible; every wave is done reading A
+        LDS_BARRIER();      // partials visible; every wave is done reading A
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float su = 0.f, sq = 0.f;
@@ -306,7 +314,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTail
                 *reinterpret_cast<f16x4*>(Xb + epi_off + i * 32 * LDB + g * 16) = th[i][g];
             }
         }
-        lds_barrier();
+        LDS_BARRIER();
     };
 
     f32x16 acc1[1][TM];
@@ -327,7 +335,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTail
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<f16x4*>(Hb + epi_off + i * 32 * LDB + g * 16) =
                 f16x4{(f16)acc1[0][i][4 * g], (f16)acc1[0][i][4 * g + 1], (f16)acc1[0][i][4 * g + 2], (f16)acc1[0][i][4 * g + 3]};
-    lds_barrier();
+    LDS_BARRIER();
     if (p.stop_after == 3) { dump(Hb); return; }
 
     // ---- S3: cross-attention over the cached context keys: A <- softmax(q2 K^T scale) V, per (head, 32-row tile)
@@ -424,7 +432,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTail
                 }
         }
     }
-    lds_barrier();
+    LDS_BARRIER();
     if (p.stop_after == 4) { dump(Ab); return; }
 
     // ---- S4: t2 = o2 Wo2^T + bo2 + t1 ; X <- t2 ; A <- LN3(t2)
@@ -456,11 +464,11 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTail
                 for (int e = 0; e < 4; ++e) hv[e] = (f16)((accg[0][i][4 * g + e] + aa[e]) * gelu_tanh_f(accg[1][i][4 * g + e] + gg[e]));
                 *reinterpret_cast<f16x4*>(Hb + (c % NH) * BUF + epi_off + i * 32 * LDB + g * 16) = hv;
             }
-        lds_barrier();
+        LDS_BARRIER();
         unit<C, TM, 1>(acc2, Hb + (c % NH) * BUF + lane_row_off, ring, rs_w, voff, piece);
         // one buffer: every wave must be done reading this chunk before the next one is written.  Two buffers: chunk c + 1 goes
         // to the other one, whose last readers (ff2 of chunk c - 1) all passed the barrier above before any wave got here
-        if (NH == 1) lds_barrier();
+        if (NH == 1) LDS_BARRIER();
     }
     // t3 = acc2 + b2 + t2 -> A ; X <- x_in rows (residual of proj_out)
     {
@@ -486,7 +494,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTail
                 for (int e = 0; e < 4; ++e) tv[e] = (f16)(acc2[0][i][4 * g + e] + b4[e] + (float)xr[e]);
                 *reinterpret_cast<f16x4*>(Ab + epi_off + i * 32 * LDB + g * 16) = tv;
             }
-        lds_barrier();      // t3 complete in A; every lane has read its t2 elements of X
+        LDS_BARRIER();      // t3 complete in A; every lane has read its t2 elements of X
 #pragma unroll
         for (int k = 0; k < (BM * CPR + NT - 1) / NT; ++k) {
             const int idx = tid + k * NT;
@@ -501,7 +509,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTail
     // ---- S6: out = t3 Wpo^T + bpo + x_in -> H -> global (+ per-column {sum, sumsq} of this row block for the next GroupNorm)
     zero_acc(acc1);
     unit<C, TM, 1>(acc1, Ab + lane_row_off, ring, rs_w, voff, piece);
-    lds_barrier();          // X (x_in rows) written by every thread
+    LDS_BARRIER();          // X (x_in rows) written by every thread
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -514,7 +522,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTail
             for (int e = 0; e < 4; ++e) ov[e] = (f16)(acc1[0][i][4 * g + e] + b4[e] + (float)xr[e]);
             *reinterpret_cast<f16x4*>(Hb + epi_off + i * 32 * LDB + g * 16) = ov;
         }
-    lds_barrier();
+    LDS_BARRIER();
     for (int idx = tid; idx < BM * CPR; idx += NT) {
         const int row = idx / CPR, ch = idx - row * CPR;
         *reinterpret_cast<f16x8*>(p.out + (size_t)(m0 + row) * C + ch * 8) = *reinterpret_cast<const f16x8*>(Hb + row * LDB + ch * 16);
@@ -536,6 +544,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTail
             p.colstats_out[((size_t)blockIdx.x * C + c) * 2 + (i & 1)] = a;
         }
     }
+    if (p.stop_after == ST_COUNT_BARRIERS && blockIdx.x == 0 && tid == 0) *reinterpret_cast<int*>(p.dbg) = nbar;
 }
 
 template <int C, int TM, int D>
@@ -543,11 +552,10 @@ void launch_tail(const StTailParams& p, hipStream_t st) {
     constexpr int NW = C / 32, BM = 32 * TM;
     constexpr size_t lds = (size_t)(TM == 1 ? 4 : 3) * BM * (C + 8) * 2 + (size_t)VecOff<C>::total * 4 + (size_t)NW * BM * 8;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static MdxPerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&st_tail_kernel<C, TM, D>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL((st_tail_kernel<C, TM, D>), dim3(p.M / BM), dim3((NW + 1) * 64), lds, st, p);
 }
@@ -603,6 +611,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_head_kernel(const StHead
     float2* csum = reinterpret_cast<float2*>(vec + 5 * C);      // [C] channel {sum, sumsq}, then {scale, shift}
     float2* part = csum + C;                                    // [NW][BM]
 
+    int nbar = 0;       // block barriers executed by this (compute) wave: LDS_BARRIER
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -659,7 +668,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_head_kernel(const StHead
         sq += __shfl_xor(sq, 1, 64);
         if (half == 0) csum[c] = make_float2(su, sq);
     }
-    lds_barrier();
+    LDS_BARRIER();
     {
         const int c = tid >> 1;
         const int g = c / CPG;
@@ -676,10 +685,10 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_head_kernel(const StHead
         var = var < 0.f ? 0.f : var;
         const float a = vec[c] * rsqrtf(var + p.gn_eps);
         const float sh = vec[C + c] - mean * a;
-        lds_barrier();          // every thread has read the channel sums
+        LDS_BARRIER();          // every thread has read the channel sums
         if ((tid & 1) == 0) csum[c] = make_float2(a, sh);
     }
-    lds_barrier();
+    LDS_BARRIER();
 #pragma unroll
     for (int k = 0; k < XL; ++k) {
         const int idx = tid + k * NT;
@@ -694,12 +703,12 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_head_kernel(const StHead
             *reinterpret_cast<f16x8*>(Ab + row * LDB + ch * 16) = y;
         }
     }
-    lds_barrier();
+    LDS_BARRIER();
 
     const int lane_row_off = l31 * LDB + hi * 16;
     const int epi_off = l31 * LDB + (n0 + 4 * hi) * 2;
     auto dump = [&](const char* buf) {
-        lds_barrier();
+        LDS_BARRIER();
         for (int idx = tid; idx < BM * CPR; idx += NT) {
             const int row = idx / CPR, ch = idx - row * CPR;
             *reinterpret_cast<f16x8*>(p.dbg + (size_t)(m0 + row) * C + ch * 8) =
@@ -737,7 +746,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_head_kernel(const StHead
             sq += __shfl_xor(sq, 32, 64);
             if (hi == 0) part[wave * BM + i * 32 + l31] = make_float2(su, sq);
         }
-        lds_barrier();
+        LDS_BARRIER();
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float su = 0.f, sq = 0.f;
@@ -763,7 +772,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_head_kernel(const StHead
                 *reinterpret_cast<f16x4*>(Xb + epi_off + i * 32 * LDB + g * 16) = th[i][g];
             }
         }
-        lds_barrier();
+        LDS_BARRIER();
     }
     if (p.stop_after == 2) { dump(Xb); return; }
     if (p.stop_after == 3) { dump(Ab); return; }
@@ -781,7 +790,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_head_kernel(const StHead
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<f16x4*>(buf + epi_off + i * 32 * LDB + g * 16) =
                     f16x4{(f16)acc[0][i][4 * g], (f16)acc[0][i][4 * g + 1], (f16)acc[0][i][4 * g + 2], (f16)acc[0][i][4 * g + 3]};
-        lds_barrier();
+        LDS_BARRIER();
     };
     auto store_rows = [&](const char* buf, int col0) {
         for (int idx = tid; idx < BM * CPR; idx += NT) {
@@ -812,6 +821,7 @@ __global__ __launch_bounds__((C / 32 + 1) * 64) void st_head_kernel(const StHead
             *reinterpret_cast<f16x8*>(p.vt + ((size_t)b * C + c) * p.vt_ld + tok0 + j * 8) = v;
         }
     }
+    if (p.stop_after == ST_COUNT_BARRIERS && blockIdx.x == 0 && tid == 0) *reinterpret_cast<int*>(p.dbg) = nbar;
 }
 
 template <int C, int TM>
@@ -819,11 +829,10 @@ void launch_head(const StHeadParams& p, hipStream_t st) {
     constexpr int NW = C / 32, BM = 32 * TM;
     constexpr size_t lds = (size_t)3 * BM * (C + 8) * 2 + (size_t)5 * C * 4 + (size_t)C * 8 + (size_t)NW * BM * 8;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static MdxPerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&st_head_kernel<C, TM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL((st_head_kernel<C, TM>), dim3(p.M / BM), dim3((NW + 1) * 64), lds, st, p);
 }
@@ -885,6 +894,17 @@ extern "C" int mdx_st_tail_f16(const mdx_st_tail_desc* d, mdx_stream_t s) {
     }
     MDX_LAUNCH_CHECK("mdx_st_tail_f16");
     return MDX_OK;
+}
+
+// Barriers in the warmer wave's schedule for this launch form (tests compare it with what the compute waves execute).
+extern "C" int mdx_st_tail_sched_barriers(int C, int tile_rows) {
+    if (C != 320) return -1;
+    return tile_rows == 64 ? make_sched<320 / 16, 1>().n : make_sched<320 / 16, 2>().n;
+}
+extern "C" int mdx_st_head_sched_barriers(int C, int tile_rows) {
+    (void)tile_rows;
+    if (C != 320) return -1;
+    return make_head_sched<320 / 16>().n;
 }
 
 extern "C" size_t mdx_st_head_stream_bytes(int C) { return (size_t)(C / 32) * (4 * (C / 16)) * 1024; }

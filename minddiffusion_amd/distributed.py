@@ -55,15 +55,41 @@ def shard_bounds(global_batch, rank, world_size):
     return rank * per, (rank + 1) * per
 
 
+# What the collectives of this process did: bench.py --gpus N reports it so that a scaling record can PROVE which backend moved
+# how many bytes over how many ranks.  calls / bytes / ms of the broadcasts since the last reset; ms is
+# bracketed by HIP events on the current stream for device payloads, by the host clock for host payloads.
+collective_stats = {"broadcasts": 0, "bytes": 0, "ms": 0.0, "last_ms": 0.0}
+
+
+def reset_collective_stats():
+    collective_stats.update(broadcasts=0, bytes=0, ms=0.0, last_ms=0.0)
+
+
 def _broadcast(payload, src):
     """The one collective.  RCCL moves device buffers directly; gloo (CPU tests, or several ranks sharing one GPU in the
     single-GPU parity test) stages a device payload through the host."""
-    if dist.get_backend() == "gloo" and payload.is_cuda:
+    import time
+    on_dev = payload.is_cuda
+    if on_dev:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    t0 = time.perf_counter()
+    if dist.get_backend() == "gloo" and on_dev:
         host = payload.cpu()
         dist.broadcast(host, src=src)
         payload.copy_(host)
     else:
         dist.broadcast(payload, src=src)
+    if on_dev:
+        e1.record()
+        e1.synchronize()       # the receivers read the header right after this call anyway
+        ms = e0.elapsed_time(e1)
+    else:
+        ms = (time.perf_counter() - t0) * 1e3
+    collective_stats["broadcasts"] += 1
+    collective_stats["bytes"] += payload.numel() * payload.element_size()
+    collective_stats["ms"] += ms
+    collective_stats["last_ms"] = ms
 
 
 def broadcast_conditioning(c, uc, x_T, global_batch, ctx_shape, latent_shape, device, src=0, dtype=torch.float16,

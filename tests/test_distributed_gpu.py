@@ -165,3 +165,8 @@ def test_bench_two_ranks_contract():
     assert d["config"]["global_batch"] == 2 and d["config"]["parallelism"].endswith("x2")
     assert abs(d["value"] - 2 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
     assert d["cpu_baseline"] is None and d["roofline"]["frac"] > 0
+    # the N > 1 record proves itself: backend, world size, the ONE collective per trajectory and what it moved
+    c = d["config"]
+    assert c["dist_backend"] == "gloo" and c["rccl_world_size"] == 2 and c["broadcasts_per_step"] == 1
+    assert c["broadcast_bytes"] > 2 * 77 * 1024 * 2 and c["broadcast_ms"] > 0
+    assert 0 < c["per_rank_units_per_s"]["min"] <= c["per_rank_units_per_s"]["max"]

@@ -337,6 +337,47 @@ def test_gemm_release_counters(ops):
     check("gemm_release_counters_M256_N640_K2560_s3", out.float().cpu(), ref, rel_l2=1e-3)
 
 
+def test_gemm_release_workspace_reuses_the_counters_under_a_recaptured_graph(ops):
+    """include/mdx.h mdx_gemm_release_workspace: a workspace that is dropped hands its arrival counters back, the next workspace
+    (another address) takes the SAME set, and a graph captured on it replays bit-stably -- the case of a server that plans at many
+    resolutions (round-3 review: every distinct workspace address used to pin 16 KiB for good)."""
+    from minddiffusion_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(23)
+    M, N, K = 256, 640, 2560
+    a = dev16(h16(rng.standard_normal((M, K))))
+    w = pack_dense(h16(rng.standard_normal((N, K)) / math.sqrt(K)))
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    n_ws = 16384 // 4 + 3 * 256 * 640 + 64
+    ws1 = torch.full((n_ws,), float("nan"), dtype=torch.float32, device=DEV)
+    d1 = ops.make_gemm_desc(a, w, N, M, 1, 1, K, out, N, splitk=3, workspace=ws1)
+    assert ops.gemm_query(d1)[6] == 1
+    ops.gemm_run(d1)
+    torch.cuda.synchronize()
+    first = out.clone()
+    assert lib.mdx_gemm_release_workspace(ctypes_ptr(ws1)) == 1
+    assert lib.mdx_gemm_release_workspace(ctypes_ptr(ws1)) == 0          # already released
+    ws2 = torch.full((n_ws + 1024,), float("nan"), dtype=torch.float32, device=DEV)      # a different buffer
+    assert ws2.data_ptr() != ws1.data_ptr()
+    d2 = ops.make_gemm_desc(a, w, N, M, 1, 1, K, out, N, splitk=3, workspace=ws2)
+    ops.gemm_run(d2)                                    # first use outside the capture: takes the released set
+    torch.cuda.synchronize()
+    g = ops.capture_graph([lambda: ops.gemm_run(d2), lambda: ops.gemm_run(d2)])
+    for _ in range(20):
+        out.zero_()
+        ws2.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, first)
+    del g
+    assert lib.mdx_gemm_release_workspace(ctypes_ptr(ws2)) == 1
+
+
+def ctypes_ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def test_gemm_two_source_1x1(ops):
     """ResBlock skip_connection on the (virtual) concat of h and the UNet skip tensor (openaimodel.py:174,568)."""
     rng = np.random.RandomState(5)

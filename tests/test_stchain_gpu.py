@@ -300,3 +300,22 @@ def test_st_head_statistic_block_sizes(ops):
     for rows in (32, 64, 256):
         got = run_head(ops, w, x, B, tokens, C, 32, rows, 1)
         check(f"st_head_stats_rows{rows}", got, ref16[1], rel_l2=1e-3, max_rel=6e-3)
+
+
+@pytest.mark.parametrize("tile_rows", [32, 64])
+def test_warmer_schedules_match_the_compute_waves(ops, tile_rows):
+    """The L2 warmer wave of the fused kernels walks a HAND-MIRRORED schedule of the compute waves' block barriers
+    (csrc/stchain.hip make_sched / make_head_sched): one barrier more or less on either side deadlocks the product launch.
+    debug_stage = MDX_ST_DEBUG_COUNT_BARRIERS (100) runs the whole chain without the warmer and reports how many barriers the
+    compute waves executed; it must equal the length of the schedule the warmer would walk."""
+    from minddiffusion_amd import _lib
+    lib = _lib.load()
+    B, tokens, C, heads, ctx_len = 1, 128, 320, 5, 77
+    w, x = make_case(5, B, tokens, C, heads, ctx_len, 1024)
+    dbg, _ = run_fused(ops, w, x, B, tokens, C, heads, ctx_len, tile_rows, stage=100)
+    n_tail = int(dbg.view(torch.int32).reshape(-1)[0])
+    assert n_tail == lib.mdx_st_tail_sched_barriers(C, tile_rows), (n_tail, lib.mdx_st_tail_sched_barriers(C, tile_rows))
+    wh, xh = make_head_case(6, B, tokens, C)
+    dbg = run_head(ops, wh, xh, B, tokens, C, tile_rows, 32, stage=100)
+    n_head = int(dbg.view(torch.int32).reshape(-1)[0])
+    assert n_head == lib.mdx_st_head_sched_barriers(C, tile_rows), (n_head, lib.mdx_st_head_sched_barriers(C, tile_rows))
