@@ -161,14 +161,15 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     # The library reads no environment variables (include/mdx.h: mdx_set_option).  The MDX_* variables the tools and the
-    # experiment scripts under tools/exp/ pass are translated HERE, once, at load time.
+    # experiment scripts under tools/exp/ pass are translated HERE, once, at load time -- BEFORE the handle is cached, so that a
+    # bad value does not leave a half-configured library behind for later calls.
     for env, (name, conv) in _ENV_OPTIONS.items():
         if env in os.environ:
             rc = lib.mdx_set_option(name.encode(), conv(os.environ[env]))
             if rc != 0:
                 raise MdxError(f"{env}: {lib.mdx_last_error().decode()}")
+    _lib = lib
     return lib
 
 

@@ -62,7 +62,12 @@ constexpr size_t c8_lds_bytes() {
 // rows {y - 1 + dy, y + dy}, columns {x - 1 + dx, x + dx} -- 4 Cin instead of 9 Cin multiply-adds per output and a gather on the
 // un-upsampled tensor.  An M tile is (low-resolution 16 x 16 patch, parity): the same halo, taps (dy + a, dx + b), weight rows
 // parity * N + n, and an epilogue row map that interleaves the parities into the 2H x 2W output (pixel shuffle).
-template <int BN, int PH, int TAPS>
+// VAR: bit 0 = the DMA instructions of a batch are issued BETWEEN the MFMAs of the burst (one per 16 x BN/2 row of MFMAs: an LDS-DMA
+// issue hides in an MFMA gap) instead of in front of it -- the product form; bit 1 = no s_setprio; bit 2 = no stagger (both halves in
+// step).  Measured on MI355X (tools/conv8p_bench.py --vars, profiles/r04_conv8p_variants.txt; 256 x 160 tiles, K = 2880 ... 11520):
+// DMA in front 1183 / 1313 / 1369 TF/s -> between the MFMAs 1208 / 1342 / 1409 (+2-3 %); s_setprio neutral (+-0.3 %); WITHOUT the
+// half-phase stagger 1044 / 1167 / 1213 (-12 %): the stagger is what the structure buys.
+template <int BN, int PH, int TAPS, int VAR = 1>
 __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     constexpr int NJ = BN / 32;              // 16-column MFMA tiles per wave (a wave owns BN / 2 columns)
     constexpr int B_BYTES = BN * 128;
@@ -148,12 +153,13 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
         const int n = (TAPS == 4 ? (par_dy * 2 + par_dx) * p.N : 0) + n0 + (jb * 8 + wave) * 8 + lrow;
         b_off[jb] = (unsigned)(((size_t)(n >> 6) * p.kt64) * 8192 + ((n & 63) * 8 + lchk) * 16);
     }
+    auto dma_b1 = [&](int jb, int kt, int stage) {
+        if (jb * 8 + wave >= BINST) return;                    // wave-uniform
+        dma16(rs_w, smem + C8_RING + stage * B_BYTES + (jb * 8 + wave) * 1024, b_off[jb] + (unsigned)kt * 8192u);
+    };
     auto dma_b = [&](int kt, int stage) {
 #pragma unroll
-        for (int jb = 0; jb < BJ; ++jb) {
-            if (jb * 8 + wave >= BINST) continue;              // wave-uniform
-            dma16(rs_w, smem + C8_RING + stage * B_BYTES + (jb * 8 + wave) * 1024, b_off[jb] + (unsigned)kt * 8192u);
-        }
+        for (int jb = 0; jb < BJ; ++jb) dma_b1(jb, kt, stage);
     };
 
     f32x4v acc[4][NJ];
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     dma_b(c_begin * TAPS + 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (wn == 1) __builtin_amdgcn_s_barrier();          // the N = 1 half runs one barrier (half a phase) behind
+    if (wn == 1 && !(VAR & 4)) __builtin_amdgcn_s_barrier();          // the N = 1 half runs one barrier (half a phase) behind
 
     int t = c_begin * TAPS;
     int rd = 0;                              // ring stage of K tile t (TAPS = 9: tap % 3, static; TAPS = 4: rotates across chunks)
@@ -221,7 +227,17 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                if (sub == 0) {
+                // the k-th DMA instruction of this tap's batch: weights of tap t + 2, then the halo slice(s) of the next chunk
+                auto issue = [&](int k) {
+                    if (k < BJ) {
+                        if (t + 2 < nt) dma_b1(k, t + 2, st_w);
+                    } else if (TAPS == 9) {
+                        if (k == BJ && more && tap < 6) dma_halo(tap, c + 1, hb ^ 1);
+                    } else if (k < BJ + 2) {
+                        if (more && tap < 3) dma_halo(2 * tap + (k - BJ), c + 1, hb ^ 1);
+                    }
+                };
+                if (sub == 0 && !(VAR & 1)) {
                     if (t + 2 < nt) dma_b(t + 2, st_w);
                     if constexpr (TAPS == 9) {
                         if (more && tap < 6) dma_halo(tap, c + 1, hb ^ 1);
@@ -233,22 +249,30 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_s_setprio(1);
+                if (!(VAR & 2)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int u = 0; u < PH; ++u)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i) {
 #pragma unroll
                         for (int j = 0; j < NJ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[u][j], af[u][i], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                        if constexpr ((VAR & 1) != 0) {
+                            if (sub == 0 && u * 4 + i < BJ + 2) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue(u * 4 + i);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                if (!(VAR & 2)) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
             }
             if constexpr (TAPS != 9) rd = rd == 2 ? 0 : rd + 1;
         }
     }
-    if (wn == 0) __builtin_amdgcn_s_barrier();          // both halves level again; every wave is done with the halos and the ring
+    if (wn == 0 && !(VAR & 4)) __builtin_amdgcn_s_barrier();          // both halves level again; every wave is done with the halos and the ring
 
     if (TAPS == 9 && p.skip_w && split == nsplit - 1) {      // (block-uniform) the last split -- the one with the fewest chunks -- takes the skip tiles
         // ---- ResBlock skip_connection (openaimodel.py:174, 201-205): conv1x1 over the block's RAW input as extra dense K tiles
@@ -461,14 +485,14 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     }
 }
 
-template <int BN, int PH, int TAPS = 9>
+template <int BN, int PH, int TAPS = 9, int VAR = 1>
 void c8_launch(const GemmParams& p, dim3 grid, hipStream_t st) {
     constexpr size_t lds = c8_lds_bytes<BN>();
     static MdxPerDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel<BN, PH, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel<BN, PH, TAPS, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL((conv8p_kernel<BN, PH, TAPS>), grid, dim3(C8_NT), lds, st, p);
+    hipLaunchKernelGGL((conv8p_kernel<BN, PH, TAPS, VAR>), grid, dim3(C8_NT), lds, st, p);
 }
 
 }  // namespace
@@ -605,7 +629,15 @@ int mdx_conv8p_launch(const GemmParams& pin, int bn, hipStream_t st) {
         case 64: c8_launch<64, 2>(p, grid, st); break;
         case 96: c8_launch<96, 2>(p, grid, st); break;
         case 128: c8_launch<128, 2>(p, grid, st); break;
-        case 160: if (p.st_hint == 9) c8_launch<160, 1>(p, grid, st); else c8_launch<160, 2>(p, grid, st); break;
+        case 160:
+            if (p.st_hint == 9) c8_launch<160, 1>(p, grid, st);
+            else switch (mdx_opt(MDX_OPT_GEMM_CONV8P_VAR)) {      // experiment forms (VAR above); 0 = the product
+                case 1: c8_launch<160, 2, 9, 0>(p, grid, st); break;      // DMA issue in front of the MFMA burst
+                case 2: c8_launch<160, 2, 9, 3>(p, grid, st); break;      // no s_setprio
+                case 4: c8_launch<160, 2, 9, 5>(p, grid, st); break;      // no stagger
+                default: c8_launch<160, 2>(p, grid, st); break;
+            }
+            break;
         case 192: c8_launch<192, 1>(p, grid, st); break;      // 96 accumulator + 80 fragment registers do not fit two waves per SIMD
         default:
             mdx_set_error("mdx_gemm_f16: conv8p has no %d-column tile", bn);

@@ -69,6 +69,7 @@ enum MdxOpt {
     MDX_OPT_GEMM_DENSE8P,        // (default 0: measured equal-or-slower inside a UNet evaluation, tools/eval_ab.py) 1: eligible dense launches with M >= gemm_dense8p_min_m and >= 128 tiles run on the 256 x 128 8-wave core (gemm8p.hip)
     MDX_OPT_GEMM_DENSE8P_MIN_M,  // (4096)
     MDX_OPT_GEMM_SUBPIXEL_MIN_TILES,   // nearest-2x + 3x3 convs with w_sub run the sub-pixel form from this many 256-pixel tiles (32)
+    MDX_OPT_GEMM_CONV8P_VAR,     // experiment forms of the 160-column conv8p kernel (conv8p.hip VAR; 0 = the product)
     MDX_OPT_COUNT
 };
 int mdx_opt(int id);

@@ -555,6 +555,8 @@ class UNetModel:
             ops.set_option("unet_st_tail", 0 | 32 | 64) forces a choice (0 = never)."""
             if (t + "tail.stream") not in w or self.transformer_depth != 1:
                 return 0
+            if TC > 96 or TC % 8:       # mdx_st_tail_f16 holds the context keys in registers: capacity <= 96, multiple of 8
+                return 0                # (a UNet built with a longer max_context_len keeps the unfused launches, any length)
             forced = ops.get_option("unet_st_tail")
             cands = [forced] if forced in (32, 64) else ([] if forced == 0 else [64, 32])
             for r in cands:

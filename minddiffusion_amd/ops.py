@@ -449,7 +449,9 @@ def gemm_shape_key(d):
     var = ((1 if d.c2 > 0 else 0) | (d.epilogue << 1) | (8 if d.n_split else 0) | (16 if d.ln_stats else 0)
            | (32 if d.stats_out else 0) | (64 if d.out_mode == 1 else 0) | (128 if d.colstats_out else 0)
            | (256 if d.residual else 0) | (512 if d.rowbias else 0) | (1024 if d.skip_w else 0) | (2048 if d.gn_gamma else 0))
-    return (d.B * d.H * d.W, d.N, d.ksize * d.ksize * (d.c1 + d.c2), d.ksize, d.stride, d.upsample, var)
+    # B, H, W are part of the key: HALO eligibility, patch geometry (16-wide patches vs the 8 x 8 two-sample form) and the
+    # eight-wave cores' tile counts depend on them, not only on M = B H W
+    return (d.B * d.H * d.W, d.N, d.ksize * d.ksize * (d.c1 + d.c2), d.ksize, d.stride, d.upsample, var, d.B, d.H, d.W)
 
 
 def gemm_tune(desc, reps=5, cold=True):
@@ -483,7 +485,10 @@ def tune_untuned(descs, reps=5):
             tune_cache[key] = gemm_tune(d, reps)
             measured += 1
         tm, tn, sk, stg = tune_cache[key][:4]
+        old = (d.tile_m, d.tile_n, d.splitk, d.stages)
         d.tile_m, d.tile_n, d.splitk, d.stages = tm, tn, sk, stg
+        if _lib.load().mdx_gemm_check(ctypes.byref(d)) != 0:      # a cached form this descriptor cannot take (e.g. a loaded cache)
+            d.tile_m, d.tile_n, d.splitk, d.stages = old
     return measured
 
 
@@ -646,6 +651,8 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
             meta[c["meta"]]["launches"] = 1   # the one-launch fused kernel (norm.hip groupnorm_impl)
             continue
 
+        fresh = []      # producers wired by THIS GroupNorm (undone if its other source cannot supply statistics)
+
         def stats_of(d, cx):
             if isinstance(d, _lib.StTailDesc):      # fused SpatialTransformer tail: per-row-block column sums of its output
                 key = ctypes.addressof(d)
@@ -656,6 +663,7 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
                     buf = torch.zeros((batch * (HW // rows), cx, 2), dtype=f32, device=device)
                     d.colstats_out = buf.data_ptr()
                     table[key] = (buf, HW // rows)
+                    fresh.append((key, d))
                 return table[key]
             if d is None or d.N != cx or d.out_ld != cx or d.defer_reduce:
                 return None
@@ -682,6 +690,7 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
                 return None
             else:
                 table[key] = (buf, HW // rows)
+            fresh.append((key, d))
             return table[key]
         s1 = stats_of(c["prod"][0], C1)
         if is_head:
@@ -692,6 +701,13 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
             continue
         s2 = stats_of(c["prod"][1], C2) if C2 else (None, 0)
         if s1 is None or s2 is None:
+            # one source cannot supply statistics: the GroupNorm takes the two-launch path, and a producer that was wired only
+            # for it must not keep paying for the statistics epilogue (nor resolve to that launch variant's tile-table row)
+            for key, d in fresh:
+                table.pop(key, None)
+                d.colstats_out = 0
+                if hasattr(d, "colstats_cap"):
+                    d.colstats_cap = 0
             continue
         c["cs"] = (s1[0], s1[1], s2[0], s2[1])
         meta[c["meta"]]["launches"] = 1 + isinstance(s1[0], FoldedColStats) + isinstance(s2[0], FoldedColStats)

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--bns", default="0", help="comma list of conv8p N tiles to try (0 = the library's pick)")
     ap.add_argument("--extra", default="", help="comma list of stages:tile_n forms (stages 9 = one phase per k-step)")
+    ap.add_argument("--vars", default="", help="comma list of gemm_conv8p_var experiment forms to time at BN 160")
     args = ap.parse_args()
     from minddiffusion_amd import ops
     dev = torch.device("cuda:0")
@@ -82,11 +83,14 @@ def main():
         for x in [x for x in args.extra.split(",") if x]:       # e.g. "9:160" = one phase per k-step at BN 160
             st, bn = x.split(":")
             forms[f"c8_st{st}_bn{bn}"] = dict(tile_m=256, stages=int(st), tile_n=int(bn))
+        for v in [int(x) for x in args.vars.split(",") if x]:
+            forms[f"c8_var{v}"] = dict(tile_m=256, stages=8, tile_n=160)
         timings = {k: [] for k in forms}
         descs = {}
         wsp = None
         def route(k):       # the "old" arm is the library's choice with the eight-wave core switched off
             ops.set_option("gemm_conv8p", 0 if k == "old" else 1)
+            ops.set_option("gemm_conv8p_var", int(k[6:]) if k.startswith("c8_var") else 0)
         for k, kw in forms.items():
             route(k)
             descs[k] = [ops.make_gemm_desc(a, w, cout, B, H, W, cin, out, cout, bias=bias, ksize=3, rowbias=emb, rowbias_ld=cout,
@@ -121,6 +125,7 @@ def main():
             continue
         finally:
             ops.set_option("gemm_conv8p", 1)
+            ops.set_option("gemm_conv8p_var", 0)
         flops = 2.0 * M * cout * (K + skc)
         rec = dict(name=name, M=M, N=cout, K=K, skip=skc)
         line = f"{name:26s} M={M:6d} N={cout:4d} K={K:5d}"
