@@ -265,6 +265,12 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
                             }
                         }
                     }
+                if constexpr ((VAR & 1) != 0 && PH * 4 < BJ + 2) {      // more DMA instructions than MFMA rows in a phase: the rest behind the burst
+                    if (sub == 0) {
+#pragma unroll
+                        for (int k = PH * 4; k < BJ + 2; ++k) issue(k);
+                    }
+                }
                 if (!(VAR & 2)) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -616,6 +622,7 @@ int mdx_conv8p_launch(const GemmParams& pin, int bn, hipStream_t st) {
         p.kt64 = (p.cin >> 6) * 4;
         switch (bn) {
             case 64: c8_launch<64, 2, 4>(p, grid, st); break;
+            case 96: c8_launch<96, 2, 4>(p, grid, st); break;
             case 128: c8_launch<128, 2, 4>(p, grid, st); break;
             case 160: c8_launch<160, 2, 4>(p, grid, st); break;
             case 192: c8_launch<192, 1, 4>(p, grid, st); break;

@@ -196,6 +196,9 @@ class Text2ImUNet:
                 w[pre + "n2.b"] = self._dev(P[pre + "out_layers_0.beta"], f32)
                 w[pre + "conv1.w"] = self._conv(P[pre + "in_layers_2.conv.weight"])
                 w[pre + "conv1.b"] = self._dev(P[pre + "in_layers_2.conv.bias"], f32)
+                if len(layer) > 3 and layer[3] == "up" and cin % 64 == 0 and cout % 64 == 0 and ops.get_option("unet_subpixel_upsample"):
+                    # the up-sampling ResBlock's conv1 follows a nearest-2x (unet.py:178-218): sub-pixel weights (mdx_gemm_desc.w_sub)
+                    w[pre + "conv1.wsub"] = ops.pack_subpixel_conv_weight(self._dev(P[pre + "in_layers_2.conv.weight"], f32))
                 w[pre + "conv2.w"] = self._conv(P[pre + "out_layers_3.conv.weight"])
                 w[pre + "conv2.b"] = self._dev(P[pre + "out_layers_3.conv.bias"], f32)
                 if cin != cout:
@@ -340,7 +343,7 @@ class Text2ImUNet:
                  out_mode=out_mode, out_bs=out_bs)
             return out
 
-        def conv3(src, cin, cout, wt, bias, h, wd, upsample=0, residual=None, skip=None):
+        def conv3(src, cin, cout, wt, bias, h, wd, upsample=0, residual=None, skip=None, wsub=None):
             """skip = (x, x2, c1, c2, packed 1x1 weights): the ResBlock's skip_connection rides on this launch as extra K tiles
             (mdx_gemm_desc.skip_w, as in the latent-diffusion planner); `bias` then holds the sum of both convs' biases."""
             ho, wo = (2 * h, 2 * wd) if upsample else (h, wd)
@@ -348,6 +351,8 @@ class Text2ImUNet:
             kw = {}
             if skip is not None:
                 kw = dict(skip_a=skip[0], skip_a2=skip[1], skip_c1=skip[2], skip_c2=skip[3], skip_w=skip[4])
+            if wsub is not None:
+                kw["w_sub"] = wsub
             gemm(a=src, w=wt, N=cout, B=B, H=h, W=wd, c1=cin, out=out, out_ld=cout, bias=bias, residual=residual,
                  residual_ld=cout if residual is not None else 0, ksize=3, upsample=upsample, **kw)
             if skip is not None:
@@ -405,7 +410,8 @@ class Text2ImUNet:
             gn(x, x2, w[pre + "n1.g"], w[pre + "n1.b"], True, a)
             if mode == "up":
                 assert x2 is None and cin == cout
-                hbuf, ho, wo = conv3(a, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd, upsample=1)
+                hbuf, ho, wo = conv3(a, cin, cout, w[pre + "conv1.w"], w[pre + "conv1.b"], h, wd, upsample=1,
+                                     wsub=w.get(pre + "conv1.wsub"))
                 xs = A.get((B, ho * wo, cin))
                 emit(lambda x=x, xs=xs: ops.upsample_nearest2x(x, B, h, wd, cin, out=xs), "small")
             elif mode == "down":

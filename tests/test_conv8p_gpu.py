@@ -242,7 +242,8 @@ def test_conv8p_phase_per_kstep_form_is_bit_identical(ops):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,cs", [(1, 16, 16, 64, 64, False), (2, 32, 16, 128, 320, True), (2, 32, 32, 640, 640, True),
-                                                (8, 48, 48, 128, 128, False)])
+                                                (8, 48, 48, 128, 128, False), (2, 32, 32, 192, 192, True), (2, 16, 32, 128, 384, False),
+                                                (1, 32, 32, 192, 576, False)])
 def test_conv8p_subpixel_upsample_conv(ops, B, H, W, Cin, Cout, cs):
     """mdx_gemm_desc.w_sub: nearest-2x + conv3x3 (Upsample.construct, openaimodel.py:57-60) as four 2 x 2 convs of the low-resolution
     tensor with pre-summed taps (one fp16 rounding of the summed weights instead of separate products: within the usual 1e-3 of the
