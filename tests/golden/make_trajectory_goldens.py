@@ -114,7 +114,8 @@ def _ldm_case(name, ocfg_name, inp, with_emu=True):
     ref, inter = O.sample(model, inp["S"], 1, (4, hw, hw), inp["c"][:1], inp["x_T"][:1], inp["sampler"], log_every_t=10, **kw)
     calls = model.calls
     out = dict(final=ref.numpy().astype(np.float16), pred_x0=inter["pred_x0"][-1].numpy().astype(np.float16),
-               x_inter=np.stack([x.numpy() for x in inter["x_inter"]]).astype(np.float16),
+               x_inter=np.stack([x.numpy() for x in (inter["x_inter"][0], inter["x_inter"][len(inter["x_inter"]) // 2],
+                                                     inter["x_inter"][-1])]).astype(np.float16),
                final_f32_norm=np.float64(ref.double().norm()))
     meta = dict(name=name, oracle_cfg=ocfg_name, unet_seed=inp["seed"], S=inp["S"], sampler=inp["sampler"], scale=inp["scale"],
                 latent=hw, unet_calls=calls, commit=_commit(), oracle_seconds=round(time.time() - t0, 1))
