@@ -138,7 +138,8 @@ _ENV_OPTIONS = {
     "MDX_GN_FUSED": ("gn_fused", int), "MDX_GN_COL_CHUNKS": ("gn_col_chunks", int),
     "MDX_GEMM_CONV8P": ("gemm_conv8p", int), "MDX_GEMM_CONV8P_MIN_M": ("gemm_conv8p_min_m", int),
     "MDX_GEMM_DENSE8P": ("gemm_dense8p", int), "MDX_GEMM_DENSE8P_MIN_M": ("gemm_dense8p_min_m", int),
-    "MDX_GEMM_SUBPIXEL_MIN_TILES": ("gemm_subpixel_min_tiles", int),
+    "MDX_GEMM_SUBPIXEL_MIN_TILES": ("gemm_subpixel_min_tiles", int), "MDX_GEMM_CONV8P_VAR": ("gemm_conv8p_var", int),
+    "MDX_ATTN8": ("attn8", int), "MDX_ATTN8_MIN_BLOCKS": ("attn8_min_blocks", int),
 }
 
 

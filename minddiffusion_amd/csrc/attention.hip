@@ -273,6 +273,248 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// attn8 (round 4, MEASURED SLOWER, opt-in through option attn8 = 2): the same flash attention with EIGHT waves per block in two
+// groups half a tile apart -- the structure of conv8p.hip with the softmax in the place of the LDS reads.
+//
+// Hypothesis: PMC (profiles/r02_attention_pmc.md) shows VALU issue on 58 % and the matrix pipe on 38 % of the SIMD cycles, together
+// ~96 % -- as if the softmax of one wave and the MFMAs of the other never overlapped.  So build the overlap: one global phase = one
+// block barrier; group 0 runs its matrix phase M(i) = PV(i-1) + QK^T(i) in even phases and its softmax phase V(i) in odd ones,
+// group 1 the other way round; both groups read the SAME K / V^T tiles (256 queries per block); the PV product of a tile moves into
+// the NEXT matrix phase (its P fragments wait in registers) so that a phase is purely matrix or purely VALU.
+//   phase 2i    : everyone issues the DMA of K(i+1) and V^T(i);  group 0: M(i);  group 1: V(i-1)
+//   phase 2i+1  :                                                 group 0: V(i);  group 1: M(i);   wait for the batch, barrier
+// Result (tools/attn_bench.py, same process, MI355X): 9216 tokens 827 -> 694 TF/s, 4096 tokens at batch 2 594 -> 474, Wukong's
+// 40-wide heads 630 -> 461.  A phase takes ~1500 cycles however it is filled: the ~160 VALU instructions of a tile's softmax ARE the
+// tile time (dependent-issue latency with one issuing wave per SIMD), the matrix phase hides under them in the four-wave kernel
+// already (two independent blocks per CU overlap dynamically, with no barrier coupling their phases), and lock-stepping the two
+// waves of a SIMD only adds the barrier and the max(M, V) of every phase.  The four-wave kernel stays the product; this one is
+// kept, parity-tested, as the record of that measurement.
+template <int D>
+__global__ __launch_bounds__(512) void attn8_kernel(const AttnParams p) {
+    static_assert(D % 8 == 0 && D <= 160, "head dim must be a multiple of 8, <= 160");
+    constexpr int KS = (D + 15) / 16;
+    constexpr int DT = (D + 31) / 32;
+    constexpr int KCH = (2 * KS <= 8) ? 8 : (2 * KS <= 16 ? 16 : 32);
+    constexpr int K_ROWB = KCH * 16;
+    constexpr int K_RPI = 64 / KCH;
+    constexpr int K_INST = BKV / K_RPI;            // K DMA instructions per tile (8 | 16 | 32)
+    constexpr int K_DMA = (K_INST + 7) / 8;        // ... per wave
+    constexpr int K_BYTES = BKV * K_ROWB;
+    constexpr int V_ROWB = 128;
+    constexpr int V_ROWS = DT * 32;
+    constexpr int V_INST = V_ROWS / 8;
+    constexpr int V_DMA = (V_INST + 7) / 8;
+    constexpr int V_BYTES = V_ROWS * V_ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // K[2] | V^T[2]
+    char* const kbuf = smem;
+    char* const vbuf = smem + 2 * K_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 256 + wave * 32;
+
+    const f16* kb = p.k + (size_t)b * p.k_bs + h * D;
+    const f16* vb = p.vt + (size_t)b * p.vt_bs + (size_t)h * D * p.vt_ld;
+    const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(kb, p.k_bytes);
+    const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(vb, p.vt_bytes);
+
+    f16x8 qf[KS];
+    {
+        const int qi = q0 + l31;
+        const f16* qp = p.q + (size_t)b * p.q_bs + (size_t)qi * p.q_ld + h * D + hi * 8;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (qi < p.Nq && s * 16 + hi * 8 < D)
+                qf[s] = *reinterpret_cast<const f16x8*>(qp + s * 16);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[s][e] = (f16)0.f;
+        }
+    }
+    auto kkey = [](int row) { return KCH == 8 ? ((row >> 1) & 7) : (row & 15); };
+    auto dma_k = [&](int t) {
+        char* sb = kbuf + (t & 1) * K_BYTES;
+        const int key0 = t * BKV;
+#pragma unroll
+        for (int j = 0; j < K_DMA; ++j) {
+            const int inst = j * 8 + wave;
+            if (inst >= K_INST) continue;
+            const int row = inst * K_RPI + lane / KCH;
+            const int chunk = (lane % KCH) ^ kkey(row);
+            const int key = key0 + row;
+            const unsigned off = (key < p.Nk && chunk * 8 < D) ? (unsigned)(((size_t)key * p.k_ld + chunk * 8) * 2) : MDX_OOB;
+            dma16(rs_k, sb + inst * 1024, off);
+        }
+    };
+    auto dma_v = [&](int t) {
+        char* sb = vbuf + (t & 1) * V_BYTES;
+        const int key0 = t * BKV;
+#pragma unroll
+        for (int j = 0; j < V_DMA; ++j) {
+            const int inst = j * 8 + wave;
+            if (inst >= V_INST) continue;
+            const int row = inst * 8 + (lane >> 3);
+            const unsigned chunk = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+            const int kc = key0 + (int)chunk * 8;
+            const unsigned off = (row < D && kc < p.vt_ld) ? (unsigned)(((size_t)row * p.vt_ld + kc) * 2) : MDX_OOB;
+            dma16(rs_v, sb + inst * 1024, off);
+        }
+    };
+
+    f32x16 acc_o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
+    f32x16 acc_s[2];
+    f16x8 pf[4];
+    float m_run = -INFINITY, l_run = 0.f;
+    const int vswz = (lane >> 1) & 7;
+    const int krow_l = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int T = p.Nk / BKV;
+
+    // matrix phase of tile i: PV(i - 1) with the P fragments of the previous softmax phase, then S^T(i) = K(i) Q^T
+    auto mphase = [&](int i) {
+        if (i >= 1) {
+            const char* sv = vbuf + ((i - 1) & 1) * V_BYTES;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const f16x8 vf = *reinterpret_cast<const f16x8*>(sv + (d * 32 + l31) * V_ROWB + (((2 * c + hi) ^ vswz) << 4));
+                    acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c], acc_o[d], 0, 0, 0);
+                }
+        }
+        if (i < T) {
+            const char* sk = kbuf + (i & 1) * K_BYTES;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_s[kt][r] = 0.f;
+                const int krow = kt * 32 + krow_l;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + krow * K_ROWB + (((2 * s + hi) ^ kkey(krow)) << 4));
+                    acc_s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], acc_s[kt], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // softmax phase of tile i (the arithmetic of attn_kernel above, unchanged): reference maximum (moved only past 2^8), P in fp16
+    auto vphase = [&](int i) {
+        if (i < 0 || i >= T) return;
+        float mx = acc_s[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc_s[kt][r]);
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float m_cand = fmaxf(m_run, mx);
+        if (__builtin_amdgcn_ballot_w64((m_cand - m_run) * p.scale_log2 > 8.0f)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) * p.scale_log2);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+            m_run = m_cand;
+        }
+        const float mb = m_run * p.scale_log2;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 sc2 = {p.scale_log2, p.scale_log2}, nmb2 = {-mb, -mb};
+        f32x2 psum2 = {0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 x2 = {acc_s[kt][r], acc_s[kt][r + 1]};
+                const f32x2 a2 = __builtin_elementwise_fma(x2, sc2, nmb2);
+                const f32x2 pv2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+                psum2 += pv2;
+                pf[kt * 2 + (r >> 3)][r & 7] = (f16)pv2.x;
+                pf[kt * 2 + (r >> 3)][(r & 7) + 1] = (f16)pv2.y;
+            }
+        l_run += psum2.x + psum2.y;
+    };
+
+    dma_k(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int i = 0; i <= T; ++i) {
+        // ---- phase 2i
+        if (i + 1 < T) dma_k(i + 1);
+        if (i < T) dma_v(i);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 0) {
+            __builtin_amdgcn_s_setprio(1);
+            mphase(i);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            vphase(i - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2i + 1
+        if (grp == 0) {
+            vphase(i);
+        } else {
+            __builtin_amdgcn_s_setprio(1);
+            mphase(i);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the batch of phase 2i (this wave's share) has landed
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- finalize (as attn_kernel): O /= l, per-wave staging in LDS, full-row stores
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    constexpr int OLD = DT * 32 + 8;
+    f16* og = reinterpret_cast<f16*>(smem) + wave * 32 * OLD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (f16)(acc_o[d][4 * g + e] * inv);
+            *reinterpret_cast<f16x4*>(&og[l31 * OLD + d * 32 + 8 * g + 4 * hi]) = v;
+        }
+    __syncthreads();
+    constexpr int CPR = D / 8;
+    for (int idx = lane; idx < 32 * CPR; idx += 64) {
+        const int row = idx / CPR, chunk = idx - row * CPR;
+        const int qi = q0 + row;
+        if (qi < p.Nq) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(&og[row * OLD + chunk * 8]);
+            *reinterpret_cast<f16x8*>(p.o + (size_t)b * p.o_bs + (size_t)qi * p.o_ld + h * D + chunk * 8) = v;
+        }
+    }
+}
+
+template <int D>
+void launch_attn8(const AttnParams& p, dim3 grid, hipStream_t st) {
+    constexpr int KS = (D + 15) / 16, DT = (D + 31) / 32;
+    constexpr int KCH = (2 * KS <= 8) ? 8 : (2 * KS <= 16 ? 16 : 32);
+    constexpr size_t ring = 2 * ((size_t)BKV * KCH * 16 + (size_t)DT * 32 * 128);
+    constexpr size_t ostage = (size_t)8 * 32 * (DT * 32 + 8) * 2;
+    constexpr size_t lds = ring > ostage ? ring : ostage;
+    static MdxPerDeviceOnce attr_once;
+    if (attr_once.first())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn8_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn8_kernel<D>, grid, dim3(512), lds, st, p);
+}
+
 template <int D>
 void launch_attn(const AttnParams& p, dim3 grid, hipStream_t st) {
     constexpr int KS = (D + 15) / 16, DT = (D + 31) / 32;
@@ -315,6 +557,19 @@ static int attention_impl(const void* q, long q_bs, int q_ld, const void* k, lon
     p.vt_bytes = (unsigned)vbytes;
     dim3 grid((Nq + BQ - 1) / BQ, heads, B);
     hipStream_t st = (hipStream_t)s;
+    // eight-wave form (attn8_kernel above; measured slower, opt-in): self-attention shapes, D <= 80 (D = 160 spills at two waves per SIMD)
+    const int a8 = mdx_opt(MDX_OPT_ATTN8);
+    if (a8 && !causal && D <= 80 && Nq % 256 == 0 && Nk % BKV == 0 &&
+        (a8 == 2 || (long)(Nq / 256) * heads * B >= mdx_opt(MDX_OPT_ATTN8_MIN_BLOCKS))) {
+        const dim3 g8(Nq / 256, heads, B);
+        switch (D) {
+            case 40: launch_attn8<40>(p, g8, st); break;
+            case 64: launch_attn8<64>(p, g8, st); break;
+            default: launch_attn8<80>(p, g8, st); break;
+        }
+        MDX_LAUNCH_CHECK("mdx_attention_f16(attn8)");
+        return MDX_OK;
+    }
     switch (D) {
         case 40: launch_attn<40>(p, grid, st); break;
         case 64: launch_attn<64>(p, grid, st); break;

@@ -70,6 +70,8 @@ enum MdxOpt {
     MDX_OPT_GEMM_DENSE8P_MIN_M,  // (4096)
     MDX_OPT_GEMM_SUBPIXEL_MIN_TILES,   // nearest-2x + 3x3 convs with w_sub run the sub-pixel form from this many 256-pixel tiles (32)
     MDX_OPT_GEMM_CONV8P_VAR,     // experiment forms of the 160-column conv8p kernel (conv8p.hip VAR; 0 = the product)
+    MDX_OPT_ATTN8,               // (default 0: measured slower, csrc/attention.hip) 1: self-attention launches with >= attn8_min_blocks 256-query blocks use the eight-wave kernel; 2: always when eligible
+    MDX_OPT_ATTN8_MIN_BLOCKS,    // (192)
     MDX_OPT_COUNT
 };
 int mdx_opt(int id);

@@ -711,6 +711,47 @@ def test_attention_stale_maximum_regime(ops, ramp, D, heads, mode):
     check(f"attention_{mode}_{ramp}_d{D}", out, ref, rel_l2=2e-3, max_abs=2e-2)
 
 
+@pytest.mark.parametrize("ramp", [None] + sorted(RAMPS))
+@pytest.mark.parametrize("D,heads,Nq,Nk", [(64, 2, 256, 256), (64, 5, 1024, 1024), (40, 8, 512, 512), (80, 2, 256, 640), (64, 1, 512, 64),
+                                           (64, 3, 256, 4224)])
+def test_attention_eight_wave_form(ops, ramp, D, heads, Nq, Nk):
+    """attn8_kernel (csrc/attention.hip; opt-in, measured slower than the four-wave kernel): the eight-wave form -- two groups of four waves half a tile apart, PV of a tile deferred
+    into the next matrix phase -- forced (option attn8 = 2) on shapes from one 256-query block up, with i.i.d. scores and with the
+    stale-maximum ramps of the test above (the lazily moved reference maximum and the deferred PV interact: P(i) is produced under
+    the reference of phase V(i) and consumed one phase later, after which O may be rescaled again).  Against the float64 softmax and
+    against the four-wave kernel (same arithmetic per tile: equal to fp16 rounding of O)."""
+    B = 2
+    C = heads * D
+    rng = np.random.RandomState(Nq + Nk + D + (sum(map(ord, ramp)) if ramp else 0))
+    q = h16(0.5 * rng.standard_normal((B, Nq, C)))
+    k = h16(0.5 * rng.standard_normal((B, Nk, C)))
+    v = h16(rng.standard_normal((B, Nk, C)))
+    if ramp:
+        scale_log2 = D ** -0.5 * 1.4426950408889634
+        for hh in range(heads):
+            q[:, :, hh * D + D - 1] = 8.0
+            for j in range(Nk):
+                k[:, j, hh * D + D - 1] = RAMPS[ramp](j // 64) / (8.0 * scale_log2)
+        q, k = h16(q), h16(k)
+    qt, kt, vt_ = [torch.tensor(t, dtype=torch.float64).reshape(B, -1, heads, D).permute(0, 2, 1, 3) for t in (q, k, v)]
+    ref = torch.matmul(torch.softmax(torch.matmul(qt, kt.transpose(2, 3)) * D ** -0.5, -1), vt_).permute(0, 2, 1, 3).reshape(B, Nq, C)
+    vt = np.ascontiguousarray(v.transpose(0, 2, 1))
+    qd, kd, vtd = dev16(q), dev16(k), dev16(vt)
+    outs = {}
+    for form in (2, 0):
+        ops.set_option("attn8", form)
+        try:
+            out = torch.full((B, Nq, C), float("nan"), dtype=torch.float16, device=DEV)
+            ops.attention(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), out.data_ptr(), B, heads, D, Nq, Nk, D ** -0.5,
+                          Nq * C, C, Nk * C, C, C * Nk, Nk, Nq * C, C)
+            torch.cuda.synchronize()
+            outs[form] = out
+        finally:
+            ops.set_option("attn8", 0)
+    check(f"attention8_{ramp}_d{D}_h{heads}_q{Nq}_k{Nk}", outs[2], ref, rel_l2=2e-3, max_abs=2e-2)
+    check(f"attention8_vs_four_wave_{ramp}_d{D}_q{Nq}_k{Nk}", outs[2], outs[0], rel_l2=1e-3)
+
+
 @pytest.mark.parametrize("B,heads,N,D", [(2, 2, 80, 64), (1, 3, 77, 64), (2, 1, 200, 64), (1, 2, 384, 64), (1, 8, 80, 40)])
 def test_attention_causal(ops, B, heads, N, D):
     """mdx_attention_causal_f16: key j is visible to query i iff j <= i (text_encoder.py:136-139); N spans one tile,

@@ -16,6 +16,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="8,5,9216,64;2,5,4096,64;16,8,4096,40;16,10,1024,64")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--forms", default="0,2", help="attn8 option values to time, interleaved (0 = four-wave kernel, 2 = eight-wave)")
+    ap.add_argument("--rounds", type=int, default=3)
     args = ap.parse_args()
     from minddiffusion_amd import ops
     dev = torch.device("cuda:0")
@@ -29,16 +31,27 @@ def main():
         def run():
             ops.attention(qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, h, D, N, N, D ** -0.5,
                           N * 2 * inner, 2 * inner, N * 2 * inner, 2 * inner, inner * N, N, N * inner, inner)
-        run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.iters):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / args.iters
-        print(f"self-attention B={B} heads={h} N={N} D={D}: {us:9.1f} us  {4.0 * B * h * N * N * D / us / 1e6:7.1f} TF/s", flush=True)
+        forms = [int(x) for x in args.forms.split(",")]
+        best = {f: 1e30 for f in forms}
+        try:
+            for _ in range(args.rounds):
+                for f in forms:
+                    ops.set_option("attn8", f)
+                    run()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(args.iters):
+                        run()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    best[f] = min(best[f], e0.elapsed_time(e1) * 1e3 / args.iters)
+        finally:
+            ops.set_option("attn8", 0)
+        line = f"self-attention B={B} heads={h} N={N} D={D}:"
+        for f in forms:
+            line += f"  attn8={f} {best[f]:9.1f} us {4.0 * B * h * N * N * D / best[f] / 1e6:7.1f} TF/s"
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
