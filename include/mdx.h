@@ -274,6 +274,22 @@ int mdx_attention_f16(const void* q, long q_bs, int q_ld, const void* k, long k_
                       long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads, int D, int Nq, int Nk,
                       float scale, mdx_stream_t s);
 
+/* ---- The same attention with the KEY tiles of every (batch, head, 128-query block) item dealt to `kv_splits` blocks
+ *      (attention.py:138-152; flash-decoding style).  For launches whose items do not fill the chip once -- the 64 x 64 and
+ *      32 x 32 self-attentions of a UNet evaluation at batch 2: 320 / 160 items on 256 CUs -- every split block keeps its own
+ *      running (reference, row sum, O), parks the normalised fp16 partial in `ws`, and the last arriver of an item stores
+ *      sum_s w_s O_s / sum_s w_s with w_s = l_s 2^(m_s - max m), summed in split order (schedule-independent bits).
+ * kv_splits : 0 = the library chooses (mdx_attention_ws_bytes tells how much workspace that needs; option attn_kv_split),
+ *             1 = no split (same launch as mdx_attention_f16), 2..8 = that many (each split needs >= 2 key tiles of 64).
+ * ws        : device memory, ZERO on the first use, at least mdx_attention_ws_bytes() bytes for kv_splits = 0 or
+ *             65536 + items * kv_splits * (128 * D * 2 + 1024) bytes otherwise (items = B * heads * ceil(Nq / 128) <= 16384);
+ *             its first 64 KiB hold one arrival counter per item, which every launch leaves at zero -- so one workspace serves all attention launches of a
+ *             stream in turn, but never two streams at once.  NULL: no split. */
+size_t mdx_attention_ws_bytes(int B, int heads, int D, int Nq, int Nk);
+int mdx_attention_splitkv_f16(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld, const void* vt,
+                              long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads, int D, int Nq, int Nk,
+                              float scale, int kv_splits, void* ws, size_t ws_bytes, mdx_stream_t s);
+
 /* ---- Row-local fused tail of a SpatialTransformer block: everything BasicTransformerBlock.construct does after the
  *      self-attention core, plus SpatialTransformer's proj_out, as ONE launch (attention.py:151-152 to_out, :177 norm2,
  *      :108 to_q, :138-150 cross-attention over the cached context keys, :183, :178 norm3, :41-70 GEGLU feed-forward, :184,

@@ -98,6 +98,10 @@ SIGNATURES = {
     "mdx_gemm_query": (c_int, [ctypes.POINTER(GemmDesc), ctypes.POINTER(c_int)]),
     "mdx_attention_f16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,
                                   c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "mdx_attention_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "mdx_attention_splitkv_f16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,
+                                          c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p,
+                                          c_size_t, c_void_p]),
     "mdx_attention_causal_f16": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_void_p, c_long, c_int,
                                   c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "mdx_st_head_f16": (c_int, [ctypes.POINTER(StHeadDesc), c_void_p]),
@@ -140,6 +144,7 @@ _ENV_OPTIONS = {
     "MDX_GEMM_DENSE8P": ("gemm_dense8p", int), "MDX_GEMM_DENSE8P_MIN_M": ("gemm_dense8p_min_m", int),
     "MDX_GEMM_SUBPIXEL_MIN_TILES": ("gemm_subpixel_min_tiles", int), "MDX_GEMM_CONV8P_VAR": ("gemm_conv8p_var", int),
     "MDX_ATTN8": ("attn8", int), "MDX_ATTN8_MIN_BLOCKS": ("attn8_min_blocks", int),
+    "MDX_ATTN_OCC3": ("attn_occ3", int), "MDX_ATTN_KV_SPLIT": ("attn_kv_split", int),
 }
 
 

@@ -35,13 +35,23 @@ struct AttnParams {
     float scale_log2;  // scale * log2(e)
     unsigned k_bytes, vt_bytes;  // per-batch extents for the buffer descriptors
     int causal;                  // 1: key j is visible to query i only if j <= i (text encoder, text_encoder.py:136-139)
+    // split-KV form (mdx_attention_splitkv_f16): the key tiles of a (batch, head, 128-query block) item are dealt to nsplit blocks;
+    // each parks its normalised partial output + (reference, row sum) in ws_part, the last arriver of the item combines them
+    int nsplit, qblocks;
+    char* ws_part;               // [item][split]{ fp16 O~[128][D], float2 {m * scale_log2, l}[128] }
+    unsigned* tickets;           // [item] arrival counters: zero on entry, left zero
 };
 
 constexpr int BQ = 128;
 constexpr int BKV = 64;
+constexpr int ATTN_MAX_SPLITS_K = 8;      // most KV splits of one item (mdx_attention_splitkv_f16)
 
-template <int D>
-__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const AttnParams p) {
+// OCC = blocks the register budget admits per CU (a block is one wave per SIMD): 2 is the form of rounds 1-3 (<= 256 VGPRs);
+// 3 (<= 168 VGPRs, D <= 64 only: the D = 64 kernel needs 182 unconstrained and fits 168 with eight spills OUTSIDE the tile loop)
+// puts a third independent wave on every SIMD -- a lone wave spends ~2000 cycles on a KV tile whose VALU + MFMA issue is ~1000,
+// two co-resident waves ~2200 per pair (tools/attn_bench.py), so the SIMD still has issue slots to give.
+template <int D, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
     static_assert(D % 8 == 0 && D <= 160, "head dim must be a multiple of 8, <= 160");
     constexpr int KS = (D + 15) / 16;          // k-steps of QK^T (contraction over d, zero-padded to 16)
     constexpr int DT = (D + 31) / 32;          // 32-row d tiles of O^T
@@ -61,7 +71,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * BQ + wave * 32;
+    // split-KV launches: blockIdx.x = query block * nsplit + split, so the blocks of one item are dispatched back to back
+    const int qblk = p.nsplit > 1 ? (int)blockIdx.x / p.nsplit : (int)blockIdx.x;
+    const int split = p.nsplit > 1 ? (int)blockIdx.x - qblk * p.nsplit : 0;
+    const int q0 = qblk * BQ + wave * 32;
 
     const f16* kb = p.k + (size_t)b * p.k_bs + h * D;
     const f16* vb = p.vt + (size_t)b * p.vt_bs + (size_t)h * D * p.vt_ld;
@@ -221,23 +234,30 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     using B1 = std::integral_constant<int, 1>;
     const bool ragged = (p.Nk % BKV) != 0;
     int ntl = ntiles;
-    if (p.causal) ntl = min(ntiles, (blockIdx.x * BQ + BQ - 1) / BKV + 1);   // tiles wholly in the future are skipped
+    if (p.causal) ntl = min(ntiles, (qblk * BQ + BQ - 1) / BKV + 1);   // tiles wholly in the future are skipped
     const int nfull = p.causal ? 0 : (ragged ? ntl - 1 : ntl);                 // leading tiles that need no masking
+    // this block's tile range [t_begin, t_end): everything, or the split's share (even boundaries: tile t lives in buffer t & 1)
+    int t_begin = 0, t_end = ntl;
+    if (p.nsplit > 1) {
+        t_begin = ((split * ntiles) / p.nsplit) & ~1;
+        t_end = split + 1 == p.nsplit ? ntiles : ((((split + 1) * ntiles) / p.nsplit) & ~1);
+    }
+    const int nfull_l = min(nfull, t_end);
 
     // tile t lives in LDS buffer t & 1; tile t + 1 is staged while tile t is computed
-    stage_tile(0, 0);
+    stage_tile(t_begin, 0);
     __syncthreads();
-    int t = 0;
-    for (; t + 2 <= nfull; t += 2) {
+    int t = t_begin;
+    for (; t + 2 <= nfull_l; t += 2) {
         stage_tile(t + 1, 1);
         tile(B0{}, std::false_type{}, t);
         __syncthreads();
-        if (t + 2 < ntl) stage_tile(t + 2, 0);
+        if (t + 2 < t_end) stage_tile(t + 2, 0);
         tile(B1{}, std::false_type{}, t + 1);
         __syncthreads();
     }
-    for (; t < ntl; ++t) {      // the (masked) tail: one tile for a ragged Nk, every tile for causal attention
-        if (t + 1 < ntl) stage_tile(t + 1, (t + 1) & 1);
+    for (; t < t_end; ++t) {      // the (masked) tail: one tile for a ragged Nk, every tile for causal attention
+        if (t + 1 < t_end) stage_tile(t + 1, (t + 1) & 1);
         const bool masked = t >= nfull;
         if (t & 1) {
             if (masked) tile(B1{}, std::true_type{}, t); else tile(B1{}, std::false_type{}, t);
@@ -263,6 +283,78 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         }
     __syncthreads();
     constexpr int CPR = D / 8;   // 16-B chunks per output row
+    if (p.nsplit > 1) {
+        // ---- split-KV hand-off (the scheme of splitk_last_block_reduce, gemm_internal.h): this block's NORMALISED partial
+        // O~ = O / l in fp16 (the rounding the final output gets anyway) and per query {m * scale_log2, l} go to the workspace with
+        // write-through (sc1) stores; drain; block barrier; one lane takes a ticket on the item's counter; the last arriver reads
+        // all nsplit partials with sc1 loads and stores  sum_s w_s O~_s / sum_s w_s,  w_s = l_s 2^(m_s - max m)  -- summed in split
+        // order whoever arrives last, so the result does not depend on the schedule.
+        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+        constexpr unsigned O_BYTES = (unsigned)BQ * D * 2u;
+        constexpr unsigned PART = O_BYTES + (unsigned)BQ * 8u;
+        const size_t item = ((size_t)b * p.heads + h) * p.qblocks + qblk;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.ws_part + item * p.nsplit * PART, (unsigned)p.nsplit * PART);
+        for (int idx = lane; idx < 32 * CPR; idx += 64) {
+            const int row = idx / CPR, chunk = idx - row * CPR;
+            const f16x8 v = *reinterpret_cast<const f16x8*>(&og[row * OLD + chunk * 8]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), rs,
+                                                   (unsigned)split * PART + (unsigned)(((wave * 32 + row) * D + chunk * 8) * 2), 0, /*sc1*/ 16);
+        }
+        if (hi == 0) {
+            u32x2v ml;
+            ml[0] = __float_as_uint(m_run * p.scale_log2);
+            ml[1] = __float_as_uint(l_tot);
+            __builtin_amdgcn_raw_buffer_store_b64(ml, rs, (unsigned)split * PART + O_BYTES + (unsigned)(wave * 32 + l31) * 8u, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem + 4 * 32 * OLD * 2);      // behind the four waves' staging rows
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.tickets + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old >= (unsigned)p.nsplit) __builtin_trap();     // counters not zero on entry (two streams on one workspace, mdx.h)
+            *flag = old == (unsigned)p.nsplit - 1u;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        if (tid == 0) __hip_atomic_store(p.tickets + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int idx = tid; idx < BQ * CPR; idx += 256) {
+            const int row = idx / CPR, chunk = idx - row * CPR;
+            const int qi = qblk * BQ + row;
+            if (qi >= p.Nq) continue;
+            // every partial's {reference, row sum} and O~ chunk in flight together (one fabric round trip, not 2 * nsplit)
+            u32x2v ml[ATTN_MAX_SPLITS_K];
+            u32x4v raw[ATTN_MAX_SPLITS_K];
+#pragma unroll
+            for (int z = 0; z < ATTN_MAX_SPLITS_K; ++z)
+                if (z < p.nsplit) {
+                    ml[z] = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)z * PART + O_BYTES + (unsigned)row * 8u, 0, 16);
+                    raw[z] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)z * PART + (unsigned)((row * D + chunk * 8) * 2), 0, 16);
+                }
+            float mmax = -INFINITY;
+#pragma unroll
+            for (int z = 0; z < ATTN_MAX_SPLITS_K; ++z)
+                if (z < p.nsplit) mmax = fmaxf(mmax, __uint_as_float(ml[z][0]));
+            float acc[8], wsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int z = 0; z < ATTN_MAX_SPLITS_K; ++z)
+                if (z < p.nsplit) {
+                    const f16x8 v = __builtin_bit_cast(f16x8, raw[z]);
+                    const float w = __uint_as_float(ml[z][1]) * __builtin_amdgcn_exp2f(__uint_as_float(ml[z][0]) - mmax);
+                    wsum += w;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += w * (float)v[e];
+                }
+            const float winv = 1.0f / wsum;
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)(acc[e] * winv);
+            *reinterpret_cast<f16x8*>(p.o + (size_t)b * p.o_bs + (size_t)qi * p.o_ld + h * D + chunk * 8) = o;
+        }
+        return;
+    }
     for (int idx = lane; idx < 32 * CPR; idx += 64) {
         const int row = idx / CPR, chunk = idx - row * CPR;
         const int qi = q0 + row;
@@ -515,26 +607,59 @@ void launch_attn8(const AttnParams& p, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL(attn8_kernel<D>, grid, dim3(512), lds, st, p);
 }
 
-template <int D>
+template <int D, int OCC>
 void launch_attn(const AttnParams& p, dim3 grid, hipStream_t st) {
     constexpr int KS = (D + 15) / 16, DT = (D + 31) / 32;
     constexpr int KCH = (2 * KS <= 8) ? 8 : (2 * KS <= 16 ? 16 : 32);
     constexpr size_t stage = (size_t)BKV * KCH * 16 + (size_t)DT * 32 * 128;
-    constexpr size_t ostage = (size_t)4 * 32 * (DT * 32 + 8) * 2;
+    constexpr size_t ostage = (size_t)4 * 32 * (DT * 32 + 8) * 2 + 16;      // + the split-KV "last arriver" flag
     constexpr size_t lds = (2 * stage > ostage ? 2 * stage : ostage);
     static MdxPerDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, OCC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL(attn_kernel<D>, grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((attn_kernel<D, OCC>), grid, dim3(256), lds, st, p);
 }
+
+constexpr int ATTN_CUS = 256;            // MI355X
+constexpr int ATTN_MAX_SPLITS = ATTN_MAX_SPLITS_K;
+
+// blocks the register file admits per CU for head dim D (see attn_kernel's OCC)
+int attn_blocks_per_cu(int D) { return D <= 64 ? (mdx_opt(MDX_OPT_ATTN_OCC3) ? 3 : 2) : (D <= 80 ? 2 : 1); }
+
+// Split-KV policy.  A launch whose (batch, head, query block) items do not fill the chip's block slots even once leaves SIMDs idle
+// while others carry two waves: SDv2's 64 x 64 self-attention at UNet batch 2 is 320 blocks of 64 tiles on 256 CUs -- 64 CUs run
+// two blocks (82 us), 192 CUs one (done at ~50 us).  Dealing every item's key tiles to S blocks (S = slots / items, each split at
+// least 24 tiles) fills the slots with equal pieces; the partial hand-off costs one 128 x D fp16 tile per block.
+int attn_auto_splits(int B, int heads, int D, int Nq, int Nk) {
+    const int mode = mdx_opt(MDX_OPT_ATTN_KV_SPLIT);
+    const int ntiles = (Nk + BKV - 1) / BKV;
+    // the hand-off is a chain of fabric round trips (drained write-through stores -> ticket -> partial loads: ~6-8 us on MI355X), so a
+    // split must be worth >= 24 key tiles (~25 us): 4096 keys split two ways 72 -> 66 us, 1024 keys split four ways 15.5 -> 24 us
+    // (tools/attn_bench.py, profiles/r04_attn_bench.txt)
+    int cap = mode >= 2 ? ntiles / 2 : ntiles / 24;
+    if (cap > ATTN_MAX_SPLITS) cap = ATTN_MAX_SPLITS;
+    if (mode == 0 || cap < 2) return 1;
+    if (mode >= 2) return mode < cap ? mode : cap;
+    const long items = (long)((Nq + BQ - 1) / BQ) * heads * B;
+    const long slots = (long)ATTN_CUS * attn_blocks_per_cu(D);
+    long s = slots / items;
+    if (s > cap) s = cap;
+    return s < 2 ? 1 : (int)s;
+}
+
+// The arrival counters live in a FIXED region at the head of the workspace: launches of different shapes share one workspace in turn,
+// and a region sized per launch would let a small launch's partials land on a bigger launch's counters.
+constexpr long ATTN_TICKET_ITEMS = 16384;
+constexpr size_t ATTN_TICKET_BYTES = (size_t)ATTN_TICKET_ITEMS * 4;
+size_t attn_part_bytes(int D) { return (size_t)BQ * D * 2 + (size_t)BQ * 8; }
 
 }  // namespace
 
 static int attention_impl(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld, const void* vt,
                           long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads, int D, int Nq, int Nk,
-                          float scale, int causal, mdx_stream_t s) {
+                          float scale, int causal, int kv_splits, void* ws, size_t ws_bytes, mdx_stream_t s) {
     MDX_REQUIRE(q && k && vt && o, "mdx_attention_f16: null pointer");
     MDX_REQUIRE(D == 40 || D == 64 || D == 80 || D == 160, "mdx_attention_f16: head dim %d not supported (40/64/80/160)", D);
     MDX_REQUIRE(B > 0 && heads > 0 && Nq > 0 && Nk > 0, "mdx_attention_f16: bad extents");
@@ -555,11 +680,32 @@ static int attention_impl(const void* q, long q_bs, int q_ld, const void* k, lon
     MDX_REQUIRE(kbytes <= 0x80000000ull && vbytes <= 0x80000000ull, "mdx_attention_f16: K/V extent too large");
     p.k_bytes = (unsigned)kbytes;
     p.vt_bytes = (unsigned)vbytes;
-    dim3 grid((Nq + BQ - 1) / BQ, heads, B);
+    const int qblocks = (Nq + BQ - 1) / BQ;
+    p.nsplit = 1;
+    p.qblocks = qblocks;
+    if (ws && !causal) {
+        const int ntiles = (Nk + BKV - 1) / BKV;
+        int S = kv_splits > 0 ? kv_splits : attn_auto_splits(B, heads, D, Nq, Nk);
+        if (kv_splits > 0) {
+            MDX_REQUIRE(S <= ATTN_MAX_SPLITS && 2 * S <= ntiles, "mdx_attention_splitkv_f16: %d splits of %d key tiles (at most %d, two tiles each)",
+                        S, ntiles, ATTN_MAX_SPLITS);
+        }
+        if (S > 1) {
+            const long items = (long)qblocks * heads * B;
+            MDX_REQUIRE(items <= ATTN_TICKET_ITEMS, "mdx_attention_splitkv_f16: %ld (batch, head, query block) items, at most %ld can be split", items, ATTN_TICKET_ITEMS);
+            const size_t tb = ATTN_TICKET_BYTES, need = tb + (size_t)items * S * attn_part_bytes(D);
+            MDX_REQUIRE(ws_bytes >= need, "mdx_attention_splitkv_f16: workspace of %zu bytes, %zu needed (mdx_attention_ws_bytes)", ws_bytes, need);
+            MDX_REQUIRE((size_t)S * attn_part_bytes(D) <= 0x80000000ull, "mdx_attention_splitkv_f16: partial extent too large");
+            p.nsplit = S;
+            p.tickets = (unsigned*)ws;
+            p.ws_part = (char*)ws + tb;
+        }
+    }
+    dim3 grid(qblocks * p.nsplit, heads, B);
     hipStream_t st = (hipStream_t)s;
     // eight-wave form (attn8_kernel above; measured slower, opt-in): self-attention shapes, D <= 80 (D = 160 spills at two waves per SIMD)
     const int a8 = mdx_opt(MDX_OPT_ATTN8);
-    if (a8 && !causal && D <= 80 && Nq % 256 == 0 && Nk % BKV == 0 &&
+    if (a8 && p.nsplit == 1 && !causal && D <= 80 && Nq % 256 == 0 && Nk % BKV == 0 &&
         (a8 == 2 || (long)(Nq / 256) * heads * B >= mdx_opt(MDX_OPT_ATTN8_MIN_BLOCKS))) {
         const dim3 g8(Nq / 256, heads, B);
         switch (D) {
@@ -570,25 +716,45 @@ static int attention_impl(const void* q, long q_bs, int q_ld, const void* k, lon
         MDX_LAUNCH_CHECK("mdx_attention_f16(attn8)");
         return MDX_OK;
     }
+    const bool occ3 = mdx_opt(MDX_OPT_ATTN_OCC3) != 0;
     switch (D) {
-        case 40: launch_attn<40>(p, grid, st); break;
-        case 64: launch_attn<64>(p, grid, st); break;
-        case 80: launch_attn<80>(p, grid, st); break;
-        default: launch_attn<160>(p, grid, st); break;
+        case 40: if (occ3) launch_attn<40, 3>(p, grid, st); else launch_attn<40, 2>(p, grid, st); break;
+        case 64: if (occ3) launch_attn<64, 3>(p, grid, st); else launch_attn<64, 2>(p, grid, st); break;
+        case 80: launch_attn<80, 2>(p, grid, st); break;
+        default: launch_attn<160, 1>(p, grid, st); break;
     }
     MDX_LAUNCH_CHECK("mdx_attention_f16");
     return MDX_OK;
 }
 
+/* Workspace the split-KV form needs for this shape under the current options (0: the launch would not be split). */
+extern "C" size_t mdx_attention_ws_bytes(int B, int heads, int D, int Nq, int Nk) {
+    if (B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0 || !(D == 40 || D == 64 || D == 80 || D == 160)) return 0;
+    const int S = attn_auto_splits(B, heads, D, Nq, Nk);
+    if (S < 2) return 0;
+    const long items = (long)((Nq + BQ - 1) / BQ) * heads * B;
+    return ATTN_TICKET_BYTES + (size_t)items * S * attn_part_bytes(D);
+}
+
+extern "C" int mdx_attention_splitkv_f16(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld,
+                                         const void* vt, long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads,
+                                         int D, int Nq, int Nk, float scale, int kv_splits, void* ws, size_t ws_bytes,
+                                         mdx_stream_t s) {
+    MDX_REQUIRE(kv_splits >= 0, "mdx_attention_splitkv_f16: kv_splits < 0");
+    MDX_REQUIRE(ws || kv_splits <= 1, "mdx_attention_splitkv_f16: %d splits need a workspace", kv_splits);
+    return attention_impl(q, q_bs, q_ld, k, k_bs, k_ld, vt, vt_bs, vt_ld, o, o_bs, o_ld, B, heads, D, Nq, Nk, scale, 0,
+                          kv_splits == 1 ? 0 : kv_splits, kv_splits == 1 ? nullptr : ws, ws_bytes, s);
+}
+
 extern "C" int mdx_attention_f16(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld,
                                  const void* vt, long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B, int heads,
                                  int D, int Nq, int Nk, float scale, mdx_stream_t s) {
-    return attention_impl(q, q_bs, q_ld, k, k_bs, k_ld, vt, vt_bs, vt_ld, o, o_bs, o_ld, B, heads, D, Nq, Nk, scale, 0, s);
+    return attention_impl(q, q_bs, q_ld, k, k_bs, k_ld, vt, vt_bs, vt_ld, o, o_bs, o_ld, B, heads, D, Nq, Nk, scale, 0, 0, nullptr, 0, s);
 }
 
 extern "C" int mdx_attention_causal_f16(const void* q, long q_bs, int q_ld, const void* k, long k_bs, int k_ld,
                                         const void* vt, long vt_bs, int vt_ld, void* o, long o_bs, int o_ld, int B,
                                         int heads, int D, int Nq, int Nk, float scale, mdx_stream_t s) {
     MDX_REQUIRE(Nq == Nk, "mdx_attention_causal_f16: causal self-attention needs Nq == Nk (got %d, %d)", Nq, Nk);
-    return attention_impl(q, q_bs, q_ld, k, k_bs, k_ld, vt, vt_bs, vt_ld, o, o_bs, o_ld, B, heads, D, Nq, Nk, scale, 1, s);
+    return attention_impl(q, q_bs, q_ld, k, k_bs, k_ld, vt, vt_bs, vt_ld, o, o_bs, o_ld, B, heads, D, Nq, Nk, scale, 1, 0, nullptr, 0, s);
 }

@@ -503,6 +503,8 @@ class UNetModel:
         emit(lambda: ops.nchw_to_nhwc(P.x_static, self.cin_pad, out=xin), "small")
 
         P.ctx_pad = None
+        P.attn_ws = None         # split-KV attention workspace (ops.attention_workspace), sized after the walk
+        attn_ws_need = [0]
         ctx_kv = {}
 
         def conv3(src, cin, cout, wt, bias, h, wd, stride=1, upsample=0, rowbias=None, residual=None, src2=None, c2=0,
@@ -737,9 +739,10 @@ class UNetModel:
                 emit(lambda hd=hd: ops.st_head_run(hd), "gemm", 2 * B * n * 4 * inner * inner, 1,
                      f"st_head M={B * n} C={inner} rows={rows_h} (GroupNorm..q|k|v fused)")
                 o = A.get((B, n, inner))
+                attn_ws_need[0] = max(attn_ws_need[0], ops.attention_ws_bytes(B, heads, dh, n, n))
                 emit(lambda qk=qk, vt=vt, o=o: ops.attention(
                     qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
-                    n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner),
+                    n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner, ws=P.attn_ws),
                     "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
                 out = fused_tail(t0, tail_rows(t0, n, heads, dh), o, tok, x, ch, inner, heads, dh, n)
                 A.release(qk); A.release(vt); A.release(tok); A.release(o)
@@ -773,9 +776,10 @@ class UNetModel:
                     qk = dense(main, ln, B, n, inner, 2 * inner, w[t + "attn1.qk.w"])
                     dense(main, ln, B, n, inner, inner, w[t + "attn1.v.w"], out=vt, out_ld=n, out_mode=ops.OUT_TRANSPOSED)
                 o = ln  # reuse: ln is dead after the projections
+                attn_ws_need[0] = max(attn_ws_need[0], ops.attention_ws_bytes(B, heads, dh, n, n))
                 emit(lambda qk=qk, vt=vt, o=o: ops.attention(
                     qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
-                    n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner),
+                    n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner, ws=P.attn_ws),
                     "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
                 rows_t = tail_rows(t, n, heads, dh)
                 if rows_t:
@@ -898,6 +902,8 @@ class UNetModel:
             d.workspace = P.gemm_ws.data_ptr()
             d.workspace_bytes = P.gemm_ws.numel() * 4
         P.gn_ws = torch.empty(max(gn_need[0], 4), dtype=f32, device=dev)
+        if attn_ws_need[0]:
+            P.attn_ws = ops.attention_workspace(attn_ws_need[0], dev)
         # ---- weight-streaming form of the small-M 3x3 convs (mdx_gemm_desc.w_frag): at M = 128 (the 8 x 8 level at UNet batch
         # 2) a conv is a 30 MB weight stream with almost no arithmetic; the launches that resolve to 128 x 64 HALO tiles read a
         # fragment-major copy of their weights straight into registers, twelve 1 KiB pieces in flight per wave.  Measured

@@ -546,13 +546,31 @@ def gemm(a, w, N, B, H, W, c1, out=None, **kw):
 
 
 def attention(q_ptr, k_ptr, vt_ptr, o_ptr, B, heads, D, Nq, Nk, scale, q_bs, q_ld, k_bs, k_ld, vt_bs, vt_ld, o_bs, o_ld,
-              causal=False):
-    """Raw-pointer form (q/k may be column slices of one fused projection buffer); see include/mdx.h."""
+              causal=False, ws=None, kv_splits=0):
+    """Raw-pointer form (q/k may be column slices of one fused projection buffer); see include/mdx.h.
+    `ws`: a zero-initialised uint8 workspace tensor (attention_workspace) -> the split-KV form, `kv_splits` 0 = auto."""
     lib = _lib.load()
+    if ws is not None and not causal:
+        _lib.check(lib.mdx_attention_splitkv_f16(
+            ctypes.c_void_p(q_ptr), q_bs, q_ld, ctypes.c_void_p(k_ptr), k_bs, k_ld, ctypes.c_void_p(vt_ptr), vt_bs, vt_ld,
+            ctypes.c_void_p(o_ptr), o_bs, o_ld, B, heads, D, Nq, Nk, float(scale), int(kv_splits), ctypes.c_void_p(ws.data_ptr()),
+            ws.numel() * ws.element_size(), _stream()), "mdx_attention_splitkv_f16")
+        return
     fn = lib.mdx_attention_causal_f16 if causal else lib.mdx_attention_f16
     _lib.check(fn(ctypes.c_void_p(q_ptr), q_bs, q_ld, ctypes.c_void_p(k_ptr), k_bs, k_ld, ctypes.c_void_p(vt_ptr), vt_bs,
                   vt_ld, ctypes.c_void_p(o_ptr), o_bs, o_ld, B, heads, D, Nq, Nk, float(scale), _stream()),
                "mdx_attention_causal_f16" if causal else "mdx_attention_f16")
+
+
+def attention_ws_bytes(B, heads, D, Nq, Nk):
+    """Bytes of workspace the library's own split choice needs for this shape (0: it would not split)."""
+    return int(_lib.load().mdx_attention_ws_bytes(B, heads, D, Nq, Nk))
+
+
+def attention_workspace(nbytes, device):
+    """Zeroed workspace for the split-KV attention: the arrival counters at its head must be zero on the first use and every
+    launch leaves them zero, so ONE workspace serves all attention launches of a plan (one stream) in turn."""
+    return torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
 def timestep_embedding(t, dim, max_period=10000.0, out=None):

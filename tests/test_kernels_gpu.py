@@ -752,6 +752,101 @@ def test_attention_eight_wave_form(ops, ramp, D, heads, Nq, Nk):
     check(f"attention8_vs_four_wave_{ramp}_d{D}_q{Nq}_k{Nk}", outs[2], outs[0], rel_l2=1e-3)
 
 
+@pytest.mark.parametrize("occ3", [1, 0])
+@pytest.mark.parametrize("ramp", [None, "stale6.5", "always12", "sawtooth"])
+@pytest.mark.parametrize("D,heads,Nq,Nk,splits", [
+    (64, 2, 256, 512, 2), (64, 5, 200, 1024, 4), (64, 1, 128, 4096, 8), (64, 2, 256, 1000, 3),     # ragged last key tile in the last split
+    (40, 8, 256, 512, 2), (80, 2, 128, 768, 3), (160, 1, 128, 512, 2), (64, 3, 384, 3200, 0),     # 0: the library's own choice (50 key tiles: two splits)
+])
+def test_attention_split_kv(ops, occ3, ramp, D, heads, Nq, Nk, splits):
+    """mdx_attention_splitkv_f16 (csrc/attention.hip): the key tiles of every (batch, head, 128-query block) item dealt to
+    2 ... 8 blocks, partials (normalised fp16 O, reference, row sum) through the workspace, the last arriver combines.  Against the
+    float64 softmax (the tolerance of the unsplit kernel) and against the unsplit kernel (one more fp16 rounding of the partials:
+    1e-3), with i.i.d. scores and with the stale-maximum ramps (each split starts its own reference; the combine weights
+    l_s 2^(m_s - max m) span many octaves under a ramp), ragged queries / keys, both register-occupancy builds; the arrival counters
+    at the head of the workspace must be zero again after every launch (the workspace is reused without clearing)."""
+    B = 2
+    C = heads * D
+    rng = np.random.RandomState(Nq + Nk + D + splits + (sum(map(ord, ramp)) if ramp else 0))
+    q = h16(0.5 * rng.standard_normal((B, Nq, C)))
+    k = h16(0.5 * rng.standard_normal((B, Nk, C)))
+    v = h16(rng.standard_normal((B, Nk, C)))
+    if ramp:
+        scale_log2 = D ** -0.5 * 1.4426950408889634
+        for hh in range(heads):
+            q[:, :, hh * D + D - 1] = 8.0
+            for j in range(Nk):
+                k[:, j, hh * D + D - 1] = RAMPS[ramp](j // 64) / (8.0 * scale_log2)
+        q, k = h16(q), h16(k)
+    qt, kt, vt_ = [torch.tensor(t, dtype=torch.float64).reshape(B, -1, heads, D).permute(0, 2, 1, 3) for t in (q, k, v)]
+    ref = torch.matmul(torch.softmax(torch.matmul(qt, kt.transpose(2, 3)) * D ** -0.5, -1), vt_).permute(0, 2, 1, 3).reshape(B, Nq, C)
+    ld = (Nk + 7) // 8 * 8
+    vt = np.zeros((B, C, ld), np.float32)
+    vt[:, :, :Nk] = v.transpose(0, 2, 1)
+    qd, kd, vtd = dev16(q), dev16(k), dev16(vt)
+    items = (Nq + 127) // 128 * heads * B
+    ws = ops.attention_workspace(65536 + items * 8 * (128 * D * 2 + 1024), DEV)
+    ops.set_option("attn_occ3", occ3)
+    try:
+        if splits == 0:
+            assert ops.attention_ws_bytes(B, heads, D, Nq, Nk) > 0, "the auto policy should split this under-filled launch"
+        outs = []
+        for rep in range(2):        # the second launch reuses the workspace as the first left it
+            out = torch.full((B, Nq, C), float("nan"), dtype=torch.float16, device=DEV)
+            ops.attention(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), out.data_ptr(), B, heads, D, Nq, Nk, D ** -0.5,
+                          Nq * C, C, Nk * C, C, C * ld, ld, Nq * C, C, ws=ws, kv_splits=splits)
+            torch.cuda.synchronize()
+            assert int(ws[: items * 4].view(torch.int32).abs().sum()) == 0, "arrival counters not back at zero"
+            outs.append(out)
+        plain = torch.empty((B, Nq, C), dtype=torch.float16, device=DEV)
+        ops.attention(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), plain.data_ptr(), B, heads, D, Nq, Nk, D ** -0.5,
+                      Nq * C, C, Nk * C, C, C * ld, ld, Nq * C, C)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option("attn_occ3", 1)
+    assert torch.equal(outs[0], outs[1]), "split-KV attention is not reproducible launch to launch"
+    name = f"attention_splitkv{splits}_occ{occ3}_{ramp}_d{D}_q{Nq}_k{Nk}"
+    check(name, outs[0], ref, rel_l2=2e-3, max_abs=2e-2)
+    check(name + "_vs_unsplit", outs[0], plain, rel_l2=1e-3)
+
+
+def test_attention_split_kv_rejects_bad_arguments(ops):
+    """Error behaviour of the split-KV entry point: too many splits for the key count, a workspace that is too small."""
+    from minddiffusion_amd._lib import MdxError
+    B, heads, D, N = 1, 1, 64, 256
+    C = heads * D
+    x = torch.zeros((B, N, C), dtype=torch.float16, device=DEV)
+    vt = torch.zeros((B, C, N), dtype=torch.float16, device=DEV)
+    o = torch.empty_like(x)
+    args = (x.data_ptr(), x.data_ptr(), vt.data_ptr(), o.data_ptr(), B, heads, D, N, N, 0.125, N * C, C, N * C, C, C * N, N, N * C, C)
+    with pytest.raises(MdxError, match="splits"):
+        ops.attention(*args, ws=ops.attention_workspace(1 << 20, DEV), kv_splits=3)      # 4 key tiles: at most 2 splits
+    with pytest.raises(MdxError, match="workspace"):
+        ops.attention(*args, ws=ops.attention_workspace(256, DEV), kv_splits=2)
+
+
+def test_attention_split_kv_shared_workspace(ops):
+    """One workspace serves launches of DIFFERENT shapes in turn (a UNet plan's 64 x 64 and 32 x 32 self-attentions): the arrival
+    counters sit in a fixed 64 KiB region at its head, so a small launch's partials cannot land on a bigger launch's counters
+    (they did when the region was sized per launch: the next big launch trapped on a non-zero counter)."""
+    shapes = [(2, 5, 512, 64, 2), (2, 10, 256, 64, 2), (1, 8, 384, 40, 3), (2, 5, 512, 64, 4)]
+    need = max(65536 + ((n + 127) // 128 * h * b) * s_ * (128 * d * 2 + 1024) for b, h, n, d, s_ in shapes)
+    ws = ops.attention_workspace(need, DEV)
+    rng = np.random.RandomState(5)
+    for rep in range(2):
+        for b, h, n, d, s_ in shapes:
+            c = h * d
+            q, k, v = (h16(rng.standard_normal((b, n, c))) for _ in range(3))
+            ref = _attn_ref(q, k, v, h)
+            qd, kd, vtd = dev16(q), dev16(k), dev16(np.ascontiguousarray(v.transpose(0, 2, 1)))
+            out = torch.empty((b, n, c), dtype=torch.float16, device=DEV)
+            ops.attention(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), out.data_ptr(), b, h, d, n, n, d ** -0.5,
+                          n * c, c, n * c, c, c * n, n, n * c, c, ws=ws, kv_splits=s_)
+            torch.cuda.synchronize()
+            assert int(ws[:65536].view(torch.int32).abs().sum()) == 0
+            check(f"attention_splitkv_shared_ws_rep{rep}_B{b}_h{h}_N{n}_d{d}_s{s_}", out, ref, rel_l2=2e-3, max_abs=2e-2)
+
+
 @pytest.mark.parametrize("B,heads,N,D", [(2, 2, 80, 64), (1, 3, 77, 64), (2, 1, 200, 64), (1, 2, 384, 64), (1, 8, 80, 40)])
 def test_attention_causal(ops, B, heads, N, D):
     """mdx_attention_causal_f16: key j is visible to query i iff j <= i (text_encoder.py:136-139); N spans one tile,

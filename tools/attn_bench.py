@@ -16,7 +16,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="8,5,9216,64;2,5,4096,64;16,8,4096,40;16,10,1024,64")
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--forms", default="0,2", help="attn8 option values to time, interleaved (0 = four-wave kernel, 2 = eight-wave)")
+    ap.add_argument("--forms", default="o2,o3,o3s",
+                    help="launch forms to time, interleaved: o2 / o3 = four-wave kernel built for two / three blocks per CU; a trailing "
+                         "'s' adds the split-KV workspace with the library's own split choice, 'sN' forces N splits; a8 = the eight-wave kernel")
     ap.add_argument("--rounds", type=int, default=3)
     args = ap.parse_args()
     from minddiffusion_amd import ops
@@ -27,30 +29,41 @@ def main():
         qk = torch.randn(B, N, 2 * inner, device=dev, dtype=torch.float16)        # [q | k] as the merged projection writes them
         vt = torch.randn(B, inner, N, device=dev, dtype=torch.float16)            # V^T
         o = torch.empty(B, N, inner, device=dev, dtype=torch.float16)
+        items = (N + 127) // 128 * h * B
+        ws = ops.attention_workspace(65536 + items * 8 * (128 * D * 2 + 1024), dev)
 
-        def run():
+        def setup(form):
+            ops.set_option("attn8", 2 if form == "a8" else 0)
+            ops.set_option("attn_occ3", 0 if form.startswith("o2") else 1)
+            if "s" in form:
+                n = form.split("s")[1]
+                return ws, (int(n) if n else 0)
+            return None, 0
+
+        def run(w, ns):
             ops.attention(qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, h, D, N, N, D ** -0.5,
-                          N * 2 * inner, 2 * inner, N * 2 * inner, 2 * inner, inner * N, N, N * inner, inner)
-        forms = [int(x) for x in args.forms.split(",")]
+                          N * 2 * inner, 2 * inner, N * 2 * inner, 2 * inner, inner * N, N, N * inner, inner, ws=w, kv_splits=ns)
+        forms = args.forms.split(",")
         best = {f: 1e30 for f in forms}
         try:
             for _ in range(args.rounds):
                 for f in forms:
-                    ops.set_option("attn8", f)
-                    run()
+                    w, ns = setup(f)
+                    run(w, ns)
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(args.iters):
-                        run()
+                        run(w, ns)
                     e1.record()
                     torch.cuda.synchronize()
                     best[f] = min(best[f], e0.elapsed_time(e1) * 1e3 / args.iters)
         finally:
             ops.set_option("attn8", 0)
+            ops.set_option("attn_occ3", 1)
         line = f"self-attention B={B} heads={h} N={N} D={D}:"
         for f in forms:
-            line += f"  attn8={f} {best[f]:9.1f} us {4.0 * B * h * N * N * D / best[f] / 1e6:7.1f} TF/s"
+            line += f"  {f} {best[f]:8.1f} us {4.0 * B * h * N * N * D / best[f] / 1e6:6.1f} TF/s"
         print(line, flush=True)
 
 
