@@ -78,6 +78,10 @@ int mdx_conv8p_launch(const GemmParams& p, int bn, hipStream_t st);
 bool mdx_gemm8p_eligible(const GemmParams& p);
 int mdx_gemm8p_tiles(const GemmParams& p);
 int mdx_gemm8p_launch(GemmParams& p, hipStream_t st);
+// ... and its 256 x 256 form (gemm8q_kernel)
+bool mdx_gemm8q_eligible(const GemmParams& p);
+int mdx_gemm8q_tiles(const GemmParams& p);
+int mdx_gemm8q_launch(GemmParams& p, hipStream_t st);
 
 namespace {
 
@@ -182,6 +186,42 @@ __device__ __forceinline__ void gemm_bias_prefetch(const GemmParams& p, const in
     }
 }
 
+// LayerNorm fold, consumer side: {mean, rstd} of token row m from the producer's per-64-column {sum, sumsq} partials (p.ln_stats),
+// added in partial order with eight loads in flight (a load -> add loop made this a chain of K / 64 L2 round trips -- 10-20 -- at the
+// head of every epilogue; with one block per CU nothing hides it).
+__device__ __forceinline__ void gemm_ln_row_fold(const GemmParams& p, const int m, float (&mr)[2]) {
+    float su = 0.f, sq = 0.f;
+    if (m < p.M) {
+        const float2* st = reinterpret_cast<const float2*>(p.ln_stats) + (size_t)m * p.ln_nt;
+        int j = 0;
+        for (; j + 8 <= p.ln_nt; j += 8) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = st[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                su += v[u].x;
+                sq += v[u].y;
+            }
+        }
+        for (; j + 2 <= p.ln_nt; j += 2) {
+            const float2 v0 = st[j], v1 = st[j + 1];
+            su += v0.x; sq += v0.y; su += v1.x; sq += v1.y;
+        }
+        for (; j < p.ln_nt; ++j) {
+            const float2 v = st[j];
+            su += v.x;
+            sq += v.y;
+        }
+    }
+    const float inv = 1.0f / (float)p.K;
+    const float mean = su * inv;
+    float var = sq * inv - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    mr[0] = mean;
+    mr[1] = rsqrtf(var + p.ln_eps);
+}
+
 // In-kernel split-K reduce ("last block in finishes the tile").  Every (tile, split) block parks its fp32 accumulators in
 // the workspace IN REGISTER LAYOUT -- [tile][split][register quad][thread] 16-byte pieces, so that the stores and the later
 // loads are 1 KiB-per-wave contiguous -- then takes a ticket on the tile's arrival counter.  The block that draws the last
@@ -277,7 +317,7 @@ __device__ __forceinline__ bool splitk_last_block_reduce(const GemmParams& p, f3
 template <int BM, int BN, bool SWAP, int NW, class RowMap>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / (16 * NW)][BN / 64], char* smem,
                                               const RowMap rm, const int n0, const int split, const float (&bpre)[16],
-                                              const int row_block = 0, const int tile_lin = 0) {
+                                              const int row_block = 0, const int tile_lin = 0, const float* ln_pre = nullptr) {
     constexpr int NT = NW * 64;           // threads per block
     constexpr int WROWS = BM / (NW / 2);  // rows of the block tile owned by one wave row (waves are (NW/2) x 2)
     constexpr int TM = WROWS / 32;
@@ -354,23 +394,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             // rstd_m * (acc - mean_m * S_n) in fp32 -- BEFORE the fp16 staging, so the cancellation costs no precision.
             float* lnrow = reinterpret_cast<float*>(smem + (size_t)BM * SLD * 2);      // [BM][2] mean, rstd
             float* lns = lnrow + 2 * BM;                                               // [BN]
-            for (int r = tid; r < BM; r += NT) {
-                const int m = rm(r);
-                float su = 0.f, sq = 0.f;
-                if (m < p.M) {
-                    const float2* st = reinterpret_cast<const float2*>(p.ln_stats) + (size_t)m * p.ln_nt;
-                    for (int j = 0; j < p.ln_nt; ++j) {
-                        const float2 v = st[j];
-                        su += v.x;
-                        sq += v.y;
-                    }
+            if (ln_pre) {      // this thread's row (tid < BM) was folded before the K loop (gemm_ln_row_prefetch)
+                if (tid < BM) {
+                    lnrow[2 * tid] = ln_pre[0];
+                    lnrow[2 * tid + 1] = ln_pre[1];
                 }
-                const float inv = 1.0f / (float)p.K;
-                const float mean = su * inv;
-                float var = sq * inv - mean * mean;
-                var = var < 0.f ? 0.f : var;
-                lnrow[2 * r] = mean;
-                lnrow[2 * r + 1] = rsqrtf(var + p.ln_eps);
+            } else {
+                for (int r = tid; r < BM; r += NT) {
+                    float mr[2];
+                    gemm_ln_row_fold(p, rm(r), mr);
+                    lnrow[2 * r] = mr[0];
+                    lnrow[2 * r + 1] = mr[1];
+                }
             }
             for (int c = tid; c < BN; c += NT) lns[c] = (n0 + c < p.N) ? p.ln_s[n0 + c] : 0.f;
             __syncthreads();
@@ -463,6 +498,41 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         for (int e = 0; e < 8; ++e)
                             f[e] = ((float)va[e] + ba[e]) * gelu_tanh_f((float)vg[e] + bg[e]);
                         epilogue_store_row8(p, f, m, on);
+                    }
+                }
+            } else if constexpr (BN == 256) {
+                // two 128-column groups, each 64 'a' columns | 64 'gate' columns -> 64 outputs at column (n0 + 128 grp) / 2
+                const int chunk = tid & 7, r0 = tid >> 3;
+#pragma unroll
+                for (int grp = 0; grp < 2; ++grp) {
+                    const int pn = n0 + grp * 128 + chunk * 8;
+                    const int on = ((n0 + grp * 128) >> 1) + chunk * 8;
+                    float ba[8], bg[8];
+                    if (grp == 0 || !p.bias || pn >= p.N) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            ba[e] = grp == 0 ? bpre[e] : 0.f;
+                            bg[e] = grp == 0 ? bpre[8 + e] : 0.f;
+                        }
+                    } else {
+                        const float4* b4 = reinterpret_cast<const float4*>(p.bias + pn);
+                        const float4 x0 = b4[0], x1 = b4[1], g0 = b4[16], g1 = b4[17];
+                        ba[0] = x0.x; ba[1] = x0.y; ba[2] = x0.z; ba[3] = x0.w; ba[4] = x1.x; ba[5] = x1.y; ba[6] = x1.z; ba[7] = x1.w;
+                        bg[0] = g0.x; bg[1] = g0.y; bg[2] = g0.z; bg[3] = g0.w; bg[4] = g1.x; bg[5] = g1.y; bg[6] = g1.z; bg[7] = g1.w;
+                    }
+#pragma unroll
+                    for (int pass = 0; pass < BM / (NT / 8); ++pass) {
+                        const int row = r0 + pass * (NT / 8);
+                        const int m = rm(row);
+                        if (m < p.M && pn < p.N) {
+                            const f16x8 va = *reinterpret_cast<const f16x8*>(&stg[row * SLD + grp * 128 + chunk * 8]);
+                            const f16x8 vg = *reinterpret_cast<const f16x8*>(&stg[row * SLD + grp * 128 + 64 + chunk * 8]);
+                            float f[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                f[e] = ((float)va[e] + ba[e]) * gelu_tanh_f((float)vg[e] + bg[e]);
+                            epilogue_store_row8(p, f, m, on);
+                        }
                     }
                 }
             }

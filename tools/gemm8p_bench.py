@@ -50,11 +50,14 @@ def main():
         out = torch.empty(M, ncols, device=dev, dtype=torch.float16)
         resid = None if epi else torch.randn(M, N, device=dev, dtype=torch.float16)
         forms = {"old": dict(), "g8": dict(tile_m=256, stages=8)}
+        if N % 64 == 0 and K % 64 == 0 and K >= 128:
+            forms["q8"] = dict(tile_m=256, tile_n=256, stages=8)
         descs = {k: [ops.make_gemm_desc(a, w, N, 1, M, 1, K, out, ncols, bias=bias, epilogue=epi, residual=resid,
                                         residual_ld=N if resid is not None else 0, **kw) for w in ws] for k, kw in forms.items()}
 
         def route(k):
             ops.set_option("gemm_dense8p", 0 if k == "old" else 1)
+            ops.set_option("gemm_dense8q", 0 if k == "old" else 1)
         wsp = None
         for k in forms:
             route(k)
@@ -87,7 +90,8 @@ def main():
             print(name, "skipped:", str(e)[:160], flush=True)
             continue
         finally:
-            ops.set_option("gemm_dense8p", 1)
+            ops.set_option("gemm_dense8p", 0)
+            ops.set_option("gemm_dense8q", 0)
         flops = 2.0 * M * N * K
         rec = dict(name=name, M=M, N=N, K=K, epi=epi)
         line = f"{name:18s} M={M:6d} N={N:5d} K={K:5d}"
