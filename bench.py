@@ -238,8 +238,8 @@ def cpu_baseline(n_evals=3):
     }
 
 
-PMC_FILE = "r03_pmc_traffic.json"
-PMC_MFMA_FILE = "r03_pmc_mfma.json"
+PMC_FILE = "r04_pmc_traffic.json"
+PMC_MFMA_FILE = "r04_pmc_mfma.json"      # the headline config; the other LDM configs: r04_pmc_mfma_<config>.json
 
 
 def pmc_traffic(gemm_launches_now):
@@ -268,7 +268,7 @@ def pmc_traffic(gemm_launches_now):
         return None, f"no PMC passes for this build ({type(e).__name__})"
 
 
-def pmc_mfma_busy(roof, gemm_launches_now):
+def pmc_mfma_busy(roof, gemm_launches_now, PMC_MFMA_FILE=PMC_MFMA_FILE):
     """Matrix-pipe occupancy per kernel family of THIS bench command, from the committed rocprofv3 PMC pass
     (tools/pmc_mfma.py: SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 32 SIMDs per shader engine)).
     PMC counters cannot be read from inside the timed process; the file is used only when its GEMM-family launch count per
@@ -493,6 +493,8 @@ def run_config(config, args, rank, world, device, steps, warmup, cpu):
             if config == "sd2_512":
                 roof["traffic"], roof["traffic_note"] = pmc_traffic(gemm_launches)
                 pmc_mfma_busy(roof, gemm_launches)
+            elif os.path.exists(os.path.join(ROOT, "profiles", f"r04_pmc_mfma_{config}.json")):
+                pmc_mfma_busy(roof, gemm_launches, f"r04_pmc_mfma_{config}.json")
         else:
             # Taichu-GLIDE: one image = 60 guided base evaluations (UNet batch 2P) + 27 super-resolution evaluations (batch P);
             # profile both plans and weight them by their evaluation counts

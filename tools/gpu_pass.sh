@@ -52,6 +52,17 @@ PY
         echo "pmc mfma attempt $attempt failed"
       done
       python tools/pmc_mfma.py $(find gpurun_out/pmc/MFMA -name '*_results.db' | head -1) "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph --no-other-configs (the timed configuration launched eagerly: rocprofv3 --pmc segfaults on hipGraph replay)" ${ATTN_PER_EVAL:-27} > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err; rm -rf gpurun_out/pmc/MFMA; cat $OUT/pmc_mfma.json | head -70; tail -3 $OUT/pmc_mfma.err ;;
+    pmc_mfma_cfg)     # matrix-pipe occupancy of the other LDM configs (one evaluation each, eager)
+      for cfg in wukong_512_plms sd2_768; do
+        for attempt in 1 2 3; do
+          rm -rf gpurun_out/pmc/MFMA_$cfg
+          timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d gpurun_out/pmc/MFMA_$cfg -o pmc -- python bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $OUT/pmc_mfma_$cfg.log 2>&1
+          [ -n "$(find gpurun_out/pmc/MFMA_$cfg -name '*_results.db' 2>/dev/null | head -1)" ] && break
+          echo "pmc mfma $cfg attempt $attempt failed"
+        done
+        python tools/pmc_mfma.py $(find gpurun_out/pmc/MFMA_$cfg -name '*_results.db' | head -1) "python bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-graph (launched eagerly: rocprofv3 --pmc segfaults on hipGraph replay)" 27 > $OUT/pmc_mfma_$cfg.json 2> $OUT/pmc_mfma_$cfg.err; rm -rf gpurun_out/pmc/MFMA_$cfg; python -c "
+import json; d=json.load(open('$OUT/pmc_mfma_$cfg.json')); print('$cfg', {k: (v['launches_per_eval'], v['mfma_busy']) for k, v in d['families'].items()})"
+      done ;;
     profcfg)     # kernel traces of the other BASELINE configs (one unit each)
       for cfg in wukong_512_plms sd2_768 glide_256; do
         timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_cfg -o $TAG -- python bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline > $OUT/${cfg}_prof.log 2>&1
