@@ -65,6 +65,11 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
     constexpr int V_DMA = (V_ROWS / 8 + 3) / 4;   // V DMA instructions per wave per tile (8 rows each)
     constexpr int V_BYTES = V_ROWS * V_ROWB;
     constexpr int STAGE = K_BYTES + V_BYTES;
+    // Row sums through the matrix pipe where the V^T tile has a spare row (D = 40, 80: the 32-row d tiles are padded): row D of the
+    // LDS tile is all ones (written once; the DMA never touches rows >= D), so O^T[D][q] accumulates sum_key P[q][key] in the PV
+    // MFMAs that run anyway -- of the fp16 P the MFMA multiplies, rescaled with O for free -- and the softmax loses its 24 VALU
+    // additions per lane and tile (of ~140; the kernel is VALU-bound).  D = 64 / 160 have no spare row and keep the VALU sum.
+    constexpr bool LROW = (D % 32) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int j = 0; j < V_DMA; ++j) {
             const int inst = wave * V_DMA + j;
-            if (inst * 8 < V_ROWS) {
+            if (inst * 8 < (LROW ? D : V_ROWS)) {                     // LROW: rows >= D hold the ones row / zeros, never refilled
                 const int row = inst * 8 + (lane >> 3);               // d row
                 const unsigned chunk = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
                 const int kc = key0 + (int)chunk * 8;                  // first key of this 16-B chunk
@@ -213,11 +218,11 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
                 const f32x2 x2 = {acc_s[kt][r], acc_s[kt][r + 1]};
                 const f32x2 a2 = __builtin_elementwise_fma(x2, sc2, nmb2);
                 const f32x2 pv2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
-                psum2 += pv2;
+                if constexpr (!LROW) psum2 += pv2;
                 pf[kt * 2 + (r >> 3)][r & 7] = (f16)pv2.x;
                 pf[kt * 2 + (r >> 3)][(r & 7) + 1] = (f16)pv2.y;
             }
-        l_run += psum2.x + psum2.y;
+        if constexpr (!LROW) l_run += psum2.x + psum2.y;
 
         // ---- O^T += V^T P^T
 #pragma unroll
@@ -244,6 +249,16 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
     }
     const int nfull_l = min(nfull, t_end);
 
+    if constexpr (LROW) {      // rows D .. V_ROWS - 1 of both V^T buffers: row D = ones, the rest zero (16-byte pieces, 8 per row)
+        for (int i = tid; i < 2 * (V_ROWS - D) * 8; i += 256) {
+            const int buf = i / ((V_ROWS - D) * 8), rem = i - buf * (V_ROWS - D) * 8;
+            const int row = D + (rem >> 3);
+            f16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = row == D ? (f16)1.0f : (f16)0.f;
+            *reinterpret_cast<f16x8*>(smem + buf * STAGE + K_BYTES + row * V_ROWB + (rem & 7) * 16) = v;
+        }
+    }
     // tile t lives in LDS buffer t & 1; tile t + 1 is staged while tile t is computed
     stage_tile(t_begin, 0);
     __syncthreads();
@@ -268,7 +283,15 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
     }
 
     // ---- finalize: O /= l ; stage [q][d] per wave in LDS, then full-row stores
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if constexpr (LROW) {      // O^T row D: d tile D / 32, local row D % 32 = (r & 3) + 8 (r >> 2) + 4 hi
+        constexpr int LR = D % 32, LREG = (LR & 3) + 4 * (LR >> 3), LHI = (LR >> 2) & 1;
+        const float mine = acc_o[D / 32][LREG];
+        const float other = __shfl_xor(mine, 32, 64);
+        l_tot = (hi == LHI) ? mine : other;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = 1.0f / l_tot;
     constexpr int OLD = DT * 32 + 8;
     f16* og = reinterpret_cast<f16*>(smem) + wave * 32 * OLD;
