@@ -532,6 +532,8 @@ void gn_geometry(GnParams& p) {
     while (cw > L && ((p.CC + cw - 1) / cw) * p.B * slabs < min_blocks) cw -= L;
     p.cw = cw;
     p.ncb = (p.CC + cw - 1) / cw;
+    // (four times the slabs for tensors of tens of MB, as the column-statistics path does, measured -0.8 % on GLIDE's 128^2 / 256^2
+    // tensors -- the statistics pass folds more partials: not taken here)
     int nblk = (GN_TARGET_BLOCKS + p.ncb * p.B - 1) / (p.ncb * p.B);
     if (nblk > cap) nblk = cap;
     if (nblk > max_by_pix) nblk = max_by_pix;
@@ -653,9 +655,27 @@ static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const 
         int cw = L * ((minc + L - 1) / L);   // >= 16 * gn_col_chunks bytes per pixel row (default 64)
         if (cw > 64) cw = L * (64 / L);      // (<= 64 chunk columns per block: one per thread row)
         if (cw > p.CC) cw = p.CC;
+        // Big tensors (UNet batch >= 8 at the 64 x 64 / 32 x 32 levels: >= gn_wide_rows pixel rows in all) are bandwidth-, not
+        // latency-bound, and 80-byte column blocks read every 128-byte line of a pixel row from two or three blocks (1.3 TB/s on a
+        // 84 MB GroupNorm): the widest column block of whole groups, line-aligned where the group width allows, and more slabs.
+        // The fold then costs chs * nrb loads per block, so the planner hands such launches pre-folded statistics (nrb = 1).
+        int target = GN_TARGET_BLOCKS;
+        const int wide_rows = mdx_opt(MDX_OPT_GN_WIDE_ROWS);
+        // 1024 blocks keep too few bytes in flight for a tensor of tens of MB (2.8 TB/s on 84-168 MB at UNet batch 16): four times
+        // the slabs from gn_boost_mb on (tools/exp/r04k_gn_bench.py, profiles/r04_gn_bench.txt: 64 x 64 x 640 at batch 16 60.8 -> 41.8 us,
+        // 32 x 32 x 1280 36.2 -> 25.8, 64 x 64 x 320 28.4 -> 25.9; the batch-2 tensors, 10 MB, lose 3 us and stay below the threshold)
+        const int boost_mb = mdx_opt(MDX_OPT_GN_BOOST_MB);
+        if (boost_mb > 0 && (size_t)B * HW * C * 2 >= ((size_t)boost_mb << 20)) target = 4 * GN_TARGET_BLOCKS;
+        if (wide_rows > 0 && (long)B * HW >= wide_rows) {
+            const int cap = p.CC < 64 ? p.CC : 64;
+            const int l8 = L / gcd_i(L, 8) * 8;          // whole groups AND whole 128-byte lines
+            cw = l8 <= cap ? (cap / l8) * l8 : (cap / L) * L;
+            if (cw < L) cw = L > p.CC ? p.CC : L;
+            target = 4 * GN_TARGET_BLOCKS;
+        }
         p.cw = cw;
         p.ncb = (p.CC + cw - 1) / cw;
-        int nblk = (GN_TARGET_BLOCKS + p.ncb * B - 1) / (p.ncb * B);
+        int nblk = (target + p.ncb * B - 1) / (p.ncb * B);
         const int max_by_pix = (HW + 3) / 4;
         if (nblk > 256) nblk = 256;
         if (nblk > max_by_pix) nblk = max_by_pix;

@@ -1,0 +1,8 @@
+set -u
+export TMPDIR=/tmp
+OUT=gpurun_out/r04l; mkdir -p $OUT
+timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "groupnorm or gn" 2>&1 | tail -4 > $OUT/pytest_gn.txt; cat $OUT/pytest_gn.txt
+timeout 300 python tools/eval_ab.py --model wukong --batch 16 --latent 64 --rounds 3 --iters 5 --arms "g0:gn_boost_mb=0" "g40:gn_boost_mb=40" > $OUT/eval_ab_wukong.txt 2>&1; grep -v amdgpu.ids $OUT/eval_ab_wukong.txt
+timeout 300 python tools/eval_ab.py --model sd2 --batch 8 --latent 96 --rounds 3 --iters 5 --arms "g0:gn_boost_mb=0" "g40:gn_boost_mb=40" > $OUT/eval_ab_sd2_768.txt 2>&1; grep -v amdgpu.ids $OUT/eval_ab_sd2_768.txt
+for a in 0 40; do MDX_GN_BOOST_MB=$a timeout 300 python bench.py --config glide_256 --no-cpu-baseline --steps 2 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('glide gn_boost_mb=$a', d['value'], d['unit'])"; done
+for a in 40 0; do MDX_GN_BOOST_MB=$a timeout 300 python bench.py --config glide_256 --no-cpu-baseline --steps 2 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('glide gn_boost_mb=$a', d['value'], d['unit'])"; done
