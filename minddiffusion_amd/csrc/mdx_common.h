@@ -73,6 +73,7 @@ enum MdxOpt {
     MDX_OPT_ATTN8,               // (default 0: measured slower, csrc/attention.hip) 1: self-attention launches with >= attn8_min_blocks 256-query blocks use the eight-wave kernel; 2: always when eligible
     MDX_OPT_ATTN8_MIN_BLOCKS,    // (192)
     MDX_OPT_GN_WIDE_ROWS,        // column-statistics GroupNorm on tensors of at least this many pixel rows (B * H * W) uses the widest line-aligned column blocks (default 0 = never: only pays with pre-folded statistics, profiles/r04_gn_bench.txt)
+    MDX_OPT_GN_FUSED_SMALL,      // (default 0: -0.2 % / -0.15 % / 0 on Wukong / 768^2 / GLIDE, within noise) 1: the one-launch GroupNorm runs 256-thread blocks when its (column block, sample) grid has >= 512 blocks
     MDX_OPT_GN_BOOST_MB,         // column-statistics GroupNorm on tensors of at least this many MB launches four times the pixel slabs (40; 0 = never)
     MDX_OPT_GEMM_DENSE8Q,        // (default 0: faster alone, +0.2 ... +1.7 % SLOWER inside an evaluation, csrc/gemm8p.hip) 1: dense launches whose shape fits 256 x 256 tiles (M >= gemm_dense8p_min_m, >= 192 tiles, N padding <= 1/8) run on the 256 x 256 eight-wave core (gemm8p.hip, gemm8q_kernel)
     MDX_OPT_GEMM_DENSE8Q_VAR,    // forms of gemm8q_kernel: 0 = DMA issue in the MFMA burst, 32 = in the read burst (+10 % at long K); 1-7 (+32) are timing ablations with WRONG results

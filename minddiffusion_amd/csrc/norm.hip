@@ -345,15 +345,17 @@ __device__ __forceinline__ f16x8 gn_slab_load(const MdxSplitInfo& sp, int b, int
     return o;
 }
 
-template <bool SLAB>
-__global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GnParams p, const MdxSplitInfo sp) {
+// NT = threads per block: 1024, or 256 for launches whose (column block, sample) grid fills the chip on its own (UNet batch >= 8:
+// 512+ blocks) -- a quarter of the threads per barrier, four times the blocks per CU.
+template <bool SLAB, int NT = GNF_THREADS>
+__global__ __launch_bounds__(NT) void gn_fused_kernel(const GnParams p, const MdxSplitInfo sp) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [trows][chs][2] partials, then the folds
     const int b = blockIdx.y, cb = blockIdx.x;
     const int col0 = cb * p.cw;
     const int cols = min(p.cw, p.CC - col0);
     const int chs = cols * 8;
     const int tid = threadIdx.x;
-    const int trows = GNF_THREADS / cols;
+    const int trows = NT / cols;
     const int tc = tid % cols, tr = tid / cols;
     const bool active = tr < trows;
     f16x8 keep[SLAB ? GNF_KEEP : 1];
@@ -391,6 +393,19 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GnParams p,
                     q[e] += f * f;
                 }
         }
+        for (; pix + 3 * trows < p.HW; pix += 4 * trows) {      // (same order of additions as one pixel at a time: same bits)
+            f16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = gn_load(p, b, pix + u * trows, col0 + tc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[u][e];
+                    s[e] += f;
+                    q[e] += f * f;
+                }
+        }
         for (; pix < p.HW; pix += trows) {
             const f16x8 v = gn_load(p, b, pix, col0 + tc);
 #pragma unroll
@@ -409,9 +424,9 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GnParams p,
     }
     __syncthreads();
     // fold the trows partial rows per channel in two fixed-order levels (trows -> GNF_FOLD -> 1)
-    float* f16p = red + (size_t)GNF_THREADS * 8 * 2;      // [GNF_FOLD][chs][2]
+    float* f16p = red + (size_t)NT * 8 * 2;      // [GNF_FOLD][chs][2]
     float* csum = f16p + (size_t)GNF_FOLD * 512 * 2;      // [chs][2]
-    for (int i = tid; i < GNF_FOLD * chs; i += GNF_THREADS) {
+    for (int i = tid; i < GNF_FOLD * chs; i += NT) {
         const int g16 = i / chs, c = i - g16 * chs;
         float s = 0.f, q = 0.f;
         for (int r = g16; r < trows; r += GNF_FOLD) {
@@ -422,7 +437,7 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GnParams p,
         f16p[(g16 * chs + c) * 2 + 1] = q;
     }
     __syncthreads();
-    for (int c = tid; c < chs; c += GNF_THREADS) {
+    for (int c = tid; c < chs; c += NT) {
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int g16 = 0; g16 < GNF_FOLD; ++g16) {
@@ -461,7 +476,7 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GnParams p,
         }
     }
     __syncthreads();
-    for (int c = tid; c < chs; c += GNF_THREADS) {
+    for (int c = tid; c < chs; c += NT) {
         const int g = c / p.cpg;
         float a = p.gamma[col0 * 8 + c] * gstat[g * 2 + 1];
         float sh = p.beta[col0 * 8 + c] - gstat[g * 2] * a;
@@ -504,6 +519,13 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GnParams p,
         for (int u = 0; u < 8; ++u) v[u] = gn_load(p, b, pix + u * trows, col0 + tc);
 #pragma unroll
         for (int u = 0; u < 8; ++u) apply(v[u], pix + u * trows);
+    }
+    for (; pix + 3 * trows < p.HW; pix += 4 * trows) {
+        f16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = gn_load(p, b, pix + u * trows, col0 + tc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) apply(v[u], pix + u * trows);
     }
     for (; pix < p.HW; pix += trows) apply(gn_load(p, b, pix, col0 + tc), pix);
 }
@@ -699,6 +721,17 @@ static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const 
             p.nblk = 1;
             p.pix = HW;
             constexpr size_t lds = ((size_t)GNF_THREADS * 8 * 2 + (size_t)GNF_FOLD * 512 * 2 + 512 * 2 + 64 * 2 + 512 * 2) * sizeof(float);
+            if (mdx_opt(MDX_OPT_GN_FUSED_SMALL) && p.ncb * B >= 512 && p.cw <= 32) {     // the grid fills the chip: 256-thread blocks
+                constexpr size_t lds4 = ((size_t)256 * 8 * 2 + (size_t)GNF_FOLD * 512 * 2 + 512 * 2 + 64 * 2 + 512 * 2) * sizeof(float);
+                static MdxPerDeviceOnce attr4_once;
+                if (attr4_once.first()) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<false, 256>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                }
+                hipLaunchKernelGGL((gn_fused_kernel<false, 256>), dim3(p.ncb, B), dim3(256), lds4, st, p, MdxSplitInfo{});
+                MDX_LAUNCH_CHECK("mdx_groupnorm_f16(fused, 256 threads)");
+                return MDX_OK;
+            }
             static MdxPerDeviceOnce attr_once;
             if (attr_once.first()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<false>),
