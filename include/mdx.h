@@ -458,6 +458,10 @@ int mdx_probe_l2_stream(const void* src, size_t total_bytes, unsigned bytes_per_
 /* diagnostics: register a device buffer (bytes >= 64 x blocks) that the blocks of subsequent mdx_gemm_f16 launches
  * fill with phase timestamps (8 x u64 per block, 100 MHz realtime counter); NULL unregisters.  tools/gemm_trace.py */
 int mdx_probe_gemm_trace(void* buf, size_t bytes);
+/* VALU issue-rate probe (no reference counterpart; diagnostics): `iters` rounds of eight independent chains per lane of one
+ * instruction kind -- 0 v_fma_f32, 1 v_exp_f32, 2 v_pk_fma_f32, 3 v_cvt_pk_f16_f32 (+ two converts back), 4 v_max3_f32 -- on
+ * `nblocks` blocks of 256 threads; time it from the host (tools/exp/r04n_valu_probe.py). */
+int mdx_probe_valu_rate(int kind, int iters, int nblocks, float* sink, mdx_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -422,3 +422,51 @@ extern "C" int mdx_probe_l2_stream(const void* src, size_t total_bytes, unsigned
     MDX_LAUNCH_CHECK("mdx_probe_l2_stream");
     return MDX_OK;
 }
+
+// ------------------------------------------------------------------ VALU issue-rate probe (tools/exp/r04n_valu_probe.py)
+namespace {
+// kind 0: v_fma_f32, 1: v_exp_f32, 2: v_pk_fma_f32 (two results), 3: v_cvt_pk_f16_f32, 4: v_max3_f32 -- eight independent chains per lane
+template <int KIND>
+__global__ __launch_bounds__(256) void valu_probe_kernel(int iters, float* sink) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float x[8];
+    f32x2 y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        x[i] = 0.001f * (float)(threadIdx.x + i) - 0.5f;
+        y[i] = f32x2{x[i], -x[i]};
+    }
+    const f32x2 c2 = {0.999f, 1.001f}, d2 = {1e-6f, -1e-6f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (KIND == 0) x[i] = __builtin_fmaf(x[i], 0.999f, 1e-6f);
+            else if (KIND == 1) x[i] = __builtin_amdgcn_exp2f(x[i]);
+            else if (KIND == 2) y[i] = __builtin_elementwise_fma(y[i], c2, d2);
+            else if (KIND == 3) {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 h = {(_Float16)x[i], (_Float16)x[(i + 1) & 7]};
+                x[i] = (float)h[0] + (float)h[1];
+            } else x[i] = __builtin_fmaxf(__builtin_fmaxf(x[i], x[(i + 1) & 7]), x[(i + 2) & 7]) * 0.5f;
+        }
+    }
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a += x[i] + y[i].x + y[i].y;
+    if (a == 123.456f) sink[0] = a;
+}
+}  // namespace
+
+extern "C" int mdx_probe_valu_rate(int kind, int iters, int nblocks, float* sink, mdx_stream_t s) {
+    MDX_REQUIRE(sink && iters > 0 && nblocks > 0 && kind >= 0 && kind <= 4, "mdx_probe_valu_rate: bad arguments");
+    hipStream_t st = (hipStream_t)s;
+    switch (kind) {
+        case 0: hipLaunchKernelGGL(valu_probe_kernel<0>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 1: hipLaunchKernelGGL(valu_probe_kernel<1>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 2: hipLaunchKernelGGL(valu_probe_kernel<2>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 3: hipLaunchKernelGGL(valu_probe_kernel<3>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        default: hipLaunchKernelGGL(valu_probe_kernel<4>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+    }
+    MDX_LAUNCH_CHECK("mdx_probe_valu_rate");
+    return MDX_OK;
+}
