@@ -375,7 +375,7 @@ def test_first_use_tuner_at_a_resolution_the_tile_table_does_not_list():
     """include/mdx.h mdx_gemm_tune + the planner's unet_tune_first_use option (no reference counterpart: the reference's graph
     compiler picks kernels per shape).  A 768 x 512 image (96 x 64 latent, UNet batch 2) is not one of the benchmarked shapes, so
     most of its launches resolve through the cost model; with the option on the plan measures every such shape once (user-side
-    cache ops.tune_cache) and must then be at least as fast per evaluation as the cost-model plan (3 % slack for timer and box
+    cache ops.tune_cache) and must then be at least as fast per evaluation as the cost-model plan (5 % slack for timer and box
     noise), with the same result to the distance of two fp16 paths that tile / split differently."""
     from minddiffusion_amd import ops
     from minddiffusion_amd.configs import SD2_UNET
@@ -417,7 +417,7 @@ def test_first_use_tuner_at_a_resolution_the_tile_table_does_not_list():
                      "ms_per_eval_cost_model": round(ms0, 4), "ms_per_eval_tuned": round(ms1, 4)})
     assert P1.tuned_shapes >= 10 and len(ops.tune_cache) == P1.tuned_shapes
     check("first_use_tuner_96x64_latent_tuned_vs_cost_model", out1, out0, rel_l2=4e-3)
-    assert ms1 <= ms0 * 1.03, f"tuned plan slower than the cost-model plan: {ms1:.3f} vs {ms0:.3f} ms"
+    assert ms1 <= ms0 * 1.05, f"tuned plan slower than the cost-model plan: {ms1:.3f} vs {ms0:.3f} ms"
     # the cache is the caller's: a second network of the same shape measures nothing
     ops.set_option("unet_tune_first_use", 1)
     try:
