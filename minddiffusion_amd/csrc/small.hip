@@ -321,10 +321,40 @@ __global__ __launch_bounds__(512) void dma_probe_kernel(const char* src, size_t 
     const int nw = blockDim.x >> 6;
     const size_t tile_bytes = (size_t)nw * per * 1024;
     const int nt = (int)(bytes_per_block / tile_bytes);
-    const char* base = src + (size_t)blockIdx.x * bytes_per_block;
+    const bool shared = (mode & 4) != 0;        // every block streams the SAME region (L2-resident operands shared by the tiles of a launch)
+    mode &= 3;
+    const char* base = src + (shared ? 0 : (size_t)blockIdx.x * bytes_per_block);
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, (unsigned)bytes_per_block);
     float acc = 0.f;
-    if (mode == 0) {
+    if (mode == 2) {
+        // BOTH paths at once (round 4): per tile every wave issues `per` LDS-DMA instructions AND `per` plain 16-byte loads into
+        // registers (of the next region: 2 x tile_bytes per step), to see whether the two operand paths add up on a CU
+        typedef unsigned pu4 __attribute__((ext_vector_type(4)));
+        const int nt2 = nt / 2;
+        auto issue = [&](int t, int stage) {
+            for (int j = 0; j < per; ++j) {
+                const unsigned off = (unsigned)((size_t)(2 * t) * tile_bytes + ((wave * per + j) * 64 + lane) * 16);
+                dma16(rs, smem + (size_t)stage * tile_bytes + (wave * per + j) * 1024, off);
+            }
+        };
+        pu4 v[8];
+        unsigned x = 0;
+        for (int i = 0; i < NS - 1 && i < nt2; ++i) issue(i, i);
+        int wr = NS - 1;
+        for (int t = 0; t < nt2; ++t) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < per) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(((wave * per + j) * 64 + lane) * 16), (unsigned)((size_t)(2 * t + 1) * tile_bytes), 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + NS - 1 < nt2) issue(t + NS - 1, wr);
+            wr = (wr + 1 == NS) ? 0 : wr + 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < per) x ^= v[j][0] ^ v[j][3];
+        }
+        acc = ((float*)smem)[threadIdx.x] + (float)(x & 1);
+    } else if (mode == 0) {
         auto issue = [&](int t, int stage) {
             for (int j = 0; j < per; ++j) {
                 const unsigned off = (unsigned)((size_t)(t * stride_tiles % nt) * tile_bytes + ((wave * per + j) * 64 + lane) * 16);
