@@ -209,7 +209,31 @@ def case_glide_threeway():
     print("wrote glide_threeway.json", res, flush=True)
 
 
-CASES = dict(config1=case_config1, config2=case_config2, config3=case_config3, config4=case_config4,
+def case_short():
+    """The SHORT full-size trajectories of tests/test_configs_gpu.py (config 1 DDIM-10, config 2 PLMS-5, config 3 DDIM-4 -- same UNets
+    and inputs as the benchmarked-length cases above, fewer steps), kept in fp32: 40 oracle row evaluations the GPU box then does
+    not spend (240 s of its 1200 s test budget in round 3)."""
+    from oracle import ldm as O
+    out, meta = {}, dict(commit=_commit(), cases={})
+    for key, ocfg_name, inp, S in (("config1_ddim10", "SD2_UNET", inputs_config1(), 10), ("config2_plms5", "WUKONG_UNET", inputs_config2(), 5),
+                                   ("config3_ddim4", "SD2_UNET", inputs_config3(), 4)):
+        t0 = time.time()
+        ocfg = getattr(O, ocfg_name)
+        model = O.ModelOracle(O.UNetOracle(ocfg, O.init_params(ocfg, seed=inp["seed"])))
+        hw = inp["hw"]
+        ref, inter = O.sample(model, S, 1, (4, hw, hw), inp["c"][:1], inp["x_T"][:1], inp["sampler"],
+                              unconditional_guidance_scale=inp["scale"], unconditional_conditioning=inp["uc"][:1])
+        out[key + "_final"] = ref.numpy().astype(np.float32)
+        out[key + "_pred_x0"] = inter["pred_x0"][-1].numpy().astype(np.float32)
+        meta["cases"][key] = dict(oracle_cfg=ocfg_name, unet_seed=inp["seed"], S=S, sampler=inp["sampler"], scale=inp["scale"], latent=hw,
+                                  unet_calls=model.calls, oracle_seconds=round(time.time() - t0, 1))
+        print(key, meta["cases"][key], flush=True)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "short_traj.npz"), **out)
+    print("wrote short_traj.npz", flush=True)
+
+
+CASES = dict(short=case_short, config1=case_config1, config2=case_config2, config3=case_config3, config4=case_config4,
              glide_threeway=case_glide_threeway)
 
 if __name__ == "__main__":
