@@ -1560,8 +1560,13 @@ static bool gemm8p_wanted(const mdx_gemm_desc* d, const GemmParams& p) {
     if (mdx_opt(MDX_OPT_GEMM_BM) || mdx_opt(MDX_OPT_GEMM_BN)) return false;
     if (!mdx_gemm8p_eligible(p)) return false;
     if (d->tile_m == 256 && d->stages == 8 && d->tile_n != 256) return true;       // forced: independent of the option (tile_n 256: gemm8q)
-    if (!mdx_opt(MDX_OPT_GEMM_DENSE8P)) return false;
+    const int mode = mdx_opt(MDX_OPT_GEMM_DENSE8P);
+    if (!mode) return false;
     if (d->tile_m != 0 || d->stages != 0 || (d->tile_n != 0 && d->tile_n != 128)) return false;
+    // mode 2: only the long-K launches with the plain epilogue -- the feed-forward's second GEMM (K = 4 C) -- where the K loop,
+    // not the epilogue, is the launch: 84 -> 80 us and 83 -> 69 us on Wukong's two levels alone (profiles/r04_gemm8q_bench.txt); the
+    // GEGLU / q|k|v / LayerNorm-fold consumers lose with one block per CU inside an evaluation and keep the four-wave tiles
+    if (mode == 2 && (p.K < 2048 || p.epilogue != MDX_EPI_NONE || p.ln_stats || p.n_split)) return false;
     return p.M >= mdx_opt(MDX_OPT_GEMM_DENSE8P_MIN_M) && mdx_gemm8p_tiles(p) >= 128;
 }
 

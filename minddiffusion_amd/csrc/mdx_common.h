@@ -66,7 +66,7 @@ enum MdxOpt {
     MDX_OPT_GN_COL_CHUNKS,       // column-statistics GroupNorm: a column block spans at least this many 16-byte chunks of a pixel row (4)
     MDX_OPT_GEMM_CONV8P,         // 1: eligible 3x3 convs with M >= gemm_conv8p_min_m run on the 256-pixel 8-wave core (conv8p.hip)
     MDX_OPT_GEMM_CONV8P_MIN_M,   // smallest M the 8-wave conv core is chosen for automatically (4096; it also needs >= 128 tiles)
-    MDX_OPT_GEMM_DENSE8P,        // (default 0: measured equal-or-slower inside a UNet evaluation, tools/eval_ab.py) 1: eligible dense launches with M >= gemm_dense8p_min_m and >= 128 tiles run on the 256 x 128 8-wave core (gemm8p.hip)
+    MDX_OPT_GEMM_DENSE8P,        // 0 (default): never; 1: all eligible dense launches (measured equal-or-slower inside a UNet evaluation, tools/eval_ab.py); 2: only long-K (K >= 2048) launches with the plain epilogue -- the feed-forward's second GEMM (-0.3 % on Wukong, -0.07 % on 768^2: within noise, and it would bypass the tuned rows of those shapes) with M >= gemm_dense8p_min_m and >= 128 tiles run on the 256 x 128 8-wave core (gemm8p.hip)
     MDX_OPT_GEMM_DENSE8P_MIN_M,  // (4096)
     MDX_OPT_GEMM_SUBPIXEL_MIN_TILES,   // nearest-2x + 3x3 convs with w_sub run the sub-pixel form from this many 256-pixel tiles (32)
     MDX_OPT_GEMM_CONV8P_VAR,     // experiment forms of the 160-column conv8p kernel (conv8p.hip VAR; 0 = the product)
