@@ -64,6 +64,13 @@ CONFIGS = {
                                metric="512x512 txt2img latents/sec (50-step DPM-Solver++ 2M)",
                                workload="SDv2 txt2img 512x512, DPM-Solver++ (multistep order 2, time_uniform) with the "
                                         "CLI's default 50 steps, CFG 9.0, batch 1 per GPU (configs[1] with --dpm_solver)"),
+    # wukong-huahua/inpaint.py with its CLI defaults (batch 4, PLMS 30 steps, scale 7.5) on the 9-channel UNet
+    "wukong_512_inpaint": dict(family="ldm", unet="wukong_inpaint", latent=64, sampler="plms", steps=30, scale=7.5, batch=4,
+                               ctx_dim=768, tflop_per_row=0.803, inpaint=True, unit="latents/s",
+                               metric="512x512 inpainting latents/sec (30-step PLMS, Wukong-Huahua inpaint)",
+                               workload="Wukong-Huahua inpainting 512x512 (LatentInpaintDiffusion, hybrid conditioning: UNet input "
+                                        "= latent + resized mask + masked-image latent = 9 channels), PLMS 30 steps (31 UNet "
+                                        "calls), CFG 7.5, batch 4 per GPU (inpaint.py CLI defaults; every rank its own images)"),
     "glide_256": dict(family="glide", batch=8, scale=5.0, tflop_per_image=63.2, unit="images/s",
                       metric="Taichu-GLIDE 256x256 images/sec (60-step guided base + 27-step DDIM super-res)",
                       workload="Taichu-GLIDE 64x64 base (60 ancestral steps, CFG 5, UNet batch 2P) + 256x256 super-res "
@@ -125,11 +132,14 @@ def build_model(device, cfg_name="sd2"):
     from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
     from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
     from minddiffusion_amd.weights import synthetic_unet_params_device
-    ucfg = dict(SD2_UNET if cfg_name == "sd2" else WUKONG_UNET)
+    from minddiffusion_amd.configs import WUKONG_INPAINT_UNET
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentInpaintDiffusion
+    ucfg = dict({"sd2": SD2_UNET, "wukong": WUKONG_UNET, "wukong_inpaint": WUKONG_INPAINT_UNET}[cfg_name])
     net = UNetModel(device=device, **ucfg)
     net.load_state_dict(synthetic_unet_params_device(net.parameter_shapes(), seed=0, device=device))
     torch.cuda.synchronize()
-    model = LatentDiffusion(net, **{k: SD2_LDM[k] for k in ("linear_start", "linear_end", "timesteps", "scale_factor")})
+    cls = LatentInpaintDiffusion if cfg_name == "wukong_inpaint" else LatentDiffusion
+    model = cls(unet_config=net, **{k: SD2_LDM[k] for k in ("linear_start", "linear_end", "timesteps", "scale_factor")})
     return model
 
 
@@ -368,7 +378,25 @@ def run_config(config, args, rank, world, device, steps, warmup, cpu):
 
         prompts = ["a photograph of an astronaut riding a horse"] * Bg
 
+        if cfg.get("inpaint"):
+            # inpaint.py:65-106: dict conditioning {c_concat: cat(resized mask, masked-image latent), c_crossattn: text}, the
+            # same c_concat on the unconditional half, x0 = the masked-image latent, no mask blend; every rank runs its own
+            # `batch` images (synthetic, seeded per rank: the hybrid conditioning is not part of the txt2img broadcast)
+            from minddiffusion_amd.ldm.models.diffusion.plms import PLMSSampler
+            rs = np.random.RandomState(100 + rank)
+            td = lambda a, dt=torch.float32: torch.from_numpy(a.astype(np.float32)).to(device, dt)
+            ic = td(rs.randn(batch, 77, cfg["ctx_dim"]), torch.float16)
+            iuc = td(np.repeat(rs.randn(1, 77, cfg["ctx_dim"]), batch, 0), torch.float16)
+            ix = td(rs.randn(batch, 4, h, w))
+            icat = td(np.concatenate([(rs.rand(batch, 1, h, w) > 0.5), rs.randn(batch, 4, h, w)], 1))
+            isampler = PLMSSampler(model)
+
         def one_step():
+            if cfg.get("inpaint"):
+                return isampler.sample(cfg["steps"], batch, (4, h, w), conditioning={"c_concat": icat, "c_crossattn": ic},
+                                       x_T=ix, unconditional_guidance_scale=cfg["scale"],
+                                       unconditional_conditioning={"c_concat": icat, "c_crossattn": iuc}, x0=icat[:, 1:],
+                                       verbose=False)[0]
             if cfg.get("text"):     # rank 0 encodes [prompts; empty prompts]; the pipeline broadcasts the embeddings
                 return pipe(prompts=prompts, x_T=x_T, H=8 * h, W=8 * w, steps=cfg["steps"], scale=cfg["scale"], eta=0.0,
                             decode=True)
@@ -442,7 +470,7 @@ def run_config(config, args, rank, world, device, steps, warmup, cpu):
             # per-UNet-step ms: HIP events around apply_model (CFG batch = 2 x per-GPU batch), median of 20 warm calls
             nb = 2 * batch
             ctx = torch.randn(nb, 77, cfg["ctx_dim"], device=device, dtype=torch.float16)
-            xs = torch.randn(nb, 4, h, w, device=device)
+            xs = torch.randn(nb, model.unet.in_channels, h, w, device=device)     # (9 channels for the inpainting UNet)
             tsv = torch.full((nb,), 501.0, device=device)
             for _ in range(3):
                 model.apply_model_nhwc(xs, tsv, ctx)

@@ -11,6 +11,10 @@ WUKONG_UNET = dict(image_size=32, in_channels=4, out_channels=4, model_channels=
                    num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
                    transformer_depth=1, context_dim=768, use_checkpoint=True, legacy=False, use_fp16=True)
 
+# vision/wukong-huahua/configs/wukong-huahua_inpaint_inference.yaml:20-36: the same UNet on 9 input channels
+# (4 latent + 1 resized mask + 4 masked-image latent), LatentInpaintDiffusion / conditioning_key 'hybrid'
+WUKONG_INPAINT_UNET = dict(WUKONG_UNET, in_channels=9)
+
 # LatentDiffusion params common to both YAMLs (v2-inference.yaml:5-19)
 SD2_LDM = dict(linear_start=0.00085, linear_end=0.0120, timesteps=1000, scale_factor=0.18215,
                conditioning_key="crossattn", image_size=64, channels=4, use_fp16=True)

@@ -17,23 +17,31 @@ from ...modules.diffusionmodules.util import make_beta_schedule
 
 
 class DiffusionWrapper:
-    """ddpm.py:346-357 (SD2) / WK ddpm.py:360-377."""
+    """ddpm.py:346-357 (SD2) / WK ddpm.py:354-377: all five conditioning keys.  None / 'concat' / 'adm' call the UNet without a
+    context -- attn2 then attends to its own input (attention.py:133) -- which the reference's UNet, like this one, only accepts
+    when context_dim equals the transformer width at every attention level."""
 
     def __init__(self, diff_model_config, conditioning_key):
         self.diffusion_model = (instantiate_from_config(diff_model_config)
                                 if isinstance(diff_model_config, dict) else diff_model_config)
         self.conditioning_key = conditioning_key
         assert self.conditioning_key in [None, "concat", "crossattn", "hybrid", "adm"]
-        if self.conditioning_key not in ("crossattn", "hybrid"):
-            raise NotImplementedError("only 'crossattn' (txt2img) and 'hybrid' (inpainting, WK ddpm.py:368-371) are used by "
-                                      "the reference's CLIs")
 
     def construct(self, x, t, c_concat=None, c_crossattn=None):
-        if self.conditioning_key == "hybrid":                       # WK ddpm.py:368-371
+        key = self.conditioning_key
+        if key in ("concat", "hybrid"):                             # WK ddpm.py:363-365, 368-371
             if c_concat is None:
-                raise MdxError("hybrid conditioning needs c_concat (mask + masked-image latent)")
-            x = torch.cat([x, _first(c_concat).to(x.dtype)], 1)
-        return self.diffusion_model(x, t, context=_first(c_crossattn))
+                raise MdxError(f"{key!r} conditioning needs c_concat")
+            x = torch.cat([x, _first(c_concat).to(device=x.device, dtype=x.dtype)], 1)
+        if key is None or key == "concat":                          # WK ddpm.py:361-365
+            return self.diffusion_model(x, t)
+        if key == "adm":                                            # WK ddpm.py:372-374: class labels ride in c_crossattn
+            if c_crossattn is None:
+                raise MdxError("'adm' conditioning needs the class labels in c_crossattn")
+            return self.diffusion_model(x, t, y=_first(c_crossattn))
+        if c_crossattn is None:
+            raise MdxError(f"{key!r} conditioning needs c_crossattn")
+        return self.diffusion_model(x, t, context=_first(c_crossattn))     # WK ddpm.py:366-371
 
     __call__ = construct
 
@@ -89,16 +97,22 @@ class LatentDiffusion:
 
     # ---- ddpm.py:290-306 (positional cond) and WK ddpm.py:276-278 (keywords); dict = hybrid conditioning (inpaint.py:84)
     def _split_cond(self, cond, c_concat=None, c_crossattn=None):
+        key = self.model.conditioning_key
         if isinstance(cond, dict):
             c_concat = cond.get("c_concat", c_concat)
             c_crossattn = cond.get("c_crossattn", c_crossattn)
         elif cond is not None:
-            c_crossattn = cond
+            # ddpm.py:299-300: a bare conditioning goes to the keyword the wrapper's key reads
+            if key == "concat":
+                c_concat = cond
+            else:
+                c_crossattn = cond
         c_crossattn, c_concat = _first(c_crossattn), _first(c_concat)
-        if c_crossattn is None:
-            raise MdxError("apply_model: a cross-attention conditioning tensor is required")
-        if (c_concat is not None) != (self.model.conditioning_key == "hybrid"):
-            raise MdxError(f"apply_model: conditioning_key={self.model.conditioning_key!r} "
+        if key in ("crossattn", "hybrid", "adm") and c_crossattn is None:
+            raise MdxError(f"apply_model: conditioning_key={key!r} needs "
+                           f"{'the class labels' if key == 'adm' else 'a cross-attention conditioning tensor'}")
+        if (c_concat is not None) != (key in ("hybrid", "concat")):
+            raise MdxError(f"apply_model: conditioning_key={key!r} "
                            f"{'needs' if c_concat is None else 'does not take'} c_concat")
         return c_concat, c_crossattn
 
@@ -109,8 +123,14 @@ class LatentDiffusion:
     def apply_model_nhwc(self, x_noisy, t, cond, temb=None):
         """Fast path used by the samplers: returns the UNet's static NHWC fp16 eps buffer [B, H*W, 8]
         (valid until the next call) so the fused sampler-step kernel can consume it without a layout pass.
-        `x_noisy` already carries the c_concat channels for hybrid conditioning (the sampler writes them once).
+        `x_noisy` already carries the c_concat channels for hybrid / concat conditioning (the sampler writes them once);
+        `cond` is the text context ('crossattn' / 'hybrid'), the class labels ('adm'), or ignored (None / 'concat').
         temb: the row of time_embedding_table() that belongs to `t` (optional)."""
+        key = self.model.conditioning_key
+        if key == "adm":
+            return self.unet.forward_nhwc(x_noisy, t, None, y=_first(cond))
+        if key is None or key == "concat":
+            return self.unet.forward_nhwc(x_noisy, t, None, temb=temb)
         return self.unet.forward_nhwc(x_noisy, t, cond, temb=temb)
 
     def time_embedding_table(self, t):

@@ -126,17 +126,43 @@ class _SamplerBase:
             raise ValueError("noise_dropout must be in [0, 1)")
         # hybrid (inpainting) conditioning: {"c_concat": mask + masked-image latent, "c_crossattn": text} (inpaint.py:84-88,
         # WK plms.py:188-205); the concat part is the same for the cond and uncond halves
-        c_cat = None
-        if isinstance(cond, dict) and "c_concat" in cond:
+        # The other DiffusionWrapper keys (WK ddpm.py:361-374) arrive the way plms.py:188-195 hands them over: a bare conditioning
+        # goes to the keyword the key reads -- 'concat': extra input channels (cond and uncond halves may differ), 'adm': class
+        # labels [B] (concatenated [uncond; cond] like a text context), None: no conditioning at all.
+        key = getattr(getattr(self.model, "model", None), "conditioning_key", "crossattn")
+        c_cat = uc_cat = None
+        if key == "concat":
+            c_cat = _first_tensor(cond["c_concat"] if isinstance(cond, dict) else cond)
+            if unconditional_conditioning is not None:
+                uc_cat = _first_tensor(unconditional_conditioning["c_concat"] if isinstance(unconditional_conditioning, dict)
+                                       else unconditional_conditioning)
+            cond = unconditional_conditioning = None
+        elif isinstance(cond, dict) and "c_concat" in cond:
             c_cat = _first_tensor(cond["c_concat"])
             cond = cond["c_crossattn"]
             if isinstance(unconditional_conditioning, dict):
                 unconditional_conditioning = unconditional_conditioning["c_crossattn"]
-        cond = _first_tensor(cond)
+        if key is None:
+            cond = unconditional_conditioning = None
+        cond = _first_tensor(cond) if cond is not None else None
         uc = _first_tensor(unconditional_conditioning) if unconditional_conditioning is not None else None
-        if not (isinstance(cond, torch.Tensor) and cond.is_cuda):
+        if key in ("crossattn", "hybrid") and not (isinstance(cond, torch.Tensor) and cond.is_cuda):
             raise MdxError("conditioning must be a CUDA(HIP) tensor [B, T, context_dim]")
-        dev = cond.device
+        if key == "adm" and cond is None:
+            raise MdxError("'adm' conditioning needs the class labels [B] as `conditioning`")
+        if key == "concat" and c_cat is None:
+            raise MdxError("'concat' conditioning needs the extra input channels [B, C', H, W] as `conditioning`")
+        if isinstance(cond, torch.Tensor) and cond.is_cuda:
+            dev = cond.device
+        elif isinstance(c_cat, torch.Tensor) and c_cat.is_cuda:
+            dev = c_cat.device
+        elif isinstance(x_T, torch.Tensor) and x_T.is_cuda:
+            dev = x_T.device
+        else:
+            dev = self.model.unet.device
+        if cond is not None:
+            cond = torch.as_tensor(cond).to(dev)
+            uc = None if uc is None else torch.as_tensor(uc).to(dev)
         b = shape[0]
         if x_T is None:
             img = torch.randn(shape, device=dev, dtype=torch.float32, generator=self.generator)
@@ -169,9 +195,12 @@ class _SamplerBase:
         if verbose:
             print(f"Running {type(self).__name__} Sampling with {total_steps} timesteps")
         scale = float(unconditional_guidance_scale)
-        use_cfg = not (uc is None or scale == 1.)
+        use_cfg = not ((uc is None and uc_cat is None) or scale == 1.)
         nb = 2 * b if use_cfg else b
-        c_in = torch.cat([uc.to(cond.dtype), cond], 0).contiguous() if use_cfg else cond.contiguous()   # built ONCE
+        if cond is None:
+            c_in = None
+        else:
+            c_in = torch.cat([uc.to(cond.dtype), cond], 0).contiguous() if use_cfg else cond.contiguous()   # built ONCE
         x_in = None                                                  # (plms.py:194 rebuilds the concat every step)
         cx = shape[1]
         if use_cfg or c_cat is not None:
@@ -179,9 +208,9 @@ class _SamplerBase:
             x_in = torch.empty((nb, cx + ccat) + tuple(shape[2:]), device=dev, dtype=torch.float32)
             if c_cat is not None:                                    # DiffusionWrapper 'hybrid': cat(x, c_concat), written once
                 cc = c_cat.to(device=dev, dtype=torch.float32)
-                x_in[:b, cx:] = cc
+                x_in[nb - b:, cx:] = cc                              # batch = [uncond ; cond]
                 if use_cfg:
-                    x_in[b:, cx:] = cc
+                    x_in[:b, cx:] = cc if uc_cat is None else uc_cat.to(device=dev, dtype=torch.float32)
         if mask is not None:
             mask = torch.as_tensor(mask).to(device=dev, dtype=torch.float32)
             x0 = torch.as_tensor(x0).to(device=dev, dtype=torch.float32)
@@ -190,7 +219,8 @@ class _SamplerBase:
         # the timestep-only part of the UNet (time_embed MLP + the ResBlock emb_layers, openaimodel.py:550-551,188) for
         # ALL steps in one batched pass; step i then hands row i to the UNet instead of recomputing it
         temb_all = None
-        if hasattr(self.model, "time_embedding_table") and os.environ.get("MDX_SAMPLER_TEMB_TABLE", "1") != "0":
+        if (hasattr(self.model, "time_embedding_table") and os.environ.get("MDX_SAMPLER_TEMB_TABLE", "1") != "0"
+                and getattr(getattr(self.model, "unet", None), "num_classes", None) is None):     # (label_emb(y) joins emb per call)
             temb_all = self.model.time_embedding_table(t_all)
         t_all = t_all[:, None].expand(total_steps, nb).contiguous()
 

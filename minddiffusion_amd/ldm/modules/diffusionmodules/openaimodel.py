@@ -404,8 +404,11 @@ class UNetModel:
     class _Plan:
         pass
 
-    def _plan(self, B, H, W, _fuse_head=True):
-        key = (B, H, W)
+    def _plan(self, B, H, W, _fuse_head=True, _selfctx=False):
+        # _selfctx: the `context=None` form of construct() (DiffusionWrapper keys None / 'concat' / 'adm', WK ddpm.py:361-374):
+        # attn2 attends to its own normalised input (attention.py:133 `context = default(context, x)`), so its to_k / to_v run per
+        # step on LayerNorm(tokens) instead of once on the text context; plans of the two forms are kept side by side
+        key = (B, H, W, "selfctx") if _selfctx else (B, H, W)
         if key in self._plans:
             return self._plans[key]
         if self.w is None:
@@ -555,7 +558,7 @@ class UNetModel:
             needs enough row blocks to fill the chip: 32-row blocks from 192 blocks up (UNet batch 2 at a 64 x 64 latent = 256),
             64-row blocks (half the weight traffic through L2) once those alone give >= 2 blocks per CU.
             ops.set_option("unet_st_tail", 0 | 32 | 64) forces a choice (0 = never)."""
-            if (t + "tail.stream") not in w or self.transformer_depth != 1:
+            if (t + "tail.stream") not in w or self.transformer_depth != 1 or _selfctx:
                 return 0
             if TC > 96 or TC % 8:       # mdx_st_tail_f16 holds the context keys in registers: capacity <= 96, multiple of 8
                 return 0                # (a UNet built with a longer max_context_len keeps the unfused launches, any length)
@@ -796,13 +799,28 @@ class UNetModel:
                     q2 = dense(main, ln, B, n, inner, inner, w[t + "attn2.q.w"])
                 else:
                     q2 = dense(main, tok2, B, n, inner, inner, w[t + "attn2.q.w"], **consumer(t + "attn2.q"))
-                kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
-                vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
-                ctx_kv[t] = (kc, vtc)
-                emit(lambda q2=q2, kc=kc, vtc=vtc, o=o: ops.attention(
-                    q2.data_ptr(), kc.data_ptr(), vtc.data_ptr(), o.data_ptr(), B, heads, dh, n, P.ctx_len, scale,
-                    n * inner, inner, TC * inner, inner, inner * TC, TC, n * inner, inner),
-                    "attention", 4 * B * heads * n * 77 * dh, 1, f"cross B={B} h={heads} N={n} d={dh}")
+                    if _selfctx:    # k / v below read LayerNorm(tok2) itself: one explicit launch (this form is not a hot path)
+                        emit(lambda ln=ln, tok2=tok2, t=t: ops.layernorm(tok2, w[t + "norm2.g"], w[t + "norm2.b"], 1e-5, out=ln),
+                             "layernorm")
+                if _selfctx:
+                    # context = default(context, x) (attention.py:133): keys / values are projections of attn2's own input
+                    k2 = dense(main, ln, B, n, inner, inner, w[t + "attn2.k.w"])
+                    v2t = A.get((B, inner, n))
+                    dense(main, ln, B, n, inner, inner, w[t + "attn2.v.w"], out=v2t, out_ld=n, out_mode=ops.OUT_TRANSPOSED)
+                    attn_ws_need[0] = max(attn_ws_need[0], ops.attention_ws_bytes(B, heads, dh, n, n))
+                    emit(lambda q2=q2, k2=k2, v2t=v2t, o=o: ops.attention(
+                        q2.data_ptr(), k2.data_ptr(), v2t.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
+                        n * inner, inner, n * inner, inner, inner * n, n, n * inner, inner, ws=P.attn_ws),
+                        "attention", 4 * B * heads * n * n * dh, 1, f"attn2-self B={B} h={heads} N={n} d={dh}")
+                    A.release(k2); A.release(v2t)
+                else:
+                    kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
+                    vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
+                    ctx_kv[t] = (kc, vtc)
+                    emit(lambda q2=q2, kc=kc, vtc=vtc, o=o: ops.attention(
+                        q2.data_ptr(), kc.data_ptr(), vtc.data_ptr(), o.data_ptr(), B, heads, dh, n, P.ctx_len, scale,
+                        n * inner, inner, TC * inner, inner, inner * TC, TC, n * inner, inner),
+                        "attention", 4 * B * heads * n * 77 * dh, 1, f"cross B={B} h={heads} N={n} d={dh}")
                 tok3 = dense(main, o, B, n, inner, inner, w[t + "attn2.o.w"], bias=w[t + "attn2.o.b"], residual=tok2,
                              stats_out=st)
                 A.release(q2); A.release(tok2)
@@ -973,7 +991,7 @@ class UNetModel:
         if any(not hd.colstats for hd in heads_fused) or any(not dd.gn_colstats for dd in gn_convs):
             # a fused head whose input tensor's producer cannot emit column statistics in its final launch form: plan again
             # with the unfused GroupNorm / proj_in / qkv launches (plans are built once per shape)
-            return self._plan(B, H, W, _fuse_head=False)
+            return self._plan(B, H, W, _fuse_head=False, _selfctx=_selfctx)
         # ---- first-use tuning (off by default): a resolution / batch the tile table was not measured at runs the cost model's
         # tiles, 10-20 % off on some shapes; with the option on, every such launch form is timed once per shape (ops.tune_cache)
         if ops.get_option("unet_tune_first_use"):
@@ -1051,7 +1069,7 @@ class UNetModel:
         e2 = ops.dense_small(e1, w["te2.w"], w["te2.b"])
         return ops.dense_small(e2, w["emb.w"], w["emb.b"], act_in=True)
 
-    def forward_nhwc(self, x, timesteps, context, temb=None, y=None):
+    def forward_nhwc(self, x, timesteps, context=None, temb=None, y=None):
         """Run the UNet; returns the plan's static NHWC fp16 eps buffer [B, H*W, 8] (first 4 channels valid).
         The buffer is overwritten by the next call.  temb: optional row(s) of time_embedding_table() for `timesteps`
         ([emb_total] or [B, emb_total]); the time-embedding launches are then skipped.  y: [B] class labels of a
@@ -1065,8 +1083,18 @@ class UNetModel:
         B, C, H, W = x.shape
         if C != self.in_channels:
             raise MdxError(f"UNetModel: expected {self.in_channels} input channels, got {C}")
-        P = self._plan(B, H, W)
-        self._ensure_context(P, context)
+        if context is None:
+            # construct(x, t) / construct(x, t, y=) of DiffusionWrapper keys None / 'concat' / 'adm' (WK ddpm.py:361-374): attn2's
+            # to_k / to_v (Dense(context_dim, inner)) then see the block's own tokens, which only type-checks -- in the reference
+            # as here -- when context_dim equals the transformer width at every attention level
+            bad = sorted({l[2] * l[3] for _, l in self._named_layers() if l[0] == "st" and l[2] * l[3] != self.context_dim})
+            if bad:
+                raise MdxError(f"UNetModel: context=None makes attn2 attend to its own input (attention.py:133), which needs "
+                               f"context_dim == transformer width; context_dim={self.context_dim}, widths {bad}")
+            P = self._plan(B, H, W, _selfctx=True)
+        else:
+            P = self._plan(B, H, W)
+            self._ensure_context(P, context)
         P.x_static.copy_(x)
         if temb is not None:
             if temb.shape[-1] != self._emb_total or temb.dtype != f32:

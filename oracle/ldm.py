@@ -351,12 +351,13 @@ class UNetOracle:
 
     # -- forward --------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, x, timesteps, context, y=None):
+    def forward(self, x, timesteps, context=None, y=None):
         p = self.p
         assert (y is not None) == (self.cfg.get("num_classes") is not None), \
             "must specify y if and only if the model is class-conditional"      # openaimodel.py:545-547
         x = r16(torch.as_tensor(x, dtype=torch.float32))              # apply_model casts x_noisy / cond (ddpm.py:291-292)
-        context = r16(torch.as_tensor(context, dtype=torch.float32))
+        if context is not None:   # None: attn2 attends to its own input (attention.py:133 `context = default(context, x)`)
+            context = r16(torch.as_tensor(context, dtype=torch.float32))
         timesteps = torch.as_tensor(timesteps)
         t_emb = timestep_embedding(timesteps, self.cfg["model_channels"])
         emb = dense(t_emb, p["time_embed.0.weight"], p["time_embed.0.bias"])
@@ -504,8 +505,10 @@ def init_params(cfg, seed=0, zero_init=False, dtype=np.float32):
 class ModelOracle:
     """The attributes/methods PLMSSampler needs from LatentDiffusion (plms.py:31,40-46; ddpm.py:290-306)."""
 
-    def __init__(self, unet, linear_start=0.00085, linear_end=0.0120, timesteps=1000):
+    def __init__(self, unet, linear_start=0.00085, linear_end=0.0120, timesteps=1000, conditioning_key="crossattn"):
         self.unet = unet
+        assert conditioning_key in [None, "concat", "crossattn", "hybrid", "adm"]     # WK ddpm.py:358
+        self.conditioning_key = conditioning_key
         s = register_schedule(linear_start, linear_end, timesteps)
         self.num_timesteps = s["num_timesteps"]
         self.betas = s["betas"]
@@ -516,14 +519,25 @@ class ModelOracle:
         self.parameterization = "eps"
         self.calls = 0
 
-    def apply_model(self, x, t, cond):
-        """ddpm.py:290-306; a dict is the hybrid (inpainting) conditioning of WK ddpm.py:368-371: the UNet input is
-        cat(x, c_concat) and the context is c_crossattn."""
+    def apply_model(self, x, t, cond=None):
+        """ddpm.py:290-306: a bare conditioning becomes {'c_concat': cond} for key 'concat' and {'c_crossattn': cond} otherwise
+        (:299-300), a dict (hybrid, inpaint.py:84-88) passes through; then DiffusionWrapper.construct, WK ddpm.py:360-377, by key:
+        None -> unet(x, t); 'concat' -> unet(cat(x, c_concat), t); 'crossattn' -> unet(x, t, context); 'hybrid' -> both;
+        'adm' -> unet(x, t, y=c_crossattn)."""
         self.calls += 1
-        if isinstance(cond, dict):
-            x = torch.cat([x, cond["c_concat"]], 1)
-            cond = cond["c_crossattn"]
-        return self.unet(x, t, cond)
+        key = self.conditioning_key
+        if not isinstance(cond, dict):
+            cond = {"c_concat" if key == "concat" else "c_crossattn": cond}
+        c_concat, c_crossattn = cond.get("c_concat"), cond.get("c_crossattn")
+        if key is None:
+            return self.unet(x, t)
+        if key == "concat":
+            return self.unet(torch.cat([x, torch.as_tensor(c_concat, dtype=torch.float32)], 1), t)
+        if key == "crossattn":
+            return self.unet(x, t, c_crossattn)
+        if key == "hybrid":
+            return self.unet(torch.cat([x, torch.as_tensor(c_concat, dtype=torch.float32)], 1), t, c_crossattn)
+        return self.unet(x, t, y=c_crossattn)      # 'adm'
 
     def q_sample(self, x0, t, noise):
         """ddpm.py:197-200."""
@@ -579,8 +593,12 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
         conditioning = conditioning["c_crossattn"]
         if isinstance(unconditional_conditioning, dict):
             unconditional_conditioning = unconditional_conditioning["c_crossattn"]
-    cond = torch.as_tensor(conditioning, dtype=torch.float32)
-    uc = None if unconditional_conditioning is None else torch.as_tensor(unconditional_conditioning, dtype=torch.float32)
+    def as_cond(c):     # text context / extra input channels: fp32; class labels ('adm'): integers stay integers
+        if c is None:
+            return None
+        c = torch.as_tensor(c)
+        return c.to(torch.float32) if c.is_floating_point() else c
+    cond, uc = as_cond(conditioning), as_cond(unconditional_conditioning)
     if mask is not None:
         mask = torch.as_tensor(mask, dtype=torch.float32)
         x0 = torch.as_tensor(x0, dtype=torch.float32)

@@ -5,6 +5,8 @@ over the full sampler length without spending oracle time on the GPU box (one or
     traj_config2_wukong_plms50.npz      Wukong UNet, 64x64, PLMS-50 (51 evaluations), CFG 7.5, image 0 of the batch of 8 (102 rows)
     traj_config3_sd2_768_ddim50.npz     SDv2 UNet, 96x96 latent, DDIM-50, CFG 7.5, image 0 of the 4 per GPU  (100 rows)
     traj_config4_glide_60_27.npz        Taichu-GLIDE base 60 guided ancestral steps (120 rows) + up-sampler 27 DDIM steps at 256x256
+    traj_inpaint_wukong_plms30.npz      Wukong inpainting UNet (9 input channels), 64x64, PLMS-30 (31 evaluations), CFG 7.5, hybrid
+                                        conditioning, image 0 of the CLI's batch of 4 (62 rows) + one apply_model row
     glide_threeway.json                 d(fp32 oracle, fp16-emulated oracle) on the full-size GLIDE 10-step / 3-step loops of
                                         tests/test_configs_gpu.py::test_config4_glide_full_size_loops (sets their bounds)
 
@@ -77,6 +79,20 @@ def inputs_config4(base_steps=60, up_steps=27):
                 unc=rng.randint(1, 50000, (base_steps, 128)).astype(np.int32),
                 noises=rng.randn(base_steps, P, 3, 64, 64).astype(np.float32),
                 up_x_T=(rng.randn(P, 3, 256, 256) * 0.997).astype(np.float32))
+
+
+def inputs_inpaint():
+    """= tests/test_configs_gpu.py::test_inpaint_wukong_full_size (Wukong 9-channel inpainting UNet seed 5, the CLI's batch of 4
+    images at its 30 PLMS steps and scale 7.5, wukong-huahua/inpaint.py:65-106 + its argparse defaults; the oracle follows image 0).
+    c_concat = cat(resized mask, masked-image latent) as inpaint.py:84-92 builds it."""
+    rng = np.random.RandomState(31)
+    x_T = rng.randn(4, 4, 64, 64).astype(np.float32)
+    c = rng.randn(4, 77, 768).astype(np.float32)
+    uc = np.repeat(rng.randn(1, 77, 768).astype(np.float32), 4, 0)
+    m = (rng.rand(4, 1, 64, 64) > 0.5).astype(np.float32)
+    masked_latent = rng.randn(4, 4, 64, 64).astype(np.float32)
+    return dict(seed=5, S=30, scale=7.5, sampler="plms", hw=64, ctx_dim=768, x_T=x_T, c=c, uc=uc,
+                c_cat=np.concatenate([m, masked_latent], 1))
 
 
 def inputs_glide_loops_test():
@@ -233,7 +249,33 @@ def case_short():
     print("wrote short_traj.npz", flush=True)
 
 
-CASES = dict(short=case_short, config1=case_config1, config2=case_config2, config3=case_config3, config4=case_config4,
+def case_inpaint():
+    """Full-size inpainting model (configs/wukong-huahua_inpaint_inference.yaml) at the CLI's length: one apply_model row at
+    t = 500 (fp32) and the PLMS-30 trajectory (31 evaluations, CFG 7.5, hybrid dict conditioning) of image 0."""
+    from oracle import ldm as O
+    inp = inputs_inpaint()
+    t0 = time.time()
+    ocfg = dict(O.WUKONG_UNET, in_channels=9)
+    model = O.ModelOracle(O.UNetOracle(ocfg, O.init_params(ocfg, seed=inp["seed"])), conditioning_key="hybrid")
+    one = model.apply_model(torch.tensor(inp["x_T"][:1]), torch.full((1,), 500.0),
+                            {"c_concat": torch.tensor(inp["c_cat"][:1]), "c_crossattn": torch.tensor(inp["c"][:1])})
+    out = dict(apply_model_t500=one.numpy().astype(np.float32))
+    print("inpaint apply_model row done", round(time.time() - t0, 1), "s", flush=True)
+    model.calls = 0
+    ref, inter = O.sample(model, inp["S"], 1, (4, 64, 64), {"c_concat": inp["c_cat"][:1], "c_crossattn": inp["c"][:1]},
+                          inp["x_T"][:1], "plms", unconditional_guidance_scale=inp["scale"],
+                          unconditional_conditioning={"c_concat": inp["c_cat"][:1], "c_crossattn": inp["uc"][:1]})
+    out["final"] = ref.numpy().astype(np.float16)
+    out["pred_x0"] = inter["pred_x0"][-1].numpy().astype(np.float16)
+    meta = dict(name="inpaint_wukong_plms30", oracle_cfg="WUKONG_UNET + in_channels=9", unet_seed=inp["seed"], S=inp["S"],
+                sampler="plms", scale=inp["scale"], latent=64, unet_calls=model.calls, commit=_commit(),
+                oracle_seconds=round(time.time() - t0, 1))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "traj_inpaint_wukong_plms30.npz"), **out)
+    print("wrote traj_inpaint_wukong_plms30.npz", meta, flush=True)
+
+
+CASES = dict(short=case_short, inpaint=case_inpaint, config1=case_config1, config2=case_config2, config3=case_config3, config4=case_config4,
              glide_threeway=case_glide_threeway)
 
 if __name__ == "__main__":

@@ -240,6 +240,41 @@ def test_config2_wukong_512_unet_batch16_and_plms():
     check("config2_wukong_512_plms5_B8_image0", got[:1], ref, rel_l2=1e-2, max_rel=2e-2)
 
 
+# --------------------------------------------------------------------------------------------- Wukong inpainting, full size
+def test_inpaint_wukong_full_size():
+    """SURVEY 8(f) item 4 at full size: configs/wukong-huahua_inpaint_inference.yaml (the Wukong UNet on 9 input channels,
+    LatentInpaintDiffusion / 'hybrid') driven as wukong-huahua/inpaint.py:65-106 drives it with its CLI defaults -- batch 4,
+    PLMS 30 steps (31 evaluations at UNet batch 8), scale 7.5, dict conditioning with the SAME c_concat on both CFG halves.
+    Oracle: committed fixture tests/golden/traj_inpaint_wukong_plms30.npz (one apply_model row + the trajectory of image 0)."""
+    import json as _json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_trajectory_goldens import inputs_inpaint
+    from minddiffusion_amd.configs import WUKONG_INPAINT_UNET
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentInpaintDiffusion
+    from minddiffusion_amd.ldm.models.diffusion.plms import PLMSSampler
+    z = np.load(os.path.join(ROOT, "tests", "golden", "traj_inpaint_wukong_plms30.npz"))
+    meta = _json.loads(str(z["meta"]))
+    inp = inputs_inpaint()
+    assert meta["S"] == inp["S"] and meta["unet_seed"] == inp["seed"] and meta["unet_calls"] == inp["S"] + 1
+    ocfg = dict(O.WUKONG_UNET, in_channels=9)
+    net, _ = _unet(WUKONG_INPAINT_UNET, ocfg, inp["seed"])
+    model = LatentInpaintDiffusion(unet_config=net, linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    dev = lambda a: torch.tensor(a, device=DEV)
+    B = 4
+    # one call through the reference's keyword surface (WK ddpm.py:276-278), all four images; row 0 against the oracle row
+    e = model.apply_model(dev(inp["x_T"]), torch.full((B,), 500.0, device=DEV), c_concat=[dev(inp["c_cat"])],
+                          c_crossattn=[dev(inp["c"])])
+    check("inpaint_wukong_full_apply_model_row0", e[:1], torch.tensor(z["apply_model_t500"]), rel_l2=5e-3, max_abs=5e-2)
+    got, _ = PLMSSampler(model).sample(inp["S"], B, (4, 64, 64),
+                                       conditioning={"c_concat": dev(inp["c_cat"]), "c_crossattn": dev(inp["c"])},
+                                       x_T=dev(inp["x_T"]), unconditional_guidance_scale=inp["scale"],
+                                       unconditional_conditioning={"c_concat": dev(inp["c_cat"]), "c_crossattn": dev(inp["uc"])},
+                                       x0=dev(inp["c_cat"][:, 1:]), verbose=False)     # inpaint.py:104 passes x0 and no mask
+    assert net._plans[(2 * B, 64, 64)].graph is not None, "the sampler replays a hipGraph of the 9-channel UNet at batch 8"
+    check("inpaint_wukong_full_plms30_B4_image0", got[:1], torch.tensor(z["final"].astype(np.float32)), rel_l2=1e-2, max_rel=2e-2)
+
+
 # --------------------------------------------------------------------------------------------- config 3: SDv2 768, 4 images / GPU
 def test_config3_sd2_768_unet_batch8_latent96():
     """BASELINE configs[3] per-GPU share: SDv2 UNet on a 96x96 latent at UNet batch 8 (4 images x CFG): M = 73 728-row

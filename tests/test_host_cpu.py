@@ -186,6 +186,36 @@ def test_no_cpu_fallback():
         net(torch.zeros(1, 4, 8, 8), torch.zeros(1), torch.zeros(1, 5, 64))
 
 
+def test_diffusion_wrapper_routes_every_conditioning_key():
+    """DiffusionWrapper.construct, WK ddpm.py:360-377, and the bare-conditioning rule of apply_model (ddpm.py:299-300): which
+    keyword reaches the UNet for each of the five keys (host logic only: the UNet is a recorder)."""
+    from minddiffusion_amd._lib import MdxError
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import DiffusionWrapper, LatentDiffusion
+
+    class Rec:
+        def __call__(self, x, t, context=None, y=None):
+            self.seen = dict(x=x, context=context, y=y)
+            return x
+    x, t = torch.zeros(2, 4, 8, 8), torch.zeros(2)
+    cc, ctx, lab = torch.ones(2, 3, 8, 8), torch.ones(2, 5, 16), torch.tensor([1, 2])
+    for key, cond, want_c, want_ctx, want_y in ((None, None, 4, None, None), ("concat", cc, 7, None, None),
+                                                 ("crossattn", ctx, 4, ctx, None), ("adm", lab, 4, None, lab),
+                                                 ("hybrid", {"c_concat": [cc], "c_crossattn": [ctx]}, 7, ctx, None)):
+        rec = Rec()
+        m = LatentDiffusion(unet_config=rec, conditioning_key=key)
+        m.apply_model(x, t, cond)
+        assert rec.seen["x"].shape[1] == want_c, key
+        assert rec.seen["context"] is want_ctx and rec.seen["y"] is want_y, key
+    with pytest.raises(AssertionError):
+        DiffusionWrapper(Rec(), "text")
+    with pytest.raises(MdxError):
+        LatentDiffusion(unet_config=Rec(), conditioning_key="concat").apply_model(x, t, None)
+    with pytest.raises(MdxError):
+        LatentDiffusion(unet_config=Rec(), conditioning_key="adm").apply_model(x, t, None)
+    with pytest.raises(MdxError):
+        LatentDiffusion(unet_config=Rec(), conditioning_key="crossattn").apply_model(x, t, {"c_concat": cc, "c_crossattn": ctx})
+
+
 def test_instantiate_from_config_reference_targets():
     from minddiffusion_amd.ldm.util import instantiate_from_config
     from minddiffusion_amd.configs import TINY_UNET

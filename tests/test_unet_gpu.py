@@ -238,6 +238,52 @@ def test_tiny_inpaint_hybrid_trajectory(blend):
     check("tiny_inpaint_apply_model", e, eo, rel_l2=5e-3, max_abs=5e-2)
 
 
+def _selfctx_cfg(**kw):
+    """A UNet the reference's `context=None` call type-checks on: attention only where the transformer width equals context_dim
+    (WK attention.py:133 `context = default(context, x)` feeds the block's own tokens to to_k / to_v = Dense(context_dim, inner))."""
+    return dict(image_size=8, in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[2], num_res_blocks=1,
+                channel_mult=[1, 2], num_head_channels=64, use_spatial_transformer=True, use_linear_in_transformer=True,
+                transformer_depth=1, context_dim=128, legacy=False, **kw)
+
+
+@pytest.mark.parametrize("key", [None, "concat", "adm"])
+def test_diffusion_wrapper_keys_without_context(key):
+    """DiffusionWrapper conditioning keys None / 'concat' / 'adm' (WK ddpm.py:360-377): one apply_model call and a PLMS-5
+    trajectory with classifier-free guidance where the key has something to guide, against the oracle's restatement."""
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from minddiffusion_amd.ldm.models.diffusion.plms import PLMSSampler
+    from minddiffusion_amd._lib import MdxError
+    cfg = _selfctx_cfg(**({"in_channels": 7} if key == "concat" else {}), **({"num_classes": 10} if key == "adm" else {}))
+    params = O.init_params(_oracle_cfg(cfg), seed=21)
+    net = _build(cfg, params, True)
+    model = LatentDiffusion(unet_config=net, linear_start=0.00085, linear_end=0.0120, timesteps=1000, conditioning_key=key)
+    omodel = O.ModelOracle(O.UNetOracle(_oracle_cfg(cfg), params), conditioning_key=key)
+    B, H, W, S = 2, 8, 8, 5
+    rng = np.random.RandomState(22)
+    x_T = rng.randn(B, 4, H, W).astype(np.float32)
+    dev = lambda a: torch.tensor(a, device=DEV)
+    if key == "concat":
+        c, uc, scale = rng.randn(B, 3, H, W).astype(np.float32), np.zeros((B, 3, H, W), np.float32), 3.0
+    elif key == "adm":
+        c, uc, scale = np.array([3, 7]), np.array([0, 0]), 3.0
+    else:
+        c, uc, scale = None, None, 1.0
+    t = np.full((B,), 500.0, np.float32)
+    e = model.apply_model(dev(x_T), dev(t), None if c is None else dev(c))
+    eo = omodel.apply_model(torch.tensor(x_T), torch.tensor(t), None if c is None else torch.as_tensor(c))
+    check(f"wrapper_key_{key}_apply_model", e, eo, rel_l2=5e-3, max_abs=5e-2)
+    ref, _ = O.sample(omodel, S, B, (4, H, W), c, x_T, "plms", unconditional_guidance_scale=scale, unconditional_conditioning=uc)
+    got, _ = PLMSSampler(model).sample(S, B, (4, H, W), conditioning=None if c is None else dev(c), x_T=dev(x_T),
+                                       unconditional_guidance_scale=scale,
+                                       unconditional_conditioning=None if uc is None else dev(uc), verbose=False)
+    check(f"wrapper_key_{key}_plms{S}", got, ref, rel_l2=1e-2, max_rel=1e-2)
+    # a UNet whose transformer widths differ from context_dim cannot run without a context -- in the reference the Dense
+    # shapes do not match; here the call is refused before anything is launched
+    bad = _build(_tiny_cfg(), O.init_params(_oracle_cfg(_tiny_cfg()), seed=0), False)
+    with pytest.raises(MdxError, match="context_dim"):
+        bad(dev(x_T), dev(t))
+
+
 def test_ddim_eta_runs_and_plms_rejects_eta():
     from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
     from minddiffusion_amd.ldm.models.diffusion.plms import PLMSSampler
