@@ -428,6 +428,7 @@ def run_config(config, args, rank, world, device, steps, warmup, cpu):
         out = one_step()
     barrier()
     D.reset_collective_stats()
+    D.time_collectives = True       # (opt-in: the library does not time or synchronise its broadcast on its own)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = one_step()

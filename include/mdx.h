@@ -200,8 +200,8 @@ typedef struct mdx_gemm_desc {
                              resolve to the HALO kernel only; set tile_m = 128.  Results are bit-identical to the tile-major form. */
     int stages;           /* 0 = auto; 2 .. 6 forces the depth of the LDS ring the K tiles are DMA'd through (same purpose; 64-row
                              tiles up to 6, 128-row tiles up to 5, HALO weight ring 2 | 3); 10 | 11 = depth 2 | 3 with EIGHT
-                             waves per block (generic kernel, tile_m = 128 only); 8 | 9 with tile_m = 256 = the eight-wave cores
-                             (conv8p.hip / gemm8p.hip; 9: one phase per 32-deep k-step) */
+                             waves per block (generic kernel, tile_m = 128 only); 8 | 9 with tile_m = 256 = the eight-wave 3x3 conv
+                             core (conv8p.hip; 9: one phase per 32-deep k-step) */
     const void* w_sub;    /* upsample = 1 only, optional: the SUB-PIXEL weights of the nearest-2x + 3x3 conv (openaimodel.py:57-60).
                              For output parity (dy, dx) the conv is a 2 x 2 conv of the low-resolution source with pre-summed taps --
                              rows {y-1+dy, y+dy}: dy = 0 -> {w[0], w[1]+w[2]}, dy = 1 -> {w[0]+w[1], w[2]}; columns likewise -- packed like

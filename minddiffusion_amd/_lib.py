@@ -142,10 +142,9 @@ _ENV_OPTIONS = {
     "MDX_GEMM_SPREAD": ("gemm_spread", int), "MDX_HALO_NSB": ("halo_nsb", int), "MDX_GN_MIN_BLOCKS": ("gn_min_blocks", int),
     "MDX_GN_FUSED": ("gn_fused", int), "MDX_GN_COL_CHUNKS": ("gn_col_chunks", int),
     "MDX_GEMM_CONV8P": ("gemm_conv8p", int), "MDX_GEMM_CONV8P_MIN_M": ("gemm_conv8p_min_m", int),
-    "MDX_GEMM_DENSE8P": ("gemm_dense8p", int), "MDX_GEMM_DENSE8P_MIN_M": ("gemm_dense8p_min_m", int),
     "MDX_GEMM_SUBPIXEL_MIN_TILES": ("gemm_subpixel_min_tiles", int), "MDX_GEMM_CONV8P_VAR": ("gemm_conv8p_var", int),
     "MDX_ATTN8": ("attn8", int), "MDX_ATTN8_MIN_BLOCKS": ("attn8_min_blocks", int),
-    "MDX_GN_WIDE_ROWS": ("gn_wide_rows", int), "MDX_GN_BOOST_MB": ("gn_boost_mb", int), "MDX_GEMM_DENSE8Q": ("gemm_dense8q", int), "MDX_GEMM_DENSE8Q_VAR": ("gemm_dense8q_var", int), "MDX_ATTN_OCC3": ("attn_occ3", int), "MDX_ATTN_KV_SPLIT": ("attn_kv_split", int),
+    "MDX_GN_WIDE_ROWS": ("gn_wide_rows", int), "MDX_GN_BOOST_MB": ("gn_boost_mb", int), "MDX_ATTN_OCC3": ("attn_occ3", int), "MDX_ATTN_KV_SPLIT": ("attn_kv_split", int),
 }
 
 

@@ -645,8 +645,19 @@ void launch_attn(const AttnParams& p, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((attn_kernel<D, OCC>), grid, dim3(256), lds, st, p);
 }
 
-constexpr int ATTN_CUS = 256;            // MI355X
 constexpr int ATTN_MAX_SPLITS = ATTN_MAX_SPLITS_K;
+
+// CUs of the current device (256 on MI355X; read once per device so that the fill policy below follows the part it runs on)
+int attn_cus() {
+    static int cus[64] = {};
+    int dv = 0;
+    if (hipGetDevice(&dv) != hipSuccess || dv < 0 || dv >= 64) return 256;
+    if (!cus[dv]) {
+        int n = 0;
+        cus[dv] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dv) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dv];
+}
 
 // blocks the register file admits per CU for head dim D (see attn_kernel's OCC)
 int attn_blocks_per_cu(int D) { return D <= 64 ? (mdx_opt(MDX_OPT_ATTN_OCC3) ? 3 : 2) : (D <= 80 ? 2 : 1); }
@@ -666,7 +677,7 @@ int attn_auto_splits(int B, int heads, int D, int Nq, int Nk) {
     if (mode == 0 || cap < 2) return 1;
     if (mode >= 2) return mode < cap ? mode : cap;
     const long items = (long)((Nq + BQ - 1) / BQ) * heads * B;
-    const long slots = (long)ATTN_CUS * attn_blocks_per_cu(D);
+    const long slots = (long)attn_cus() * attn_blocks_per_cu(D);
     long s = slots / items;
     if (s > cap) s = cap;
     return s < 2 ? 1 : (int)s;
@@ -713,8 +724,19 @@ static int attention_impl(const void* q, long q_bs, int q_ld, const void* k, lon
             MDX_REQUIRE(S <= ATTN_MAX_SPLITS && 2 * S <= ntiles, "mdx_attention_splitkv_f16: %d splits of %d key tiles (at most %d, two tiles each)",
                         S, ntiles, ATTN_MAX_SPLITS);
         }
+        const long items = (long)qblocks * heads * B;
+        if (kv_splits <= 0 && S > 1) {
+            // auto mode: the split is a fill policy, not a request -- it depends on options (attn_occ3, attn_kv_split) that may have
+            // changed since the caller sized its workspace with mdx_attention_ws_bytes, so take what the workspace and the ticket
+            // region allow and fall back to the unsplit launch (always correct) instead of failing every evaluation
+            if (items > ATTN_TICKET_ITEMS || ws_bytes < ATTN_TICKET_BYTES) {
+                S = 1;
+            } else {
+                const size_t fit = (ws_bytes - ATTN_TICKET_BYTES) / ((size_t)items * attn_part_bytes(D));
+                if ((size_t)S > fit) S = fit < 2 ? 1 : (int)fit;
+            }
+        }
         if (S > 1) {
-            const long items = (long)qblocks * heads * B;
             MDX_REQUIRE(items <= ATTN_TICKET_ITEMS, "mdx_attention_splitkv_f16: %ld (batch, head, query block) items, at most %ld can be split", items, ATTN_TICKET_ITEMS);
             const size_t tb = ATTN_TICKET_BYTES, need = tb + (size_t)items * S * attn_part_bytes(D);
             MDX_REQUIRE(ws_bytes >= need, "mdx_attention_splitkv_f16: workspace of %zu bytes, %zu needed (mdx_attention_ws_bytes)", ws_bytes, need);

@@ -1366,7 +1366,6 @@ extern "C" int mdx_probe_gemm_trace(void* buf, size_t bytes) {
 // batch 2, profiles/r02_l_splitk_fixup.txt: 4 splits -1.7 us, 3 splits -1.4 us, 5 splits 0 ... +1.7 us, 10 splits +7 us,
 // 20 splits +8 us per launch); deeper splits, transposed outputs and deferred reduces keep the [split][M][N] slabs + reduce kernel.
 static bool conv8p_wanted(const mdx_gemm_desc* d, const GemmParams& p);
-static bool gemm8p_wanted(const mdx_gemm_desc* d, const GemmParams& p);
 
 static bool fixup_eligible(const mdx_gemm_desc* d, const GemmParams& p, int bm, int bn, int ns) {
     const int max_ns = mdx_opt(MDX_OPT_GEMM_SPLITK_FIXUP_MAX);
@@ -1390,7 +1389,6 @@ extern "C" size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d) {
     GemmParams p{};
     if (fill_params(d, p) != MDX_OK) return 0;
     if (conv8p_wanted(d, p)) return mdx_conv8p_plan(p, mdx_conv8p_pick_bn(p, d->tile_n), 0, false, true);
-    if (gemm8p_wanted(d, p)) return 0;
     const GemmCfg c = pick_cfg(p);
     const Tiling tl = choose_tiling(p, c.bn, d->splitk, d->tile_m);
     if (tl.ns <= 1) return 0;
@@ -1418,8 +1416,6 @@ struct Resolved {
     bool halo, tuned;
     bool fixup;      // split-K reduced by the last block of each tile (no reduce launch)
     bool c8;         // the 256-pixel eight-wave conv core (conv8p.hip); implies halo, tile_m 256, no split
-    bool g8;         // the 256 x 128 eight-wave dense core (gemm8p.hip); tile_m 256, tile_n 128, no split
-    bool g8q;        // ... its 256 x 256 form (gemm8q_kernel); tile_n 256
 };
 
 // Arrival counters of the in-kernel split-K reduce.  They used to sit in the first MDX_GEMM_WS_HEAD bytes of the caller's
@@ -1553,64 +1549,8 @@ static bool conv8p_wanted(const mdx_gemm_desc* d, const GemmParams& p) {
     return p.M >= mdx_opt(MDX_OPT_GEMM_CONV8P_MIN_M) && mdx_conv8p_tiles(p) >= 128;
 }
 
-// The eight-wave 256 x 128 dense core: forced by tile_m = 256 with stages = 8, or automatic for M >= gemm_dense8p_min_m with at
-// least 128 tiles (the token GEMMs of the 32 x 32 / 16 x 16 levels at UNet batch >= 8).
-static bool gemm8p_wanted(const mdx_gemm_desc* d, const GemmParams& p) {
-    if (d->w_frag || d->defer_reduce || d->splitk > 1) return false;
-    if (mdx_opt(MDX_OPT_GEMM_BM) || mdx_opt(MDX_OPT_GEMM_BN)) return false;
-    if (!mdx_gemm8p_eligible(p)) return false;
-    if (d->tile_m == 256 && d->stages == 8 && d->tile_n != 256) return true;       // forced: independent of the option (tile_n 256: gemm8q)
-    const int mode = mdx_opt(MDX_OPT_GEMM_DENSE8P);
-    if (!mode) return false;
-    if (d->tile_m != 0 || d->stages != 0 || (d->tile_n != 0 && d->tile_n != 128)) return false;
-    // mode 2: only the long-K launches with the plain epilogue -- the feed-forward's second GEMM (K = 4 C) -- where the K loop,
-    // not the epilogue, is the launch: 84 -> 80 us and 83 -> 69 us on Wukong's two levels alone (profiles/r04_gemm8q_bench.txt); the
-    // GEGLU / q|k|v / LayerNorm-fold consumers lose with one block per CU inside an evaluation and keep the four-wave tiles
-    if (mode == 2 && (p.K < 2048 || p.epilogue != MDX_EPI_NONE || p.ln_stats || p.n_split)) return false;
-    return p.M >= mdx_opt(MDX_OPT_GEMM_DENSE8P_MIN_M) && mdx_gemm8p_tiles(p) >= 128;
-}
-
-// The 256 x 256 form of the eight-wave dense core (gemm8q_kernel): forced by tile_m = 256, tile_n = 256, stages = 8; automatic
-// (option gemm_dense8q) for M >= gemm_dense8p_min_m when the 256 x 256 tiling fits the shape: at most 1/8 of the N extent of the
-// tiles is padding, at least 192 tiles, and the last round of 256 CUs at least 3/4 full (the GEGLU ff1 and q|k|v GEMMs of the
-// 32 x 32 / 16 x 16 levels at UNet batch >= 8; N = 640 / 1280 outputs keep the four-wave tiles).
-static bool gemm8q_wanted(const mdx_gemm_desc* d, const GemmParams& p) {
-    if (d->w_frag || d->defer_reduce || d->splitk > 1) return false;
-    if (mdx_opt(MDX_OPT_GEMM_BM) || mdx_opt(MDX_OPT_GEMM_BN)) return false;
-    if (!mdx_gemm8q_eligible(p)) return false;
-    if (d->tile_m == 256 && d->tile_n == 256 && d->stages == 8) return true;
-    if (!mdx_opt(MDX_OPT_GEMM_DENSE8Q)) return false;
-    if (d->tile_m != 0 || d->stages != 0 || d->tile_n != 0) return false;
-    if (p.M < mdx_opt(MDX_OPT_GEMM_DENSE8P_MIN_M)) return false;
-    const int tn = (p.N + 255) / 256, tiles = mdx_gemm8q_tiles(p);
-    if (tn * 256 * 8 > p.N * 9) return false;
-    const int rem = tiles % 256;
-    return tiles >= 192 && (rem == 0 || rem >= 192 || tiles >= 1024);
-}
-
 static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
     r.c8 = false;
-    r.g8 = false;
-    r.g8q = false;
-    const bool want_q = gemm8q_wanted(d, p);
-    if (want_q || gemm8p_wanted(d, p)) {
-        r.c = GemmCfg{256, want_q ? 256 : 128, 64, 3};
-        r.bn = want_q ? 256 : 128;
-        r.ns = 1;
-        r.stages = 8;
-        r.halo = false;
-        r.tuned = false;
-        r.fixup = false;
-        r.g8 = !want_q;
-        r.g8q = want_q;
-        p.bk = 64;
-        p.ktiles = (p.K + 63) / 64;
-        p.nsplit = 1;
-        p.ktiles_per_split = p.ktiles;
-        p.skip_kt_per_split = 0;
-        p.tickets = nullptr;
-        return MDX_OK;
-    }
     if (conv8p_wanted(d, p)) {
         r.c = GemmCfg{256, mdx_conv8p_pick_bn(p, d->tile_n), 64, 3};
         r.bn = r.c.bn;
@@ -1758,18 +1698,6 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         MDX_REQUIRE((p.M + rows - 1) / rows <= d->colstats_cap,
                     "mdx_gemm_f16: colstats_out holds %d row blocks, this launch writes %d (%d rows each)", d->colstats_cap,
                     (p.M + rows - 1) / rows, rows);
-    }
-    if (rs.g8q) {
-        rc = mdx_gemm8q_launch(p, st);
-        if (rc != MDX_OK) return rc;
-        MDX_LAUNCH_CHECK("mdx_gemm_f16(gemm8q)");
-        return MDX_OK;
-    }
-    if (rs.g8) {
-        rc = mdx_gemm8p_launch(p, st);
-        if (rc != MDX_OK) return rc;
-        MDX_LAUNCH_CHECK("mdx_gemm_f16(gemm8p)");
-        return MDX_OK;
     }
     if (rs.c8) {
         if (p.c8_split > 1) {       // tail tiles split along K: partials in the workspace, library-owned arrival counters

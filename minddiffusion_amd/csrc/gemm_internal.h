@@ -74,15 +74,6 @@ int mdx_conv8p_tiles(const GemmParams& p);
 size_t mdx_conv8p_plan(GemmParams& p, int bn, size_t workspace_bytes, bool have_workspace, bool query_only);
 int mdx_conv8p_launch(const GemmParams& p, int bn, hipStream_t st);
 
-// 8-wave 256 x 128 dense core (gemm8p.hip)
-bool mdx_gemm8p_eligible(const GemmParams& p);
-int mdx_gemm8p_tiles(const GemmParams& p);
-int mdx_gemm8p_launch(GemmParams& p, hipStream_t st);
-// ... and its 256 x 256 form (gemm8q_kernel)
-bool mdx_gemm8q_eligible(const GemmParams& p);
-int mdx_gemm8q_tiles(const GemmParams& p);
-int mdx_gemm8q_launch(GemmParams& p, hipStream_t st);
-
 namespace {
 
 
@@ -498,41 +489,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         for (int e = 0; e < 8; ++e)
                             f[e] = ((float)va[e] + ba[e]) * gelu_tanh_f((float)vg[e] + bg[e]);
                         epilogue_store_row8(p, f, m, on);
-                    }
-                }
-            } else if constexpr (BN == 256) {
-                // two 128-column groups, each 64 'a' columns | 64 'gate' columns -> 64 outputs at column (n0 + 128 grp) / 2
-                const int chunk = tid & 7, r0 = tid >> 3;
-#pragma unroll
-                for (int grp = 0; grp < 2; ++grp) {
-                    const int pn = n0 + grp * 128 + chunk * 8;
-                    const int on = ((n0 + grp * 128) >> 1) + chunk * 8;
-                    float ba[8], bg[8];
-                    if (grp == 0 || !p.bias || pn >= p.N) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            ba[e] = grp == 0 ? bpre[e] : 0.f;
-                            bg[e] = grp == 0 ? bpre[8 + e] : 0.f;
-                        }
-                    } else {
-                        const float4* b4 = reinterpret_cast<const float4*>(p.bias + pn);
-                        const float4 x0 = b4[0], x1 = b4[1], g0 = b4[16], g1 = b4[17];
-                        ba[0] = x0.x; ba[1] = x0.y; ba[2] = x0.z; ba[3] = x0.w; ba[4] = x1.x; ba[5] = x1.y; ba[6] = x1.z; ba[7] = x1.w;
-                        bg[0] = g0.x; bg[1] = g0.y; bg[2] = g0.z; bg[3] = g0.w; bg[4] = g1.x; bg[5] = g1.y; bg[6] = g1.z; bg[7] = g1.w;
-                    }
-#pragma unroll
-                    for (int pass = 0; pass < BM / (NT / 8); ++pass) {
-                        const int row = r0 + pass * (NT / 8);
-                        const int m = rm(row);
-                        if (m < p.M && pn < p.N) {
-                            const f16x8 va = *reinterpret_cast<const f16x8*>(&stg[row * SLD + grp * 128 + chunk * 8]);
-                            const f16x8 vg = *reinterpret_cast<const f16x8*>(&stg[row * SLD + grp * 128 + 64 + chunk * 8]);
-                            float f[8];
-#pragma unroll
-                            for (int e = 0; e < 8; ++e)
-                                f[e] = ((float)va[e] + ba[e]) * gelu_tanh_f((float)vg[e] + bg[e]);
-                            epilogue_store_row8(p, f, m, on);
-                        }
                     }
                 }
             }

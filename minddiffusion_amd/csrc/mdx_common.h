@@ -66,8 +66,6 @@ enum MdxOpt {
     MDX_OPT_GN_COL_CHUNKS,       // column-statistics GroupNorm: a column block spans at least this many 16-byte chunks of a pixel row (4)
     MDX_OPT_GEMM_CONV8P,         // 1: eligible 3x3 convs with M >= gemm_conv8p_min_m run on the 256-pixel 8-wave core (conv8p.hip)
     MDX_OPT_GEMM_CONV8P_MIN_M,   // smallest M the 8-wave conv core is chosen for automatically (4096; it also needs >= 128 tiles)
-    MDX_OPT_GEMM_DENSE8P,        // 0 (default): never; 1: all eligible dense launches (measured equal-or-slower inside a UNet evaluation, tools/eval_ab.py); 2: only long-K (K >= 2048) launches with the plain epilogue -- the feed-forward's second GEMM (-0.3 % on Wukong, -0.07 % on 768^2: within noise, and it would bypass the tuned rows of those shapes) with M >= gemm_dense8p_min_m and >= 128 tiles run on the 256 x 128 8-wave core (gemm8p.hip)
-    MDX_OPT_GEMM_DENSE8P_MIN_M,  // (4096)
     MDX_OPT_GEMM_SUBPIXEL_MIN_TILES,   // nearest-2x + 3x3 convs with w_sub run the sub-pixel form from this many 256-pixel tiles (32)
     MDX_OPT_GEMM_CONV8P_VAR,     // experiment forms of the 160-column conv8p kernel (conv8p.hip VAR; 0 = the product)
     MDX_OPT_ATTN8,               // (default 0: measured slower, csrc/attention.hip) 1: self-attention launches with >= attn8_min_blocks 256-query blocks use the eight-wave kernel; 2: always when eligible
@@ -75,8 +73,6 @@ enum MdxOpt {
     MDX_OPT_GN_WIDE_ROWS,        // column-statistics GroupNorm on tensors of at least this many pixel rows (B * H * W) uses the widest line-aligned column blocks (default 0 = never: only pays with pre-folded statistics, profiles/r04_gn_bench.txt)
     MDX_OPT_GN_FUSED_SMALL,      // (default 0: -0.2 % / -0.15 % / 0 on Wukong / 768^2 / GLIDE, within noise) 1: the one-launch GroupNorm runs 256-thread blocks when its (column block, sample) grid has >= 512 blocks
     MDX_OPT_GN_BOOST_MB,         // column-statistics GroupNorm on tensors of at least this many MB launches four times the pixel slabs (40; 0 = never)
-    MDX_OPT_GEMM_DENSE8Q,        // (default 0: faster alone, +0.2 ... +1.7 % SLOWER inside an evaluation, csrc/gemm8p.hip) 1: dense launches whose shape fits 256 x 256 tiles (M >= gemm_dense8p_min_m, >= 192 tiles, N padding <= 1/8) run on the 256 x 256 eight-wave core (gemm8p.hip, gemm8q_kernel)
-    MDX_OPT_GEMM_DENSE8Q_VAR,    // forms of gemm8q_kernel: 0 = DMA issue in the MFMA burst, 32 = in the read burst (+10 % at long K); 1-7 (+32) are timing ablations with WRONG results
     MDX_OPT_ATTN_OCC3,           // 1: the D <= 64 attention kernels are built for three blocks per CU (<= 168 VGPRs) instead of two
     MDX_OPT_ATTN_KV_SPLIT,       // split-KV attention (mdx_attention_splitkv_f16 with a workspace): 0 never, 1 auto (fill the chip's block slots), >= 2 force that many splits
     MDX_OPT_COUNT

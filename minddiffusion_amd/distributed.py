@@ -59,6 +59,9 @@ def shard_bounds(global_batch, rank, world_size):
 # how many bytes over how many ranks.  calls / bytes / ms of the broadcasts since the last reset; ms is
 # bracketed by HIP events on the current stream for device payloads, by the host clock for host payloads.
 collective_stats = {"broadcasts": 0, "bytes": 0, "ms": 0.0, "last_ms": 0.0}
+# Timing is OPT-IN (bench.py sets it): bracketing a device broadcast with HIP events and waiting on the second one makes the
+# otherwise asynchronous RCCL broadcast a blocking call.  The call and byte counters are always kept.
+time_collectives = False
 
 
 def reset_collective_stats():
@@ -70,7 +73,8 @@ def _broadcast(payload, src):
     single-GPU parity test) stages a device payload through the host."""
     import time
     on_dev = payload.is_cuda
-    if on_dev:
+    timed = time_collectives
+    if timed and on_dev:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     t0 = time.perf_counter()
@@ -80,11 +84,12 @@ def _broadcast(payload, src):
         payload.copy_(host)
     else:
         dist.broadcast(payload, src=src)
-    if on_dev:
+    ms = 0.0
+    if timed and on_dev:
         e1.record()
-        e1.synchronize()       # the receivers read the header right after this call anyway
+        e1.synchronize()
         ms = e0.elapsed_time(e1)
-    else:
+    elif timed:
         ms = (time.perf_counter() - t0) * 1e3
     collective_stats["broadcasts"] += 1
     collective_stats["bytes"] += payload.numel() * payload.element_size()

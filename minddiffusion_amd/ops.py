@@ -448,7 +448,8 @@ def gemm_shape_key(d):
     """What a launch form depends on: problem shape + launch variant (the tile table's key, gemm.hip tuned_variant())."""
     var = ((1 if d.c2 > 0 else 0) | (d.epilogue << 1) | (8 if d.n_split else 0) | (16 if d.ln_stats else 0)
            | (32 if d.stats_out else 0) | (64 if d.out_mode == 1 else 0) | (128 if d.colstats_out else 0)
-           | (256 if d.residual else 0) | (512 if d.rowbias else 0) | (1024 if d.skip_w else 0) | (2048 if d.gn_gamma else 0))
+           | (256 if d.residual else 0) | (512 if d.rowbias else 0) | (1024 if d.skip_w else 0) | (2048 if d.gn_gamma else 0)
+           | (4096 if d.w_sub else 0))      # (w_sub: the sub-pixel form of an Upsample conv resolves to another kernel)
     # B, H, W are part of the key: HALO eligibility, patch geometry (16-wide patches vs the 8 x 8 two-sample form) and the
     # eight-wave cores' tile counts depend on them, not only on M = B H W
     return (d.B * d.H * d.W, d.N, d.ksize * d.ksize * (d.c1 + d.c2), d.ksize, d.stride, d.upsample, var, d.B, d.H, d.W)
@@ -496,17 +497,34 @@ def release_tune_scratch():
     _tune_flush.clear()
 
 
+TUNE_CACHE_VERSION = 2      # bump when gemm_shape_key changes: entries keyed the old way can never match and are dropped on load
+
+
 def save_tune_cache(path):
     import json
     with open(path, "w") as f:
-        json.dump([[list(k), list(v)] for k, v in sorted(tune_cache.items())], f)
+        json.dump({"version": TUNE_CACHE_VERSION, "key_fields": 10,
+                   "entries": [[list(k), list(v)] for k, v in sorted(tune_cache.items())]}, f)
 
 
 def load_tune_cache(path):
+    """Returns the number of entries taken.  A file written under another key layout (no / other version, other key length) is
+    ignored with a message: its keys would never match and every shape would silently be measured again."""
     import json
+    import warnings
     with open(path) as f:
-        for k, v in json.load(f):
-            tune_cache[tuple(k)] = tuple(v)
+        data = json.load(f)
+    if not isinstance(data, dict) or data.get("version") != TUNE_CACHE_VERSION:
+        warnings.warn(f"load_tune_cache: {path} was written under another key layout (version "
+                      f"{data.get('version') if isinstance(data, dict) else 'none'}, this build: {TUNE_CACHE_VERSION}); ignored")
+        return 0
+    n = 0
+    for k, v in data["entries"]:
+        if len(k) != 10:
+            continue
+        tune_cache[tuple(k)] = tuple(v)
+        n += 1
+    return n
 
 
 def gemm_run(desc):

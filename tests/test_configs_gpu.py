@@ -405,7 +405,10 @@ def test_config4_glide_full_size_loops():
     import json as _json
     tw = _json.load(open(os.path.join(ROOT, "tests", "golden", "glide_threeway.json")))
     print("PARITY", _json.dumps(dict(name="config4_glide_full_loops_fp16emu_reference", **tw)))
-    assert not tw["base_loop10_fp16emu_finite"] or metrics_rel(got, ref) <= 2 * tw["base_loop10_d_oracle32_vs_fp16emu"]
+    # The fp16-emulated oracle does not survive this loop (the fixture records a non-finite end point), so there is no finite
+    # envelope to tie the base loop to: its bound is the rel-L2 above alone.  The fixture is asserted to still say so -- if a
+    # regenerated one ever reports a finite fp16 loop, this test must get the envelope assertion the up-sampler loop has below.
+    assert tw["base_loop10_fp16emu_finite"] is False
     del dm, oracle, bp
     torch.cuda.empty_cache()
     up = OG.init_params(OG.UPSAMPLE_OPTIONS, seed=1)

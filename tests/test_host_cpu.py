@@ -216,6 +216,84 @@ def test_diffusion_wrapper_routes_every_conditioning_key():
         LatentDiffusion(unet_config=Rec(), conditioning_key="crossattn").apply_model(x, t, {"c_concat": cc, "c_crossattn": ctx})
 
 
+def test_distributed_selects_rccl_when_a_gpu_is_present(monkeypatch):
+    """The only untested thing about N > 1 should be RCCL itself: with MDX_DIST_BACKEND unset and a GPU visible, init_from_env
+    picks "nccl" (= RCCL on ROCm), pins the device BEFORE creating the group and passes device_id; _broadcast then hands the DEVICE
+    payload to dist.broadcast directly (no host staging) and neither times nor synchronises unless time_collectives is set."""
+    from minddiffusion_amd import distributed as D
+    calls = []
+    monkeypatch.delenv("MDX_DIST_BACKEND", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setattr(D.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(D.torch.cuda, "set_device", lambda i: calls.append(("set_device", i)))
+    monkeypatch.setattr(D.dist, "is_initialized", lambda: False)
+    monkeypatch.setattr(D.dist, "init_process_group", lambda **kw: calls.append(("init", kw)))
+    assert D.init_from_env() == (1, 2, 1)
+    assert calls[0] == ("set_device", 1)
+    assert calls[1][0] == "init" and calls[1][1]["backend"] == "nccl" and calls[1][1]["device_id"] == torch.device("cuda", 1)
+    # gloo is only taken on request (several ranks on one GPU) or without a GPU
+    calls.clear()
+    monkeypatch.setenv("MDX_DIST_BACKEND", "gloo")
+    D.init_from_env()
+    assert calls == [("init", {"backend": "gloo"})]
+    calls.clear()
+    monkeypatch.delenv("MDX_DIST_BACKEND")
+    monkeypatch.setattr(D.torch.cuda, "is_available", lambda: False)
+    D.init_from_env()
+    assert calls == [("init", {"backend": "gloo"})]
+
+    class DevPayload:       # what _broadcast touches of a device tensor
+        is_cuda = True
+
+        def numel(self):
+            return 10
+
+        def element_size(self):
+            return 2
+
+        def cpu(self):
+            raise AssertionError("the RCCL branch must not stage the payload through the host")
+    sent = []
+    monkeypatch.setattr(D.dist, "get_backend", lambda: "nccl")
+    monkeypatch.setattr(D.dist, "broadcast", lambda t, src: sent.append((t, src)))
+    monkeypatch.setattr(D.torch.cuda, "Event", lambda **kw: (_ for _ in ()).throw(AssertionError("timed without opt-in")))
+    D.reset_collective_stats()
+    assert D.time_collectives is False
+    pl = DevPayload()
+    D._broadcast(pl, 0)
+    assert sent == [(pl, 0)] and D.collective_stats["broadcasts"] == 1 and D.collective_stats["bytes"] == 20
+    assert D.collective_stats["ms"] == 0.0
+
+
+def test_tune_cache_file_is_versioned(tmp_path):
+    """ops.save_tune_cache / load_tune_cache: a file written under another key layout is ignored with a warning instead of
+    loading entries that can never match (every shape would silently be measured again)."""
+    import json
+    import warnings
+    from minddiffusion_amd import ops
+    saved = dict(ops.tune_cache)
+    try:
+        ops.tune_cache.clear()
+        key = (2048, 640, 640, 1, 1, 0, 4096 | 256, 2, 1024, 1)
+        ops.tune_cache[key] = (64, 64, 1, 3, 12.5, 11.0)
+        f = tmp_path / "tc.json"
+        ops.save_tune_cache(str(f))
+        ops.tune_cache.clear()
+        assert ops.load_tune_cache(str(f)) == 1 and ops.tune_cache[key] == (64, 64, 1, 3, 12.5, 11.0)
+        ops.tune_cache.clear()
+        old = tmp_path / "old.json"
+        old.write_text(json.dumps([[[2048, 640, 640, 1, 1, 0, 256], [64, 64, 1, 3, 12.5, 11.0]]]))      # rounds 1-3: 7-field keys
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert ops.load_tune_cache(str(old)) == 0
+        assert w and "another key layout" in str(w[0].message) and not ops.tune_cache
+    finally:
+        ops.tune_cache.clear()
+        ops.tune_cache.update(saved)
+
+
 def test_instantiate_from_config_reference_targets():
     from minddiffusion_amd.ldm.util import instantiate_from_config
     from minddiffusion_amd.configs import TINY_UNET

@@ -2,7 +2,7 @@
 """Same-box A/B of one UNet evaluation (hipGraph replay) under two option sets, interleaved in one process (cdna guide 5.4 rule 24):
 the boxes of the pool differ by +-3-5 % for one build, so whole-evaluation claims need both arms on one box.
 
-    python tools/eval_ab.py --model wukong --batch 16 --latent 64 --arms "base:gemm_conv8p=0,gemm_dense8p=0,unet_subpixel_upsample=0" "new:"
+    python tools/eval_ab.py --model wukong --batch 16 --latent 64 --arms "base:gemm_conv8p=0,unet_subpixel_upsample=0" "new:"
 
 An arm is  name:opt=value,opt=value  (library options of include/mdx.h or planner options of ops._OPTIONS; options an arm does not
 name keep their defaults).  Every arm builds its own network + plan under its options (the library options are set again before each

@@ -22,7 +22,7 @@ def family(name):
     if name.startswith("void at::") or "at::native" in name or "rocclr" in name:
         return None   # torch's weight-initialisation / copy kernels
     if ("gemm_kernel" in name or "conv3x3_halo_kernel" in name or "st_tail_kernel" in name or "st_head_kernel" in name
-            or "conv8p_kernel" in name or "gemm8p_kernel" in name or "gemm8q_kernel" in name):
+            or "conv8p_kernel" in name):
         return "gemm"      # (the fused SpatialTransformer head / tail launches are chains of dense GEMMs)
     if "splitk_reduce" in name:
         return "splitk_reduce"
