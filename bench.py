@@ -69,7 +69,7 @@ CONFIGS = {
                                ctx_dim=768, tflop_per_row=0.803, inpaint=True, unit="latents/s",
                                metric="512x512 inpainting latents/sec (30-step PLMS, Wukong-Huahua inpaint)",
                                workload="Wukong-Huahua inpainting 512x512 (LatentInpaintDiffusion, hybrid conditioning: UNet input "
-                                        "= latent + resized mask + masked-image latent = 9 channels), PLMS 30 steps (31 UNet "
+                                        "= latent + resized mask + masked-image latent = 9 channels), PLMS S = 30 (31-point grid, 32 UNet "
                                         "calls), CFG 7.5, batch 4 per GPU (inpaint.py CLI defaults; every rank its own images)"),
     "glide_256": dict(family="glide", batch=8, scale=5.0, tflop_per_image=63.2, unit="images/s",
                       metric="Taichu-GLIDE 256x256 images/sec (60-step guided base + 27-step DDIM super-res)",
@@ -486,7 +486,10 @@ def run_config(config, args, rank, world, device, steps, warmup, cpu):
             result["per_unet_step_ms"] = round(float(np.median([a.elapsed_time(b) for a, b in evs])), 3)
             result["config"].update(ddim_steps=cfg["steps"], cfg_scale=cfg["scale"], unet_batch_per_gpu=nb,
                                     sampler=cfg["sampler"])
-            n_evals = cfg["steps"] + (1 if cfg["sampler"] == "plms" else 0)
+            from minddiffusion_amd.ldm.modules.diffusionmodules.util import make_ddim_timesteps
+            # (the reference's uniform grid has range(0, 1000, 1000 // S) points: 50 for S = 50, 31 for S = 30)
+            n_grid = len(make_ddim_timesteps("uniform", cfg["steps"], 1000, verbose=False)) if cfg["sampler"] != "dpm_solver" else cfg["steps"]
+            n_evals = n_grid + (1 if cfg["sampler"] == "plms" else 0)
             tflop_per_unit = cfg["tflop_per_row"] * 2 * n_evals + cfg.get("vae_tflop", 0.0)   # CFG doubles the rows
             Pl = model.unet._plan(nb, h, w)
             # what actually ran in the timed region: a captured hipGraph replay, or (capture failed / --no-graph) eager launches

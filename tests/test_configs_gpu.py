@@ -244,7 +244,7 @@ def test_config2_wukong_512_unet_batch16_and_plms():
 def test_inpaint_wukong_full_size():
     """SURVEY 8(f) item 4 at full size: configs/wukong-huahua_inpaint_inference.yaml (the Wukong UNet on 9 input channels,
     LatentInpaintDiffusion / 'hybrid') driven as wukong-huahua/inpaint.py:65-106 drives it with its CLI defaults -- batch 4,
-    PLMS 30 steps (31 evaluations at UNet batch 8), scale 7.5, dict conditioning with the SAME c_concat on both CFG halves.
+    PLMS with S = 30 (a 31-point grid: 32 evaluations at UNet batch 8), scale 7.5, dict conditioning with the SAME c_concat on both CFG halves.
     Oracle: committed fixture tests/golden/traj_inpaint_wukong_plms30.npz (one apply_model row + the trajectory of image 0)."""
     import json as _json
     import sys
@@ -256,7 +256,8 @@ def test_inpaint_wukong_full_size():
     z = np.load(os.path.join(ROOT, "tests", "golden", "traj_inpaint_wukong_plms30.npz"))
     meta = _json.loads(str(z["meta"]))
     inp = inputs_inpaint()
-    assert meta["S"] == inp["S"] and meta["unet_seed"] == inp["seed"] and meta["unet_calls"] == inp["S"] + 1
+    # (S = 30 on the reference's uniform grid is range(0, 1000, 1000 // 30): 31 timesteps, so PLMS makes 32 model calls)
+    assert meta["S"] == inp["S"] and meta["unet_seed"] == inp["seed"] and meta["unet_calls"] == 32
     ocfg = dict(O.WUKONG_UNET, in_channels=9)
     net, _ = _unet(WUKONG_INPAINT_UNET, ocfg, inp["seed"])
     model = LatentInpaintDiffusion(unet_config=net, linear_start=0.00085, linear_end=0.0120, timesteps=1000)
