@@ -175,7 +175,11 @@ typedef struct mdx_gemm_desc {
      * mdx_st_tail_desc.colstats_out: [B * gn_nrb][Cin][2]), gn_gamma / gn_beta fp32 [Cin].  Every block folds its sample's
      * partials into a per-channel {scale, shift} table and normalises the halo slices in LDS after they land; `a` is then the RAW
      * tensor and no GroupNorm launch runs.  Single-source 3x3 stride-1 convs with Cin %% 64 == 0, Cin <= 640, images larger than
-     * 8 x 8, that resolve to the HALO kernel with 64-column tiles (mdx_gemm_query: out7[3] == 1, out7[1] == 64). */
+     * 8 x 8, that resolve to the HALO kernel with 64-column tiles (mdx_gemm_query: out7[3] == 1, out7[1] == 64).
+     * DENSE launches (ksize = 1; round 5): nn.GroupNorm(32) WITHOUT an activation in front of a Dense / 1x1 conv
+     * (SpatialTransformer.norm -> proj_in, attention.py:243-247; GLIDE AttentionBlock.norm -> qkv): set gn_silu = 0.  The block folds
+     * the partials into fp16 {scale, shift} tables and applies them to the A fragments between LDS and the matrix pipe (one packed fma
+     * per two values).  Single source, Cin %% 64 == 0, Cin <= 2560, tokens per sample %% tile_m == 0 (mdx_gemm_query out7[0]). */
     const float* gn_colstats;
     const float* gn_gamma;
     const float* gn_beta;

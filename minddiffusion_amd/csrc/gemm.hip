@@ -36,7 +36,14 @@
 namespace {
 
 
-template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK, int NW>
+// GNA (dense launches, ksize 1): nn.GroupNorm(32) of the INPUT -- no activation: SpatialTransformer.norm -> proj_in (attention.py:
+// 243-247), GLIDE's AttentionBlock.norm -> qkv -- applied to the A fragments on their way from LDS to the matrix pipe.  GroupNorm
+// without an activation is affine per (sample, channel): x' = a[b][k] x + s[b][k], a = gamma rstd, s = beta - mean a.  The block
+// folds its sample's column partials (the producer's colstats_out, exactly as the HALO conv does below) into two fp16 tables in LDS
+// and every A fragment becomes ONE packed fma per two halves (v_pk_fma_f16, single rounding) right after its ds_read: the
+// normalised tensor is never written or read, and the GroupNorm launch disappears.  An M tile lies inside one sample
+// (tokens per sample %% BM == 0, checked on the host).
+template <int BM, int BN, int BK, int NS, bool SWAP, bool FASTK, int NW, bool GNA = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const GemmParams p) {
     // NW = 4 (2 x 2 waves) or 8 (4 x 2 waves, BM = 128 only).  The 8-wave form is for grids of at most one block per
     // CU: a wave's K-step is a serial chain (wait -> barrier -> DMA issue -> ds_read -> MFMA), so a lone 4-wave block
@@ -237,6 +244,59 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i)
         if (i < nt) stage_tile(kt_begin + i, i);
+    // GNA tables live behind everything the ring and the epilogue staging use: [cin] a, [cin] s (fp16), [cin] {sum, sumsq} scratch
+    constexpr size_t GNA_RING = (size_t)NS * (BM + BN) * BK * 2;
+    constexpr size_t GNA_EPI = (size_t)(BM > BN ? BM : BN) * ((BM > BN ? BN : BM) + 8) * 2 + 4096;
+    constexpr size_t GNA_BASE = GNA_RING > GNA_EPI ? GNA_RING : GNA_EPI;
+    [[maybe_unused]] const f16* gta = reinterpret_cast<const f16*>(smem + GNA_BASE);
+    [[maybe_unused]] const f16* gts = gta + p.cin;
+    if constexpr (GNA) {
+        // (the prologue DMAs above are already in flight: the fold's global round trip overlaps them)
+        f16* wa = reinterpret_cast<f16*>(smem + GNA_BASE);
+        f16* wsft = wa + p.cin;
+        float2* csum = reinterpret_cast<float2*>(wsft + p.cin);
+        const int pb = m0 / p.HoWo;
+        const int cpg = p.cin >> 5;
+        const float2* src = reinterpret_cast<const float2*>(p.gn_cs) + (size_t)pb * p.gn_nrb * p.cin;
+        for (int c = tid; c < p.cin; c += NW * 64) {
+            float su = 0.f, sq = 0.f;
+            int k = 0;
+            for (; k + 8 <= p.gn_nrb; k += 8) {
+                float2 v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = src[(size_t)(k + e) * p.cin + c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    su += v[e].x;
+                    sq += v[e].y;
+                }
+            }
+            for (; k < p.gn_nrb; ++k) {
+                const float2 v = src[(size_t)k * p.cin + c];
+                su += v.x;
+                sq += v.y;
+            }
+            csum[c] = make_float2(su, sq);
+        }
+        __syncthreads();
+        for (int c = tid; c < p.cin; c += NW * 64) {
+            const int g = c / cpg;
+            float su = 0.f, sq = 0.f;
+            for (int e = 0; e < cpg; ++e) {
+                const float2 v = csum[g * cpg + e];
+                su += v.x;
+                sq += v.y;
+            }
+            const float inv = 1.0f / ((float)cpg * (float)p.HoWo);
+            const float mean = su * inv;
+            float var = sq * inv - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            const float a = p.gn_gamma[c] * rsqrtf(var + p.gn_eps);
+            wa[c] = (f16)a;
+            wsft[c] = (f16)(p.gn_beta[c] - mean * a);
+        }
+        __syncthreads();
+    }
     int rd = 0;            // stage holding tile t
     int wr = NS - 1;       // stage that tile t+NS-1 goes to
     trace_mark(p, 1);
@@ -258,10 +318,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
         if (t + NS - 1 < nt) stage_tile(kt_begin + t + NS - 1, wr);
         const char* sb = smem + rd * STAGE;
         f16x8 af[2][TM], bf[2][TN];
+        [[maybe_unused]] f16x8 gna[2], gns[2];      // GNA: this lane's 8 channels' {a, s} of k-step s (channel = K index: dense launch)
+        [[maybe_unused]] const int gk = (kt_begin + t) * BK + hi * 8;
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + ((hi ^ swz) << 4));
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + ((hi ^ swz) << 4));
+        if constexpr (GNA) {
+            gna[0] = *reinterpret_cast<const f16x8*>(gta + gk);
+            gns[0] = *reinterpret_cast<const f16x8*>(gts + gk);
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
@@ -271,6 +337,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
                 for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + coff);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + coff);
+                if constexpr (GNA) {
+                    gna[nxt] = *reinterpret_cast<const f16x8*>(gta + gk + 16 * (s + 1));
+                    gns[nxt] = *reinterpret_cast<const f16x8*>(gts + gk + 16 * (s + 1));
+                }
+            }
+            if constexpr (GNA) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[cur][i] = af[cur][i] * gna[cur] + gns[cur];      // v_pk_fma_f16 x 4
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -1056,10 +1130,17 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     p.gn_eps = d->gn_eps;
     if (p.gn_cs) {
         MDX_REQUIRE(p.gn_gamma && p.gn_beta && p.gn_nrb > 0, "mdx_gemm_f16: gn_colstats needs gn_gamma, gn_beta and gn_nrb > 0");
-        MDX_REQUIRE(p.ksize == 3 && p.stride == 1 && !p.upsample && p.c2 == 0 && p.cin % 64 == 0 && p.cin % 32 == 0 &&
-                        p.cin <= 640 && !d->w_frag && !(d->H == 8 && d->W == 8),
-                    "mdx_gemm_f16: the fused input GroupNorm rides on a single-source 3x3 stride-1 conv with Cin %% 64 == 0, "
-                    "Cin <= 640, images larger than 8 x 8 and tile-major weights");
+        if (p.ksize == 1) {     // GroupNorm (no activation) -> Dense / 1x1 conv: applied to the A fragments (gemm_kernel GNA)
+            MDX_REQUIRE(p.stride == 1 && !p.upsample && p.c2 == 0 && p.cin % 64 == 0 && p.cin <= 2560 && !p.gn_silu &&
+                            p.HoWo % 64 == 0,
+                        "mdx_gemm_f16: the fused input GroupNorm of a dense launch needs a single source, Cin %% 64 == 0, "
+                        "Cin <= 2560, gn_silu = 0 and tokens per sample %% 64 == 0");
+        } else {
+            MDX_REQUIRE(p.ksize == 3 && p.stride == 1 && !p.upsample && p.c2 == 0 && p.cin % 64 == 0 && p.cin % 32 == 0 &&
+                            p.cin <= 640 && !d->w_frag && !(d->H == 8 && d->W == 8),
+                        "mdx_gemm_f16: the fused input GroupNorm rides on a single-source 3x3 stride-1 conv with Cin %% 64 == 0, "
+                        "Cin <= 640, images larger than 8 x 8 and tile-major weights");
+        }
     }
     p.w_sub = (const f16*)d->w_sub;
     p.w_sub_bytes = 0;
@@ -1255,6 +1336,30 @@ void launch_one(const GemmParams& p, dim3 grid, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, NS, SWAP, FASTK, NW>), grid, dim3(NW * 64), lds, st, p);
+}
+
+// GNA form (GroupNorm of the input on the A fragments): four waves, ring depth 2 | 3, K-contiguous (dense) launches only
+template <int BM, int BN, int NS, bool SWAP>
+void launch_gna_one(const GemmParams& p, dim3 grid, hipStream_t st) {
+    constexpr size_t ring = (size_t)NS * (BM + BN) * 64 * 2;
+    constexpr size_t epi = (size_t)(BM > BN ? BM : BN) * ((BM > BN ? BN : BM) + 8) * 2 + 4096;
+    constexpr size_t lds0 = ring > epi ? ring : epi;
+    const size_t lds = lds0 + (size_t)p.cin * 12;       // a, s (fp16) + {sum, sumsq} scratch (fp32 pairs)
+    static MdxPerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, 64, NS, SWAP, true, 4, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds0 + 2560 * 12));
+    }
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, 64, NS, SWAP, true, 4, true>), grid, dim3(256), lds, st, p);
+}
+
+template <int BM, int BN>
+void launch_gna(const GemmParams& p, int ns, bool swap, dim3 grid, hipStream_t st) {
+    if (ns >= 3) {
+        if (swap) launch_gna_one<BM, BN, 3, true>(p, grid, st); else launch_gna_one<BM, BN, 3, false>(p, grid, st);
+    } else {
+        if (swap) launch_gna_one<BM, BN, 2, true>(p, grid, st); else launch_gna_one<BM, BN, 2, false>(p, grid, st);
+    }
 }
 
 template <int BM, int BN, int BK, int NS, int NW>
@@ -1595,7 +1700,13 @@ static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
         }
     }
     r.halo = r.c.bm >= 128 && halo_eligible(p, r.c.bm);
-    if (p.gn_cs && !(r.halo && r.bn == 64 && !halo8_eligible(p))) {
+    if (p.gn_cs && p.ksize == 1) {
+        if (p.HoWo % r.c.bm != 0) {
+            mdx_set_error("mdx_gemm_f16: the fused input GroupNorm of a dense launch needs tokens per sample (%d) %% tile_m (%d) == 0",
+                          p.HoWo, r.c.bm);
+            return MDX_E_INVALID;
+        }
+    } else if (p.gn_cs && !(r.halo && r.bn == 64 && !halo8_eligible(p))) {
         mdx_set_error("mdx_gemm_f16: the fused input GroupNorm needs a launch that resolves to the HALO 3x3 kernel with 64-column "
                       "tiles (ask mdx_gemm_query first)");
         return MDX_E_INVALID;
@@ -1765,6 +1876,16 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
             if (bn == 128) launch_halo_cfg<128, 128, 8>(p, nsb, swap, grid, st); else launch_halo_cfg<128, 64, 8>(p, nsb, swap, grid, st);
         } else {
             if (bn == 128) launch_halo_cfg<128, 128>(p, nsb, swap, grid, st); else launch_halo_cfg<128, 64>(p, nsb, swap, grid, st);
+        }
+        ok = true;
+    } else if (p.gn_cs) {       // (ksize 1, checked in fill_params / resolve_launch) GroupNorm of the input on the A fragments
+        MDX_REQUIRE(fastk, "mdx_gemm_f16: the fused input GroupNorm needs Cin %% 64 == 0");
+        // (ring depth as the occupancy rule / tile table chose it, capped at the three stages this form is built with)
+        const int gns = cc.ns >= 3 ? 3 : 2;
+        if (cc.bm == 64) {
+            if (bn == 128) launch_gna<64, 128>(p, gns, swap, grid, st); else launch_gna<64, 64>(p, gns, swap, grid, st);
+        } else {
+            if (bn == 128) launch_gna<128, 128>(p, gns, swap, grid, st); else launch_gna<128, 64>(p, gns, swap, grid, st);
         }
         ok = true;
     } else if (cc.bm == 64)

@@ -760,6 +760,13 @@ class UNetModel:
                 return dict(bias=w[name + ".cb"], ln_stats=st, ln_s=w[name + ".s"], ln_eps=1e-5)
             tok = dense(main, a, B, n, ch, inner, w[pre + "proj_in.w"], bias=w[pre + "proj_in.b"],
                         stats_out=st if fold1 else None)
+            # SpatialTransformer.norm has no activation (attention.py:243-247): proj_in can apply it to its A fragments from the
+            # producer's column statistics (mdx_gemm_desc.gn_colstats on a dense launch).  Decided when the statistics are wired
+            # (ops.wire_groupnorm_colstats): on success the GroupNorm op above is dropped and proj_in reads the raw x
+            pf = ops.get_option("unet_gn_proj_fuse")
+            if (_fuse_head and pf and n >= pf and n % 64 == 0 and ch % 64 == 0 and ch <= 2560
+                    and producer.get(x.data_ptr()) is not None):
+                gn_calls[-1]["proj"] = dict(desc=descs[-1], meta=len(meta) - 1)
             A.release(a)
             for k in range(self.transformer_depth):
                 t = pre + f"transformer_blocks.{k}."
@@ -963,7 +970,7 @@ class UNetModel:
         fuse_hw = ops.get_option("unet_gn_splitk_fuse")     # fuse for tensors of at most this many pixels per sample (0 = never)
         if fuse_hw:
             for c in gn_calls:
-                if c.get("head") is not None or c.get("conv") is not None:
+                if c.get("head") is not None or c.get("conv") is not None or c.get("proj") is not None:
                     continue
                 _, HW, C1 = c["x1"].shape
                 if HW > fuse_hw:
@@ -992,6 +999,10 @@ class UNetModel:
             # a fused head whose input tensor's producer cannot emit column statistics in its final launch form: plan again
             # with the unfused GroupNorm / proj_in / qkv launches (plans are built once per shape)
             return self._plan(B, H, W, _fuse_head=False, _selfctx=_selfctx)
+        if any(m.get("dead") for m in meta):      # GroupNorm launches that moved into the GEMM behind them
+            keep = [i for i, m in enumerate(meta) if not m.get("dead")]
+            main[:] = [main[i] for i in keep]
+            meta[:] = [meta[i] for i in keep]
         # ---- first-use tuning (off by default): a resolution / batch the tile table was not measured at runs the cost model's
         # tiles, 10-20 % off on some shapes; with the option on, every such launch form is timed once per shape (ops.tune_cache)
         if ops.get_option("unet_tune_first_use"):

@@ -40,7 +40,12 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
             "unet_tune_first_use": int(os.environ.get("MDX_UNET_TUNE_FIRST_USE", "0")),
             # 1 = Upsample convs carry the sub-pixel weights (mdx_gemm_desc.w_sub: 4 Cin instead of 9 Cin products per output on the
             # un-upsampled tensor); the library uses them wherever the eight-wave conv core applies
-            "unet_subpixel_upsample": int(os.environ.get("MDX_UNET_SUBPIXEL_UPSAMPLE", "1"))}
+            "unet_subpixel_upsample": int(os.environ.get("MDX_UNET_SUBPIXEL_UPSAMPLE", "1")),
+            # SpatialTransformer.norm (GroupNorm without an activation) applied inside proj_in (mdx_gemm_desc.gn_colstats on a dense
+            # launch: one packed fma per A fragment) at levels with at least this many tokens per sample (0 = never): no GroupNorm
+            # launch, no normalised copy of the tensor.  Below ~1k tokens the GroupNorm launch doubles as the split-K reduce of the
+            # conv in front of it (unet_gn_splitk_fuse), which the fold would give back as a reduce launch.
+            "unet_gn_proj_fuse": int(os.environ.get("MDX_UNET_GN_PROJ_FUSE", "1024"))}
 
 
 def set_option(name, value):
@@ -679,7 +684,7 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
     for c in gn_calls:
         _, HW, C1 = c["x1"].shape
         # fused SpatialTransformer head / GroupNorm inside the consuming conv: the statistics feed that launch (any block count)
-        is_head = c.get("head") is not None or c.get("conv") is not None
+        is_head = c.get("head") is not None or c.get("conv") is not None or c.get("proj") is not None
         C2 = 0 if c["x2"] is None else c["x2"].shape[2]
         cpg = (C1 + C2) // 32
         L = cpg // math.gcd(cpg, 8)           # chunk columns of the minimal whole-group column block
@@ -729,6 +734,37 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
             fresh.append((key, d))
             return table[key]
         s1 = stats_of(c["prod"][0], C1)
+        if c.get("proj") is not None:
+            # GroupNorm (no activation) in front of a Dense / 1x1 conv: the consumer applies it to its A fragments when the
+            # producer can supply column statistics in <= 64 row blocks per sample and an M tile stays inside one sample;
+            # otherwise this call falls back to the GroupNorm launch it was planned with (handled below like any other)
+            pj = c.pop("proj")
+            dd = pj["desc"]
+            ok = False
+            if s1 is not None and not isinstance(s1[0], FoldedColStats) and int(s1[1]) <= 64:
+                keep = (dd.a, dd.gn_colstats, dd.gn_nrb, dd.gn_gamma, dd.gn_beta, dd.gn_eps, dd.gn_silu)
+                dd.a, dd.gn_colstats, dd.gn_nrb = c["x1"].data_ptr(), s1[0].data_ptr(), int(s1[1])
+                dd.gn_gamma, dd.gn_beta, dd.gn_eps, dd.gn_silu = c["g"].data_ptr(), c["b"].data_ptr(), float(c["eps"]), 0
+                ok = _lib.load().mdx_gemm_check(ctypes.byref(dd)) == 0 and HW % gemm_query(dd)[0] == 0
+                if not ok:
+                    dd.a, dd.gn_colstats, dd.gn_nrb, dd.gn_gamma, dd.gn_beta, dd.gn_eps, dd.gn_silu = keep
+            if ok:
+                dd._gn_src = (c["x1"], s1[0])       # (python-side: keeps the raw input and the statistics buffer alive)
+                meta[c["meta"]]["dead"] = True      # the planner drops the GroupNorm op
+                meta[pj["meta"]]["info"] += " +groupnorm(in)"
+                continue
+            for key, d in fresh:
+                table.pop(key, None)
+                d.colstats_out = 0
+                if hasattr(d, "colstats_cap"):
+                    d.colstats_cap = 0
+            fresh.clear()
+            is_head = False
+            L_ = cpg // math.gcd(cpg, 8)
+            if L_ <= 64 and HW * L_ * 16 <= (64 << 10):
+                meta[c["meta"]]["launches"] = 1
+                continue
+            s1 = stats_of(c["prod"][0], C1)
         if is_head:
             if s1 is not None and c.get("head") is not None:
                 c["head"].colstats, c["head"].nrb = s1[0].data_ptr(), int(s1[1])

@@ -847,14 +847,35 @@ def test_unet_plan_fuses_the_320_channel_transformer_blocks():
     assert lib.mdx_st_tail_supported(640, 10, 64, 1024, 32) == 0 and lib.mdx_st_head_supported(640, 1024, 32) == 0
     infos = [m["info"] for m in P.meta]
     assert sum(i.startswith("st_head") for i in infos) == blocks320 and sum(i.startswith("st_tail") for i in infos) == blocks320
+    pf = ops.get_option("unet_gn_proj_fuse")
     try:
         ops.set_option("unet_st_tail", 0)
         ops.set_option("unet_st_head", 0)
-        P0 = build()._plan(2, 64, 64)
+        P1 = build()._plan(2, 64, 64)               # launch-per-op transformers, SpatialTransformer.norm folded into proj_in (round 5)
+        ops.set_option("unet_gn_proj_fuse", 0)
+        P0 = build()._plan(2, 64, 64)               # ... and with the GroupNorm launches of rounds 1-4
     finally:
         ops.set_option("unet_st_tail", -1)
         ops.set_option("unet_st_head", -1)
+        ops.set_option("unet_gn_proj_fuse", pf)
     assert not P0.tails and not P0.heads_fused
+    # round 5: every transformer whose level has >= unet_gn_proj_fuse tokens per sample loses its GroupNorm launch to proj_in
+    # (all of them here: 4096 and 1024 tokens), the GEMM count is unchanged, and the fused-head plan P already had none to lose at
+    # the 320-channel level but folds the 640-channel ones
+    folded1 = sum("+groupnorm(in)" in m["info"] for m in P1.meta)
+    assert folded1 == sum(m["info"].startswith("self ") for m in P1.meta) and folded1 > blocks320
+    assert kinds(P0)["groupnorm"] - kinds(P1)["groupnorm"] == folded1 and kinds(P0)["gemm"] == kinds(P1)["gemm"]
+    assert len(P0.main) - len(P1.main) == folded1 and not any("+groupnorm(in)" in m["info"] for m in P0.meta)
+    assert sum("+groupnorm(in)" in m["info"] for m in P.meta) == folded1 - blocks320
+    for m in P1.meta:
+        if "+groupnorm(in)" in m["info"]:
+            d = m["desc"]
+            assert d.gn_colstats and d.gn_nrb > 0 and d.gn_silu == 0 and d.ksize == 1 and (d.H * d.W) % ops.gemm_query(d)[0] == 0
+    try:
+        ops.set_option("unet_gn_proj_fuse", 0)
+        P = build()._plan(2, 64, 64)                # (the comparison below is about the fused head / tail alone)
+    finally:
+        ops.set_option("unet_gn_proj_fuse", pf)
     k, k0 = kinds(P), kinds(P0)
     # per fused block: 8 GEMMs (proj_in, q|k|v, to_out, q, to_out, ff1, ff2, proj_out) become 2, the GroupNorm and the
     # cross-attention launch disappear

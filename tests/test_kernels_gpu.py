@@ -1256,3 +1256,65 @@ def test_conv3x3_with_fused_input_groupnorm(ops, B, H, W, Cin, Cout, splitk, row
         an = ops.groupnorm(xd, None, gd, btd, 1e-5, True)
         two = ops.gemm(an, wd, Cout, B, H, W, Cin, bias=bd, rowbias=rbd, rowbias_ld=Cout, ksize=3)
         check(f"conv3x3_fused_gn_vs_two_launches_{H}x{W}_{Cin}_r{rows}", out.reshape(-1, Cout), two, rel_l2=1e-3)
+
+
+@pytest.mark.parametrize("B,HW,Cin,N,rows,splitk,tile_m,tile_n,extra", [
+    (2, 1024, 640, 640, 128, 0, 0, 0, "stats"),      # SDv2 32 x 32 level at UNet batch 2: proj_in with LayerNorm row statistics out
+    (2, 256, 1280, 1280, 64, 3, 0, 0, "stats"),      # 16 x 16 level: in-kernel split-K, statistics from 64-row reduce blocks
+    (16, 1024, 640, 640, 128, 0, 0, 0, ""),          # batch 16: 128-row tiles
+    (3, 576, 320, 320, 64, 0, 64, 64, ""),           # 24 x 24 tokens, 10 channels per group, forced 64 x 64 tiles
+    (2, 1024, 640, 640, 32, 0, 128, 128, ""),        # 32-row statistics blocks (a fused SpatialTransformer tail's), 128 x 128 tiles
+    (2, 1024, 192, 576, 128, 0, 0, 0, "qkv"),        # GLIDE AttentionBlock: norm -> qkv (6 channels per group), no bias folding
+])
+def test_dense_with_fused_input_groupnorm(ops, B, HW, Cin, N, rows, splitk, tile_m, tile_n, extra):
+    """mdx_gemm_desc.gn_colstats on a DENSE launch: nn.GroupNorm(32) without an activation -> Dense / 1x1 conv
+    (SpatialTransformer.norm -> proj_in, attention.py:243-247; GLIDE AttentionBlock.norm -> qkv) in ONE launch on the RAW input,
+    the normalisation applied to the A fragments as a packed fp16 fma.  Against the fp32 reference and against the GroupNorm
+    launch + GEMM launch it replaces.  Tolerance 1.5e-3: the per-channel scale / shift are fp16 (2^-11 each) on top of the fp16
+    rounding of the normalised value that the two-launch form also has."""
+    rng = np.random.RandomState(B + HW + Cin + N + rows)
+    x = h16(rng.standard_normal((B, HW, Cin)) * (0.5 + rng.rand(Cin))[None, None, :] + rng.standard_normal(Cin)[None, None, :])
+    g, bt = (1.0 + 0.2 * rng.standard_normal(Cin)).astype(np.float32), (0.1 * rng.standard_normal(Cin)).astype(np.float32)
+    wt = h16(rng.standard_normal((N, Cin)) / math.sqrt(Cin))
+    bv = rng.standard_normal(N).astype(np.float32)
+    xn = O.group_norm(torch.tensor(x).permute(0, 2, 1).reshape(B, Cin, HW, 1), torch.tensor(g), torch.tensor(bt), 1e-6)
+    ref = xn.reshape(B, Cin, HW).permute(0, 2, 1).reshape(B * HW, Cin) @ torch.tensor(wt).T + torch.tensor(bv)
+    xd = dev16(x)
+    nrb = HW // rows
+    blk = xd.float().reshape(B * nrb, rows, Cin)
+    cs = torch.stack([blk.sum(1), (blk * blk).sum(1)], 2).contiguous()
+    out = torch.empty((B * HW, N), dtype=torch.float16, device=DEV)
+    wd, bd, gd, btd = pack_dense(wt), dev32(bv), dev32(g), dev32(bt)
+    st = torch.zeros((B * HW, N // 64, 2), dtype=torch.float32, device=DEV) if extra == "stats" else None
+    d = ops.make_gemm_desc(xd, wd, N, B, HW, 1, Cin, out, N, bias=bd, splitk=splitk, tile_m=tile_m, tile_n=tile_n,
+                           stats_out=st, gn_colstats=cs, gn_nrb=nrb, gn_gamma=gd, gn_beta=btd, gn_eps=1e-6, gn_silu=0)
+    ws_ = ops.new_gemm_workspace(max(ops.gemm_workspace_bytes(d), 1 << 20), DEV)
+    d.workspace, d.workspace_bytes = ws_.data_ptr(), ws_.numel() * 4
+    q = ops.gemm_query(d)
+    assert q[3] == 0 and HW % q[0] == 0, q
+    out.fill_(float("nan"))
+    ops.gemm_run(d)
+    torch.cuda.synchronize()
+    name = f"dense_fused_gn_B{B}_HW{HW}_{Cin}_{N}_r{rows}_s{q[2]}_t{q[0]}x{q[1]}"
+    check(name, out, ref, rel_l2=1.5e-3)
+    an = ops.groupnorm(xd, None, gd, btd, 1e-6, False)
+    two = ops.gemm(an, wd, N, B, HW, 1, Cin, bias=bd)
+    check(name + "_vs_two_launches", out, two, rel_l2=1.5e-3)
+    if st is not None:      # the LayerNorm row statistics the launch emits are those of the values it stored
+        o32 = out.float().reshape(B * HW, N // 64, 64)
+        check(name + "_rowstats", st[:, :, 0], o32.sum(-1), rel_l2=1e-5)
+    # replay determinism, and refusal where the form does not apply (SiLU requested / an M tile that would straddle two samples)
+    out2 = torch.empty_like(out)
+    d.out = out2.data_ptr()
+    ops.gemm_run(d)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    from minddiffusion_amd._lib import MdxError
+    bad = ops.make_gemm_desc(xd, wd, N, B, HW, 1, Cin, out, N, gn_colstats=cs, gn_nrb=nrb, gn_gamma=gd, gn_beta=btd, gn_silu=1)
+    with pytest.raises(MdxError):
+        ops.gemm_run(bad)
+    if HW % 128:
+        bad = ops.make_gemm_desc(xd, wd, N, B, HW, 1, Cin, out, N, tile_m=128, gn_colstats=cs, gn_nrb=nrb, gn_gamma=gd,
+                                 gn_beta=btd, gn_silu=0)
+        with pytest.raises(MdxError):
+            ops.gemm_run(bad)

@@ -238,6 +238,37 @@ def test_tiny_inpaint_hybrid_trajectory(blend):
     check("tiny_inpaint_apply_model", e, eo, rel_l2=5e-3, max_abs=5e-2)
 
 
+def test_groupnorm_folds_into_proj_in_where_the_plan_says_so():
+    """Planner option unet_gn_proj_fuse: SpatialTransformer.norm moves into proj_in (one launch less per transformer block, no
+    normalised copy).  The fused plan has fewer ops than the unfused one, at least one launch carries "+groupnorm(in)", and both
+    agree with the oracle (the fold adds fp16 scale / shift rounding: same bounds as every UNet test)."""
+    from minddiffusion_amd import ops
+    cfg = dict(_tiny_cfg(), model_channels=128, attention_resolutions=[1, 2])     # 128 / 256-wide transformers: K tiles of 64
+    params = O.init_params(_oracle_cfg(cfg), seed=13)
+    oracle = O.UNetOracle(_oracle_cfg(cfg), params)
+    B, H, W, T = 2, 32, 32, 9
+    x, ctx = _inputs(B, H, W, T, cfg["context_dim"], seed=5)
+    ts = np.full((B,), 321.0, np.float32)
+    ref = oracle(x, torch.tensor(ts), ctx)
+    keep = {k: ops.get_option(k) for k in ("unet_gn_proj_fuse", "unet_st_head", "unet_st_tail")}
+    counts = {}
+    try:
+        ops.set_option("unet_st_head", 0)        # the transformers take the launch-per-op path the fold applies to
+        ops.set_option("unet_st_tail", 0)
+        for mode in (0, 64):
+            ops.set_option("unet_gn_proj_fuse", mode)
+            net = _build(cfg, params, True)
+            got = net(torch.tensor(x, device=DEV), torch.tensor(ts, device=DEV), torch.tensor(ctx, device=DEV))
+            check(f"unet_gn_proj_fuse{mode}", got, ref, rel_l2=5e-3, max_abs=5e-2)
+            P = net._plans[(B, H, W)]
+            counts[mode] = (len(P.main), sum("+groupnorm(in)" in m["info"] for m in P.meta))
+    finally:
+        for k, v in keep.items():
+            ops.set_option(k, v)
+    assert counts[0][1] == 0 and counts[64][1] >= 1, counts
+    assert counts[64][0] == counts[0][0] - counts[64][1], counts
+
+
 def _selfctx_cfg(**kw):
     """A UNet the reference's `context=None` call type-checks on: attention only where the transformer width equals context_dim
     (WK attention.py:133 `context = default(context, x)` feeds the block's own tokens to to_k / to_v = Dense(context_dim, inner))."""
