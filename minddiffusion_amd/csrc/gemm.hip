@@ -258,6 +258,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
         const int pb = m0 / p.HoWo;
         const int cpg = p.cin >> 5;
         const float2* src = reinterpret_cast<const float2*>(p.gn_cs) + (size_t)pb * p.gn_nrb * p.cin;
+        // gamma / beta of this thread's channels first: they are cold in HBM (weights stream through the caches between two uses),
+        // and fetched here their miss overlaps the partials' round trip instead of following it
+        constexpr int GNA_CPT = 2560 / (NW * 64);      // channels per thread at the largest Cin
+        float gg[GNA_CPT], gb[GNA_CPT];
+#pragma unroll
+        for (int i = 0; i < GNA_CPT; ++i) {
+            const int c = tid + i * NW * 64;
+            gg[i] = c < p.cin ? p.gn_gamma[c] : 0.f;
+            gb[i] = c < p.cin ? p.gn_beta[c] : 0.f;
+        }
         for (int c = tid; c < p.cin; c += NW * 64) {
             float su = 0.f, sq = 0.f;
             int k = 0;
@@ -279,21 +289,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
             csum[c] = make_float2(su, sq);
         }
         __syncthreads();
-        for (int c = tid; c < p.cin; c += NW * 64) {
-            const int g = c / cpg;
-            float su = 0.f, sq = 0.f;
-            for (int e = 0; e < cpg; ++e) {
-                const float2 v = csum[g * cpg + e];
-                su += v.x;
-                sq += v.y;
+        const float inv = 1.0f / ((float)cpg * (float)p.HoWo);
+#pragma unroll
+        for (int i = 0; i < GNA_CPT; ++i) {
+            const int c = tid + i * NW * 64;
+            if (c < p.cin) {
+                const int g = c / cpg;
+                float su = 0.f, sq = 0.f;
+                for (int e = 0; e < cpg; ++e) {
+                    const float2 v = csum[g * cpg + e];
+                    su += v.x;
+                    sq += v.y;
+                }
+                const float mean = su * inv;
+                float var = sq * inv - mean * mean;
+                var = var < 0.f ? 0.f : var;
+                const float a = gg[i] * rsqrtf(var + p.gn_eps);
+                wa[c] = (f16)a;
+                wsft[c] = (f16)(gb[i] - mean * a);
             }
-            const float inv = 1.0f / ((float)cpg * (float)p.HoWo);
-            const float mean = su * inv;
-            float var = sq * inv - mean * mean;
-            var = var < 0.f ? 0.f : var;
-            const float a = p.gn_gamma[c] * rsqrtf(var + p.gn_eps);
-            wa[c] = (f16)a;
-            wsft[c] = (f16)(p.gn_beta[c] - mean * a);
         }
         __syncthreads();
     }
@@ -1223,6 +1237,11 @@ const TunedEntry* lookup_tuned(const GemmParams& p) {
             if (e->var1 == 0 && !any) any = e;
         }
     if (!any) return nullptr;
+    // The key is (M, N, K, ksize), not the image geometry: a row measured at one (B, H, W) also matches other factorizations of M.
+    // A 256-row entry means the 16 x 16-patch HALO kernel; where that kernel does not apply (8 x 8 images at UNet batch 8 share
+    // M = 512 with the 16 x 16 level at batch 2) the row does not describe this launch -- round 5: it used to be taken, the generic
+    // kernel then ran its 128-row tiles on a grid sized for 256-row ones and left the second half of every tile pair unwritten
+    if (any->bm == 256 && !halo_eligible(p, 256)) return nullptr;
     return (any->bm >= 128 || !halo_eligible(p, 128)) ? any : nullptr;
 }
 
@@ -1700,6 +1719,11 @@ static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
         }
     }
     r.halo = r.c.bm >= 128 && halo_eligible(p, r.c.bm);
+    if (r.c.bm == 256 && !r.halo) {      // 256-row tiles exist for the HALO conv only (forced tile_m = 256 on another launch)
+        mdx_set_error("mdx_gemm_f16: tile_m = 256 needs a launch the 16 x 16-patch HALO conv applies to (3x3, stride 1, H %% 16 == 0, "
+                      "W %% 16 == 0, Cin %% 64 == 0)");
+        return MDX_E_INVALID;
+    }
     if (p.gn_cs && p.ksize == 1) {
         if (p.HoWo % r.c.bm != 0) {
             mdx_set_error("mdx_gemm_f16: the fused input GroupNorm of a dense launch needs tokens per sample (%d) %% tile_m (%d) == 0",

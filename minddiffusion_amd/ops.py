@@ -43,9 +43,11 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
             "unet_subpixel_upsample": int(os.environ.get("MDX_UNET_SUBPIXEL_UPSAMPLE", "1")),
             # SpatialTransformer.norm (GroupNorm without an activation) applied inside proj_in (mdx_gemm_desc.gn_colstats on a dense
             # launch: one packed fma per A fragment) at levels with at least this many tokens per sample (0 = never): no GroupNorm
-            # launch, no normalised copy of the tensor.  Below ~1k tokens the GroupNorm launch doubles as the split-K reduce of the
-            # conv in front of it (unet_gn_splitk_fuse), which the fold would give back as a reduce launch.
-            "unet_gn_proj_fuse": int(os.environ.get("MDX_UNET_GN_PROJ_FUSE", "1024"))}
+            # launch, no normalised copy of the tensor.  Measured round 5 (tools/eval_ab.py, profiles/r05_gn_proj_fuse_ab.txt): at
+            # 1024, SDv2 batch 2 233 ops instead of 238 at EQUAL time (4.2824 vs 4.2825 ms: every consumer block folds the statistics
+            # before its first MFMA, which costs what the 7 us launch did), Wukong batch 16 +0.4 %, 96 x 96 batch 8 +0.5 %; at 256
+            # (the levels whose GroupNorm launch doubles as a split-K reduce) +0.5 % / +1.0 % / +1.6 %.  Off.
+            "unet_gn_proj_fuse": int(os.environ.get("MDX_UNET_GN_PROJ_FUSE", "0"))}
 
 
 def set_option(name, value):

@@ -505,9 +505,11 @@ def init_params(cfg, seed=0, zero_init=False, dtype=np.float32):
 class ModelOracle:
     """The attributes/methods PLMSSampler needs from LatentDiffusion (plms.py:31,40-46; ddpm.py:290-306)."""
 
-    def __init__(self, unet, linear_start=0.00085, linear_end=0.0120, timesteps=1000, conditioning_key="crossattn"):
+    def __init__(self, unet, linear_start=0.00085, linear_end=0.0120, timesteps=1000, conditioning_key="auto"):
+        """conditioning_key: one of DiffusionWrapper's (WK ddpm.py:358), or "auto" = what the two shipped model classes use --
+        'hybrid' when the conditioning is a dict with c_concat (LatentInpaintDiffusion), 'crossattn' otherwise."""
         self.unet = unet
-        assert conditioning_key in [None, "concat", "crossattn", "hybrid", "adm"]     # WK ddpm.py:358
+        assert conditioning_key in [None, "concat", "crossattn", "hybrid", "adm", "auto"]
         self.conditioning_key = conditioning_key
         s = register_schedule(linear_start, linear_end, timesteps)
         self.num_timesteps = s["num_timesteps"]
@@ -526,6 +528,8 @@ class ModelOracle:
         'adm' -> unet(x, t, y=c_crossattn)."""
         self.calls += 1
         key = self.conditioning_key
+        if key == "auto":
+            key = "hybrid" if isinstance(cond, dict) and cond.get("c_concat") is not None else "crossattn"
         if not isinstance(cond, dict):
             cond = {"c_concat" if key == "concat" else "c_crossattn": cond}
         c_concat, c_crossattn = cond.get("c_concat"), cond.get("c_crossattn")

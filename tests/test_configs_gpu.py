@@ -240,6 +240,35 @@ def test_config2_wukong_512_unet_batch16_and_plms():
     check("config2_wukong_512_plms5_B8_image0", got[:1], ref, rel_l2=1e-2, max_rel=2e-2)
 
 
+# --------------------------------------------------------------------------------------------- every UNet batch 1..16 at 64 x 64
+@pytest.mark.parametrize("model", ["sd2", "wukong"])
+def test_full_size_unet_every_row_of_batches_that_are_not_benchmarked(model):
+    """Round-5 regression (found by the full-size inpainting test, whose CLI default batch is 4 = UNet batch 8): the measured tile
+    table is keyed by (M, N, K, ksize), and at UNet batch 8 the 8 x 8 level shares its key with 256-row rows measured at batch 2 on
+    the 16 x 16 level; the rows 4-7 of every batch-8 evaluation were wrong (rel 0.5) while batches 2 / 4 / 6 / 12 / 16 -- the ones
+    the benchmarks and the other tests run -- were right.  Here EVERY row of UNet batches 3, 8 and 10 is compared with its own
+    batch-1 evaluation (which test_unet_gpu / the trajectory fixtures pin against the oracle): <= 4e-3, two fp16 paths."""
+    from minddiffusion_amd.configs import SD2_UNET, WUKONG_UNET
+    from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from minddiffusion_amd.weights import synthetic_unet_params_device
+    cfg, cd = (SD2_UNET, 1024) if model == "sd2" else (WUKONG_UNET, 768)
+    net = UNetModel(**dict(cfg))
+    net.use_graph = False
+    net.load_state_dict(synthetic_unet_params_device(net.parameter_shapes(), seed=0, device=DEV))
+    rng = np.random.RandomState(11)
+    for B in (3, 8, 10):
+        x = torch.tensor(rng.randn(B, 4, 64, 64).astype(np.float32), device=DEV)
+        ctx = torch.tensor(rng.randn(B, 77, cd).astype(np.float32), device=DEV)
+        t = torch.full((B,), 500.0, device=DEV)
+        full = net(x, t, ctx).clone()
+        worst = 0.0
+        for r in range(B):
+            one = net(x[r:r + 1].clone(), t[:1], ctx[r:r + 1].clone())
+            worst = max(worst, metrics_rel(full[r:r + 1], one))
+        print("PARITY", {"name": f"{model}_unet_batch{B}_worst_row_vs_batch1", "rel_l2": worst})
+        assert worst <= 4e-3, (model, B, worst)
+
+
 # --------------------------------------------------------------------------------------------- Wukong inpainting, full size
 def test_inpaint_wukong_full_size():
     """SURVEY 8(f) item 4 at full size: configs/wukong-huahua_inpaint_inference.yaml (the Wukong UNet on 9 input channels,

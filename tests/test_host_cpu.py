@@ -851,6 +851,7 @@ def test_unet_plan_fuses_the_320_channel_transformer_blocks():
     try:
         ops.set_option("unet_st_tail", 0)
         ops.set_option("unet_st_head", 0)
+        ops.set_option("unet_gn_proj_fuse", 1024)
         P1 = build()._plan(2, 64, 64)               # launch-per-op transformers, SpatialTransformer.norm folded into proj_in (round 5)
         ops.set_option("unet_gn_proj_fuse", 0)
         P0 = build()._plan(2, 64, 64)               # ... and with the GroupNorm launches of rounds 1-4
@@ -866,7 +867,13 @@ def test_unet_plan_fuses_the_320_channel_transformer_blocks():
     assert folded1 == sum(m["info"].startswith("self ") for m in P1.meta) and folded1 > blocks320
     assert kinds(P0)["groupnorm"] - kinds(P1)["groupnorm"] == folded1 and kinds(P0)["gemm"] == kinds(P1)["gemm"]
     assert len(P0.main) - len(P1.main) == folded1 and not any("+groupnorm(in)" in m["info"] for m in P0.meta)
-    assert sum("+groupnorm(in)" in m["info"] for m in P.meta) == folded1 - blocks320
+    assert not any("+groupnorm(in)" in m["info"] for m in P.meta)      # the option is off by default (measured equal-or-slower)
+    try:
+        ops.set_option("unet_gn_proj_fuse", 1024)
+        Pf = build()._plan(2, 64, 64)
+    finally:
+        ops.set_option("unet_gn_proj_fuse", pf)
+    assert sum("+groupnorm(in)" in m["info"] for m in Pf.meta) == folded1 - blocks320      # the fused heads already hold theirs
     for m in P1.meta:
         if "+groupnorm(in)" in m["info"]:
             d = m["desc"]

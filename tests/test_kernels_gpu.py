@@ -1318,3 +1318,35 @@ def test_dense_with_fused_input_groupnorm(ops, B, HW, Cin, N, rows, splitk, tile
                                  gn_beta=btd, gn_silu=0)
         with pytest.raises(MdxError):
             ops.gemm_run(bad)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(8, 8, 8, 1280, 1280), (8, 8, 8, 2560, 1280), (32, 4, 4, 1280, 1280)])
+def test_conv3x3_shape_that_shares_M_with_a_256_row_tuned_row(ops, B, H, W, Cin, Cout):
+    """Round-5 regression: the tile table is keyed by (M, N, K, ksize).  The 8 x 8 level at UNet batch 8 has M = 512, N = 1280,
+    K = 11520 / 23040 -- the key of rows measured at batch 2 on the 16 x 16 level with 256-row tiles (16 x 16-patch HALO kernel).
+    That kernel does not apply to 8 x 8 images; the row used to be taken anyway and the generic kernel ran 128-row tiles on a grid
+    sized for 256-row ones: samples 4-7 were never written.  Every output row is checked against the fp32 conv."""
+    rng = np.random.RandomState(B + Cin)
+    x = h16(rng.standard_normal((B, Cin, H, W)))
+    wt = h16(rng.standard_normal((Cout, Cin, 3, 3)) / math.sqrt(9 * Cin))
+    bv = rng.standard_normal(Cout).astype(np.float32)
+    ref = O.conv2d(torch.tensor(x), torch.tensor(wt), torch.tensor(bv))
+    xd, wd, bd = dev16(nhwc(x)), pack_conv(wt), dev32(bv)
+    out = torch.full((B * H * W, Cout), float("nan"), dtype=torch.float16, device=DEV)
+    d = ops.make_gemm_desc(xd, wd, Cout, B, H, W, Cin, out, Cout, bias=bd, ksize=3)
+    ws_ = ops.new_gemm_workspace(max(ops.gemm_workspace_bytes(d), 1 << 20), DEV)
+    d.workspace, d.workspace_bytes = ws_.data_ptr(), ws_.numel() * 4
+    q = ops.gemm_query(d)
+    assert q[0] in (64, 128), q      # never the 256-row form: these images do not tile into 16 x 16 patches
+    ops.gemm_run(d)
+    torch.cuda.synchronize()
+    got = from_nhwc(out.float().cpu().numpy(), B, H, W)
+    assert np.isfinite(got).all()
+    check(f"conv3x3_M{B * H * W}_{H}x{W}_{Cin}_{Cout}_not_256_rows", got, ref, rel_l2=1e-3)
+    for b in (0, B // 2, B - 1):      # the failure left whole samples stale: per-sample check
+        check(f"conv3x3_M{B * H * W}_{H}x{W}_{Cin}_sample{b}", got[b:b + 1], ref[b:b + 1], rel_l2=1e-3)
+    from minddiffusion_amd._lib import MdxError
+    bad = ops.make_gemm_desc(xd, wd, Cout, B, H, W, Cin, out, Cout, bias=bd, ksize=3, tile_m=256)
+    bad.workspace, bad.workspace_bytes = d.workspace, d.workspace_bytes
+    qb = ops.gemm_query(bad)
+    assert qb[0] != 256, qb          # a forced 256-row tile on a launch it does not apply to is not honoured

@@ -272,9 +272,9 @@ def test_groupnorm_folds_into_proj_in_where_the_plan_says_so():
 def _selfctx_cfg(**kw):
     """A UNet the reference's `context=None` call type-checks on: attention only where the transformer width equals context_dim
     (WK attention.py:133 `context = default(context, x)` feeds the block's own tokens to to_k / to_v = Dense(context_dim, inner))."""
-    return dict(image_size=8, in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[2], num_res_blocks=1,
-                channel_mult=[1, 2], num_head_channels=64, use_spatial_transformer=True, use_linear_in_transformer=True,
-                transformer_depth=1, context_dim=128, legacy=False, **kw)
+    return dict(dict(image_size=8, in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[2], num_res_blocks=1,
+                     channel_mult=[1, 2], num_head_channels=64, use_spatial_transformer=True, use_linear_in_transformer=True,
+                     transformer_depth=1, context_dim=128, legacy=False), **kw)
 
 
 @pytest.mark.parametrize("key", [None, "concat", "adm"])
