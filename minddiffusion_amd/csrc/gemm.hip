@@ -1113,7 +1113,8 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
         MDX_REQUIRE(p.out_mode == MDX_OUT_ROWMAJOR, "mdx_gemm_f16: GEGLU is row-major only");
     }
     if (p.out_mode == MDX_OUT_TRANSPOSED) {
-        MDX_REQUIRE(p.HoWo % 8 == 0 && p.out_ld % 8 == 0, "mdx_gemm_f16: transposed store needs tokens %% 8 == 0");
+        // (tokens per sample need not be a multiple of 8: the epilogue then stores element-wise; out_ld is the padded row length)
+        MDX_REQUIRE(p.out_ld % 8 == 0 && p.out_ld >= p.HoWo, "mdx_gemm_f16: transposed store needs out_ld %% 8 == 0 and out_ld >= tokens");
         MDX_REQUIRE(!p.rowbias && !p.residual, "mdx_gemm_f16: transposed store takes bias only");
     }
     if (p.n_split) {
@@ -1121,8 +1122,8 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
                     "mdx_gemm_f16: n_split must be a multiple of 128 inside (0, N) with out2 set");
         MDX_REQUIRE(p.out_mode == MDX_OUT_ROWMAJOR && p.epilogue == MDX_EPI_NONE && !p.rowbias && !p.residual && !p.out_bs,
                     "mdx_gemm_f16: the split row-major | transposed output takes bias only");
-        MDX_REQUIRE(p.HoWo % 8 == 0 && p.out2_ld % 8 == 0 && p.out2_ld >= p.HoWo,
-                    "mdx_gemm_f16: transposed part needs tokens %% 8 == 0 and out2_ld >= tokens");
+        MDX_REQUIRE(p.out2_ld % 8 == 0 && p.out2_ld >= p.HoWo,
+                    "mdx_gemm_f16: transposed part needs out2_ld %% 8 == 0 and out2_ld >= tokens");
     }
     if (p.ln_stats) {
         MDX_REQUIRE(p.ln_s && p.ln_nt * 64 == p.K && p.ksize == 1 && p.c2 == 0 && p.stride == 1 && !p.upsample &&

@@ -367,9 +367,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + bb);
                 }
-                const int b = m / p.HoWo;
-                const int tok = m - b * p.HoWo;
-                *reinterpret_cast<f16x8*>(p.out + ((size_t)b * p.N + n) * p.out_ld + tok) = v;
+                if ((p.HoWo & 7) == 0) {
+                    const int b = m / p.HoWo;
+                    const int tok = m - b * p.HoWo;
+                    *reinterpret_cast<f16x8*>(p.out + ((size_t)b * p.N + n) * p.out_ld + tok) = v;
+                } else {
+                    // tokens per sample not a multiple of 8 (5 x 5, 6 x 6, 7 x 7 ... images at the deepest level of a 320 / 384 / 448-
+                    // pixel run): the 8 rows of a chunk may straddle two samples or run past M -- element stores (tiny tensors)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int mm = m + e;
+                        if (mm < p.M) {
+                            const int b = mm / p.HoWo;
+                            p.out[((size_t)b * p.N + n) * p.out_ld + (mm - b * p.HoWo)] = v[e];
+                        }
+                    }
+                }
             }
         }
     } else {
@@ -460,9 +473,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     f16x8 v;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (f16)((float)stg[(mchunk * 8 + e) * SLD + nrow] + bbv);
-                    const int b = m / p.HoWo;
-                    const int tok = m - b * p.HoWo;
-                    *reinterpret_cast<f16x8*>(p.out2 + ((size_t)b * nv + (nn - p.n_split)) * p.out2_ld + tok) = v;
+                    if ((p.HoWo & 7) == 0) {
+                        const int b = m / p.HoWo;
+                        const int tok = m - b * p.HoWo;
+                        *reinterpret_cast<f16x8*>(p.out2 + ((size_t)b * nv + (nn - p.n_split)) * p.out2_ld + tok) = v;
+                    } else {      // ragged token count: element stores (see the transposed store above)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int mm = m + e;
+                            if (mm < p.M) {
+                                const int b = mm / p.HoWo;
+                                p.out2[((size_t)b * nv + (nn - p.n_split)) * p.out2_ld + (mm - b * p.HoWo)] = v[e];
+                            }
+                        }
+                    }
                 }
             }
         } else if (p.epilogue == MDX_EPI_GEGLU) {

@@ -719,6 +719,23 @@ class UNetModel:
                 A.release(skip)
             return out, ho, wo
 
+        ragged_vt = []
+
+        def vt_buffer(n, inner):
+            """V^T [B, inner, row length] for attention.  Token counts that are not a multiple of 8 (5 x 5 ... 7 x 7 images at the
+            deepest level of 320 / 384 / 448-pixel runs; the reference takes any multiple of 64 pixels) get rows padded to 8 in a
+            DEDICATED zeroed buffer: the transposed store never writes the pad, the attention kernel's 16-byte V^T loads read it
+            (times a zero probability), so it must stay finite -- an arena buffer would hand it another tensor's bytes."""
+            if n % 8 == 0:
+                return A.get((B, inner, n))
+            t_ = torch.zeros((B, inner, _round_up(n, 8)), dtype=f16, device=dev)
+            ragged_vt.append(t_)
+            return t_
+
+        def vt_release(t_):
+            if not any(t_ is r for r in ragged_vt):
+                A.release(t_)
+
         def transformer(pre, x, ch, heads, dh, h, wd):
             """SpatialTransformer.construct attention.py:237-256 + `transformer_depth` BasicTransformerBlocks :181-185
             (NHWC == tokens)."""
@@ -776,29 +793,30 @@ class UNetModel:
                 if not fold1:
                     emit(lambda ln=ln, tok=tok, t=t: ops.layernorm(tok, w[t + "norm1.g"], w[t + "norm1.b"], 1e-5, out=ln),
                          "layernorm")
-                vt = A.get((B, inner, n))
+                vt = vt_buffer(n, inner)
+                nv = vt.shape[2]        # row length of V^T: n, or n rounded up to 8 (ragged_vt)
                 if (t + "attn1.qkv.w") in w:
                     qk = A.get((B, n, 2 * inner))
                     add_gemm(main, a=tok if fold1 else ln, w=w[t + "attn1.qkv.w"], N=3 * inner, B=B, H=n, W=1, c1=inner, out=qk,
-                             out_ld=2 * inner, out2=vt, out2_ld=n, n_split=2 * inner,
+                             out_ld=2 * inner, out2=vt, out2_ld=nv, n_split=2 * inner,
                              **(consumer(t + "attn1.qkv") if fold1 else {}))
                 else:
                     qk = dense(main, ln, B, n, inner, 2 * inner, w[t + "attn1.qk.w"])
-                    dense(main, ln, B, n, inner, inner, w[t + "attn1.v.w"], out=vt, out_ld=n, out_mode=ops.OUT_TRANSPOSED)
+                    dense(main, ln, B, n, inner, inner, w[t + "attn1.v.w"], out=vt, out_ld=nv, out_mode=ops.OUT_TRANSPOSED)
                 o = ln  # reuse: ln is dead after the projections
                 attn_ws_need[0] = max(attn_ws_need[0], ops.attention_ws_bytes(B, heads, dh, n, n))
-                emit(lambda qk=qk, vt=vt, o=o: ops.attention(
+                emit(lambda qk=qk, vt=vt, o=o, nv=nv: ops.attention(
                     qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
-                    n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner, ws=P.attn_ws),
+                    n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * nv, nv, n * inner, inner, ws=P.attn_ws),
                     "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
                 rows_t = tail_rows(t, n, heads, dh)
                 if rows_t:
                     out = fused_tail(t, rows_t, o, tok, x, ch, inner, heads, dh, n)
-                    A.release(qk); A.release(vt); A.release(tok); A.release(ln)
+                    A.release(qk); vt_release(vt); A.release(tok); A.release(ln)
                     return out
                 tok2 = dense(main, o, B, n, inner, inner, w[t + "attn1.o.w"], bias=w[t + "attn1.o.b"], residual=tok,
                              stats_out=st)
-                A.release(qk); A.release(vt); A.release(tok)
+                A.release(qk); vt_release(vt); A.release(tok)
                 # --- attn2 (cross): K / V^T of the context are produced by the context plan
                 if st is None:
                     emit(lambda ln=ln, tok2=tok2, t=t: ops.layernorm(tok2, w[t + "norm2.g"], w[t + "norm2.b"], 1e-5, out=ln),
@@ -812,14 +830,15 @@ class UNetModel:
                 if _selfctx:
                     # context = default(context, x) (attention.py:133): keys / values are projections of attn2's own input
                     k2 = dense(main, ln, B, n, inner, inner, w[t + "attn2.k.w"])
-                    v2t = A.get((B, inner, n))
-                    dense(main, ln, B, n, inner, inner, w[t + "attn2.v.w"], out=v2t, out_ld=n, out_mode=ops.OUT_TRANSPOSED)
+                    v2t = vt_buffer(n, inner)
+                    nv2 = v2t.shape[2]
+                    dense(main, ln, B, n, inner, inner, w[t + "attn2.v.w"], out=v2t, out_ld=nv2, out_mode=ops.OUT_TRANSPOSED)
                     attn_ws_need[0] = max(attn_ws_need[0], ops.attention_ws_bytes(B, heads, dh, n, n))
-                    emit(lambda q2=q2, k2=k2, v2t=v2t, o=o: ops.attention(
+                    emit(lambda q2=q2, k2=k2, v2t=v2t, o=o, nv2=nv2: ops.attention(
                         q2.data_ptr(), k2.data_ptr(), v2t.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
-                        n * inner, inner, n * inner, inner, inner * n, n, n * inner, inner, ws=P.attn_ws),
+                        n * inner, inner, n * inner, inner, inner * nv2, nv2, n * inner, inner, ws=P.attn_ws),
                         "attention", 4 * B * heads * n * n * dh, 1, f"attn2-self B={B} h={heads} N={n} d={dh}")
-                    A.release(k2); A.release(v2t)
+                    A.release(k2); vt_release(v2t)
                 else:
                     kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
                     vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
@@ -1030,6 +1049,7 @@ class UNetModel:
         P.ln_stats = ln_stats
         P.arena = A   # owns the activation buffers (descriptors only hold raw device pointers)
         P.tails = tails
+        P.ragged_vt = ragged_vt     # (owned by the plan: descriptors hold raw pointers)
         P.heads_fused = heads_fused
         P.ctx_kv = ctx_kv     # the cached context K / V^T buffers: descriptors hold raw pointers only
         P.graph = None

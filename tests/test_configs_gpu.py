@@ -269,6 +269,26 @@ def test_full_size_unet_every_row_of_batches_that_are_not_benchmarked(model):
         assert worst <= 4e-3, (model, B, worst)
 
 
+def test_full_size_unet_320_pixel_latent_with_ragged_token_counts():
+    """320 x 320 pixels = a 40 x 40 latent: the reference takes any multiple of 64 pixels (txt2img.py --H / --W), and the 10 x 10 and
+    5 x 5 levels then have 100 / 25 tokens per sample -- not multiples of 8 (round 5: planning used to refuse them).  Full SDv2
+    UNet at batch 2, row 1 against the oracle, row 0 against its batch-1 evaluation."""
+    from minddiffusion_amd.configs import SD2_UNET
+    _threads()
+    net, oracle = _unet(SD2_UNET, O.SD2_UNET, 3)
+    rng = np.random.RandomState(40)
+    x = rng.randn(2, 4, 40, 40).astype(np.float32)
+    ctx = rng.randn(2, 77, 1024).astype(np.float32)
+    ts = np.full((2,), 700.0, np.float32)
+    dev = lambda a: torch.tensor(a, device=DEV)
+    got = net(dev(x), dev(ts), dev(ctx)).cpu()
+    assert len(net._plans[(2, 40, 40)].ragged_vt) > 0
+    ref = oracle(x[1:2], torch.tensor(ts[1:2]), ctx[1:2])
+    check("sd2_latent40_B2_row1_vs_oracle", got[1:2], ref, rel_l2=5e-3, max_abs=5e-2)
+    one = net(dev(x[:1]), dev(ts[:1]), dev(ctx[:1])).cpu()
+    check("sd2_latent40_B2_row0_vs_B1_hip", got[:1], one, rel_l2=4e-3, max_abs=2e-2)
+
+
 # --------------------------------------------------------------------------------------------- Wukong inpainting, full size
 def test_inpaint_wukong_full_size():
     """SURVEY 8(f) item 4 at full size: configs/wukong-huahua_inpaint_inference.yaml (the Wukong UNet on 9 input channels,

@@ -49,7 +49,10 @@ def test_tiny_unet_forward(graph):
     params = O.init_params(_oracle_cfg(cfg), seed=0)
     net = _build(cfg, params, graph)
     oracle = O.UNetOracle(_oracle_cfg(cfg), params)
-    for (B, H, W, T, t) in ((2, 8, 8, 5, 981.0), (1, 16, 16, 77, 21.0), (3, 8, 12, 9, 500.0)):
+    # (2, 12, 12) and (1, 10, 14): 36 / 35-token levels -- token counts that are not multiples of 8 (the deepest level of a
+    # 384- or 320 x 448-pixel run): V^T rows are padded in a dedicated zeroed buffer and stored element-wise (round 5)
+    for (B, H, W, T, t) in ((2, 8, 8, 5, 981.0), (1, 16, 16, 77, 21.0), (3, 8, 12, 9, 500.0), (2, 12, 12, 7, 333.0),
+                            (1, 10, 14, 11, 77.0)):
         x, ctx = _inputs(B, H, W, T, cfg["context_dim"], seed=B + H)
         ts = np.full((B,), t, np.float32)
         ref = oracle(x, torch.tensor(ts), ctx)
