@@ -110,6 +110,9 @@ class GenerativePSampleDiffusionModel:
         return torch.cat([sample, sample], 0), torch.cat([pred, pred], 0)
 
 
+_TEXT_CACHE = __import__("os").environ.get("MDX_GLIDE_TEXT_CACHE", "1") != "0"      # 0: recompute the text transformer every step (A/B)
+
+
 class DDimSampleDiffusionModel:
     """gaussian_diffusion.py:51-62: DDIM (eta = 0) step of the super-resolution model."""
 
@@ -118,14 +121,33 @@ class DDimSampleDiffusionModel:
         self.schedule = schedule
         self.shape = tuple(shape)
         self.num_timesteps = schedule.num_timesteps
+        self._text = None         # (token object, mask object, their versions / digests, device copies, epoch)
+        self._epoch = 0
+
+    @staticmethod
+    def _stamp(a):
+        """Something that changes when the array's content may have: torch tensors count their in-place writes; anything else is
+        hashed (128 ints per prompt)."""
+        if isinstance(a, torch.Tensor):
+            return ("v", a._version, tuple(a.shape))
+        import numpy as _np
+        return ("h", hash(_np.ascontiguousarray(a).tobytes()))
 
     def __call__(self, x, timesteps, token, mask, samples, is_train=False):
         dev = self.model.device
         i = int(torch.as_tensor(timesteps).reshape(-1)[0])
         P = x.shape[0]
         t = torch.full((P,), float(self.schedule.timestep_map[i]), device=dev)
-        out = self.model.forward_nhwc(x, t, torch.as_tensor(token)[:P], torch.as_tensor(mask)[:P],
-                                      low_res=samples[:P].to(dev, torch.float32).contiguous())
+        # the loop (main_funcs.py:47-69) hands the SAME token / mask objects to every one of its 27 steps: the model's text
+        # transformer then runs once per loop instead of once per step (Text2ImUNet.forward_nhwc text_epoch)
+        tx = self._text
+        if (tx is None or tx[0] is not token or tx[1] is not mask or tx[2] != (self._stamp(token), self._stamp(mask), P)):
+            self._epoch += 1
+            tx = self._text = (token, mask, (self._stamp(token), self._stamp(mask), P),
+                               torch.as_tensor(token)[:P].to(dev, torch.int32).contiguous(),
+                               torch.as_tensor(mask)[:P].to(dev, torch.int32).contiguous(), (id(self), self._epoch))
+        out = self.model.forward_nhwc(x, t, tx[3], tx[4], low_res=samples[:P].to(dev, torch.float32).contiguous(),
+                                      text_epoch=tx[5] if _TEXT_CACHE else None)
         sample, pred = torch.empty_like(x), torch.empty_like(x)
         ops.glide_step(x.contiguous(), out, None, out.shape[-1], 1.0, self.schedule.coef8(i), 1, 0.0, None, sample, pred)
         return sample, pred

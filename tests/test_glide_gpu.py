@@ -281,6 +281,33 @@ def test_tiny_superres_unet_and_ddim_loop():
     got = ddim_sample_loop(sr, (P, 3, 32, 32), torch.tensor(low, device=DEV), torch.tensor(tok), torch.tensor(mask), 27,
                            noise=torch.tensor(x * 0.997))
     check("glide_tiny_ddim_superres_loop", got, ref, rel_l2=1e-2)  # the benchmarked 27 steps; measured 3.4e-3 (round 2)
+    # round 5: the loop hands the same token objects to every step, so the text transformer (the plan's prefix) ran once, not 27
+    # times.  The cached form must be BIT-identical to recomputing it, and a changed prompt must not be served the old prefix.
+    net = sr.model
+    Pl = net._plans[(P, 32, 32)]
+    assert 0 < Pl.n_text < len(Pl.main) and all(m["text"] for m in Pl.meta[:Pl.n_text]) and not any(m["text"] for m in Pl.meta[Pl.n_text:])
+    dx, dl = torch.tensor(x, device=DEV), torch.tensor(low, device=DEV)
+    dt, dm_ = torch.tensor(tok, device=DEV), torch.tensor(mask, device=DEV)
+    t5 = torch.full((P,), 300.0, device=DEV)
+    full = net.forward_nhwc(dx, t5, dt, dm_, low_res=dl).clone()                        # no epoch: everything recomputed
+    a = net.forward_nhwc(dx, t5, dt, dm_, low_res=dl, text_epoch=("t", 1)).clone()      # new epoch: recomputed, then remembered
+    b = net.forward_nhwc(dx, t5, dt, dm_, low_res=dl, text_epoch=("t", 1)).clone()      # same epoch: prefix skipped
+    assert torch.equal(full, a) and torch.equal(a, b)
+    tok2 = tok.copy()
+    tok2[:, 3] = (tok2[:, 3] + 7) % 90 + 1
+    c = net.forward_nhwc(dx, t5, torch.tensor(tok2, device=DEV), dm_, low_res=dl, text_epoch=("t", 2)).clone()
+    assert not torch.equal(c, a)
+    ref2 = net.forward_nhwc(dx, t5, torch.tensor(tok2, device=DEV), dm_, low_res=dl).clone()
+    assert torch.equal(c, ref2)
+    # the sampler object notices an in-place change of the caller's token tensor (version counter) and a new numpy array (digest)
+    tk = torch.tensor(tok)
+    s1, _ = sr(x=dx, timesteps=torch.tensor([5]), token=tk, mask=torch.tensor(mask), samples=dl)
+    e1 = sr._epoch
+    s1b, _ = sr(x=dx, timesteps=torch.tensor([5]), token=tk, mask=sr._text[1], samples=dl)
+    assert sr._epoch == e1 and torch.equal(s1, s1b)
+    tk[:, 3] = torch.tensor(tok2[:, 3])
+    s2, _ = sr(x=dx, timesteps=torch.tensor([5]), token=tk, mask=sr._text[1], samples=dl)
+    assert sr._epoch == e1 + 1 and not torch.equal(s2, s1)
 
 
 def test_full_size_glide_base_single_step():
