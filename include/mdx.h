@@ -52,6 +52,11 @@ const char* mdx_last_error(void);
  * launch they affect, not thread safe).  The library itself reads NO environment variables.  Names:
  *   gemm_tuned (1)  gemm_bm (0 = auto)  gemm_bn (0)  gemm_ring (0 = auto, 2..5)  gemm_halo (1)  gemm_halo8 (1)
  *   gemm_splitk_fixup_max (4)  gemm_spread (1)  halo_nsb (0 = auto)  gn_min_blocks (512)  gn_fused (1)
+ *   gemm_dense_issue (1): dense launches of the generic GEMM kernel issue their K tiles with a fixed per-lane offset + a scalar K offset
+ *   gn_prefetch (1)  gemm_ln_prefetch (1): round-5 "latency diet" -- parameters that are cold in HBM (GroupNorm gamma / beta /
+ *   FiLM rows, LayerNorm-fold S[n] and row statistics) are fetched at the top of the kernel instead of behind the dependency
+ *   they used to follow; 0 restores the round-4 order for A/B runs (same results bit for bit either way)
+ *   (the full list with defaults: csrc/mdx_common.h enum MdxOpt)
  * Unknown names return MDX_E_INVALID. */
 int mdx_set_option(const char* name, int value);
 int mdx_get_option(const char* name, int* value);
@@ -463,7 +468,8 @@ int mdx_probe_l2_stream(const void* src, size_t total_bytes, unsigned bytes_per_
  * fill with phase timestamps (8 x u64 per block, 100 MHz realtime counter); NULL unregisters.  tools/gemm_trace.py */
 int mdx_probe_gemm_trace(void* buf, size_t bytes);
 /* VALU issue-rate probe (no reference counterpart; diagnostics): `iters` rounds of eight independent chains per lane of one
- * instruction kind -- 0 v_fma_f32, 1 v_exp_f32, 2 v_pk_fma_f32, 3 v_cvt_pk_f16_f32 (+ two converts back), 4 v_max3_f32 -- on
+ * instruction kind -- 0 v_fma_f32, 1 v_exp_f32, 2 v_pk_fma_f32, 3 v_cvt_pk_f16_f32 (+ two converts back), 4 v_max3_f32, 5 v_exp_f16,
+ * 6 v_pk_fma_f16, 7 v_pk_max_f16 -- on
  * `nblocks` blocks of 256 threads; time it from the host (tools/exp/r04n_valu_probe.py). */
 int mdx_probe_valu_rate(int kind, int iters, int nblocks, float* sink, mdx_stream_t s);
 

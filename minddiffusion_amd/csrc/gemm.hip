@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -151,9 +152,28 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
         b_off[j] = (unsigned)(((size_t)panel * p.kt64) * 8192 + ((row & 63) * 8 + lchk) * 16);
     }
 
+    // Dense launches (ksize 1, stride 1, no upsample, one source: every token GEMM and 1x1 conv -- two thirds of the launches of a
+    // UNet evaluation): the source offset of a K tile is the lane's row offset + kt * 128 bytes.  The lane part is fixed for the
+    // whole launch and the K part is UNIFORM, so it rides in the DMA instruction's scalar offset: issuing a K tile is AJ + BJ
+    // instructions and their m0 moves, instead of the tap / source decode (~45 scalar instructions: a division by the tap count)
+    // plus ~10 instructions per DMA.  A block that has a SIMD to itself issues one instruction per ~4 clocks, and its K step
+    // (~190 instructions at 64 x 64) was issue-bound as much as DMA-bound (round 5).
+    const bool dense = FASTK && p.ksize == 1 && p.stride == 1 && !p.upsample && p.c2 == 0 && p.dense_issue;
+    unsigned a_voff[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j)
+        a_voff[j] = (a_mask[j] & 1u) ? (unsigned)(a_pix[j] * (p.c1 * 2)) + a_cb[j] : MDX_OOB;
+
     auto stage_tile = [&](int kt, int buf) {
         char* sbase = smem + buf * STAGE;
         const int k0 = kt * BK;
+        if (dense) {
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) dma16s(rs_a, sbase + (wave * AJ + j) * 1024, a_voff[j], (unsigned)k0 * 2u);
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) dma16s(rs_w, sbase + A_BYTES + (wave * BJ + j) * 1024, b_off[j], (unsigned)kt * 8192u);
+            return;
+        }
         if constexpr (FASTK) {
             // K is ordered [cin chunk of 64][tap][64] (weights packed to match; Cin % 64 == 0, c1 % 64 == 0), so a K
             // tile lies in one tap and one source, and consecutive K tiles re-read the SAME pixels' cache lines
@@ -215,8 +235,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
             }
         }
 #pragma unroll
-        for (int j = 0; j < BJ; ++j)
-            dma16(rs_w, sbase + A_BYTES + (wave * BJ + j) * 1024, b_off[j] + (unsigned)kt * 8192);
+        for (int j = 0; j < BJ; ++j) dma16s(rs_w, sbase + A_BYTES + (wave * BJ + j) * 1024, b_off[j], (unsigned)kt * 8192u);
     };
 
     f32x16 acc[TM][TN];
@@ -241,6 +260,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
     const int nt = kt_end - kt_begin;
     float bpre[16];
     gemm_bias_prefetch<BN, SWAP, NW>(p, n0, bpre);
+    // LayerNorm-fold consumer (round 5): the epilogue opens with the tile's row statistics (BM x K / 64 {sum, sumsq} pairs, written by
+    // the previous launch on other XCDs) and S[n] (a weight-like vector, cold in HBM): 2-3 us of misses at the head of the epilogue of
+    // every q|k|v, cross-attention q and GEGLU ff1 launch, which one block per CU cannot hide.  Each thread TOUCHES one 128-byte line
+    // of them here, ahead of the prologue DMAs (older in the vmcnt order: the counted waits of the main loop cover them), so that
+    // the epilogue's own loads hit this XCD's L2.  Two VGPRs, kept live to the epilogue so that the loads are not sunk; the values
+    // are not used -- the arithmetic is the epilogue's, unchanged.
+    [[maybe_unused]] float touch_ln = 0.f, touch_s = 0.f;
+    if constexpr (SWAP) {
+        if (p.ln_stats != nullptr && p.ln_prefetch) {
+            const int rows = min(BM, p.M - m0);
+            const unsigned bytes = (unsigned)rows * (unsigned)p.ln_nt * 8u;
+            const char* base = reinterpret_cast<const char*>(p.ln_stats) + (size_t)m0 * p.ln_nt * 8;
+            // (one line per thread covers BM x K / 64 pairs up to K = 2048; beyond that the rest stays cold.  No loop, no add: a
+            // dependent instruction here would make the compiler wait for the miss in front of the prologue)
+            if ((unsigned)tid * 128u < bytes) touch_ln = *reinterpret_cast<const float*>(base + (unsigned)tid * 128u);
+            if (tid < BN / 32 && n0 + tid * 32 < p.N) touch_s = p.ln_s[n0 + tid * 32];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i)
         if (i < nt) stage_tile(kt_begin + i, i);
@@ -329,46 +366,77 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (t == 0) trace_mark(p, 2);
-        if (t + NS - 1 < nt) stage_tile(kt_begin + t + NS - 1, wr);
+        // Order inside a K tile (round 5).  A block that has its SIMDs to itself -- nearly every launch at UNet batch 2 -- runs the
+        // chain wait -> barrier -> DMA issue -> ds_read -> MFMA serially, one instruction per ~3 ns, and the ISA of round 4 showed
+        // the machine scheduler sinking every fragment read to its use: each MFMA waited for a ds_read issued right before it, KS
+        // LDS round trips per K tile with nothing to hide them.  Now (i) the fragment reads of k-step 0 -- of ALL KS k-steps on
+        // tiles with at most two MFMAs per k-step, which have nothing to hide a read behind -- are issued BEFORE the DMA
+        // instructions that refill the ring (they read stage rd, the DMAs write stage wr: no hazard beyond the barrier above), so
+        // their LDS round trip overlaps the DMA issue, and (ii) sched_barriers pin the reads where they are written.
         const char* sb = smem + rd * STAGE;
-        f16x8 af[2][TM], bf[2][TN];
+        constexpr bool ALLK = (TM * TN <= 2) && !GNA;
+        constexpr int FD = ALLK ? KS : 2;
+        static_assert(KS == 4, "64-deep K tiles");
+        f16x8 af[FD][TM], bf[FD][TN];
         [[maybe_unused]] f16x8 gna[2], gns[2];      // GNA: this lane's 8 channels' {a, s} of k-step s (channel = K index: dense launch)
         [[maybe_unused]] const int gk = (kt_begin + t) * BK + hi * 8;
+        auto rdfrag = [&](auto slot_c, const int ks) {
+            constexpr int slot = decltype(slot_c)::value;
+            const int coff = (((2 * ks + hi) ^ swz) << 4);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + ((hi ^ swz) << 4));
+            for (int i = 0; i < TM; ++i) af[slot][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + coff);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + ((hi ^ swz) << 4));
-        if constexpr (GNA) {
-            gna[0] = *reinterpret_cast<const f16x8*>(gta + gk);
-            gns[0] = *reinterpret_cast<const f16x8*>(gts + gk);
-        }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-            if (s < KS - 1) {
-                const int coff = (((2 * (s + 1) + hi) ^ swz) << 4);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f16x8*>(sb + a_row_off + i * 32 * ROWB + coff);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + coff);
-                if constexpr (GNA) {
-                    gna[nxt] = *reinterpret_cast<const f16x8*>(gta + gk + 16 * (s + 1));
-                    gns[nxt] = *reinterpret_cast<const f16x8*>(gts + gk + 16 * (s + 1));
-                }
+            for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * ROWB + coff);
+            if constexpr (GNA) {
+                gna[slot & 1] = *reinterpret_cast<const f16x8*>(gta + gk + 16 * ks);
+                gns[slot & 1] = *reinterpret_cast<const f16x8*>(gts + gk + 16 * ks);
             }
+        };
+        auto mfmas = [&](auto slot_c) {
+            constexpr int slot = decltype(slot_c)::value;
             if constexpr (GNA) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[cur][i] = af[cur][i] * gna[cur] + gns[cur];      // v_pk_fma_f16 x 4
+                for (int i = 0; i < TM; ++i) af[slot][i] = af[slot][i] * gna[slot & 1] + gns[slot & 1];      // v_pk_fma_f16 x 4
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if constexpr (SWAP)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[slot][j], af[slot][i], acc[i][j], 0, 0, 0);
                     else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[slot][i], bf[slot][j], acc[i][j], 0, 0, 0);
                 }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        const bool refill = t + NS - 1 < nt;
+        if constexpr (ALLK) {
+            using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>;
+            rdfrag(I0{}, 0); rdfrag(I1{}, 1); rdfrag(I2{}, 2); rdfrag(I3{}, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (refill) stage_tile(kt_begin + t + NS - 1, wr);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I0{}); mfmas(I1{}); mfmas(I2{}); mfmas(I3{});
+        } else {
+            rdfrag(I0{}, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (refill) stage_tile(kt_begin + t + NS - 1, wr);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks += 2) {
+                rdfrag(I1{}, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(I0{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 2 < KS) {
+                    rdfrag(I0{}, ks + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfmas(I1{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         rd = (rd + 1 == NS) ? 0 : rd + 1;
         wr = (wr + 1 == NS) ? 0 : wr + 1;
@@ -376,6 +444,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
 
     __syncthreads();  // all waves done with the ring before the epilogue reuses it
     trace_mark(p, 3);
+    if constexpr (SWAP) asm volatile("" ::"v"(touch_ln), "v"(touch_s));      // (the touches above stay loads issued up there)
     gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{m0}, n0, split, bpre, tile_m, tile_id);
     trace_mark(p, 4);
 }
@@ -511,7 +580,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     auto dma_b = [&](int kt, int stage) {
         char* sb = smem + 2 * HALO_BYTES + stage * B_BYTES;
 #pragma unroll
-        for (int j = 0; j < BJ; ++j) dma16(rs_w, sb + (wave * BJ + j) * 1024, b_off[j] + (unsigned)kt * 8192);
+        for (int j = 0; j < BJ; ++j) dma16s(rs_w, sb + (wave * BJ + j) * 1024, b_off[j], (unsigned)kt * 8192u);
     };
 
     f32x16 acc[TM][TN];
@@ -726,9 +795,8 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
             }
             __builtin_amdgcn_s_barrier();
             if (t == 0) trace_mark(p, 2);
-            if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
-            if (t + NSB - 1 < nt) dma_b(kt_begin + t + NSB - 1, wr);
-
+            // (round 5: fragment reads ahead of the DMA issue, pinned by sched_barriers -- see gemm_kernel's main loop.  The reads take
+            // halo buffer hb and ring stage rd, the DMAs write halo buffer hb ^ 1 and stage wr.)
             const int ky = tap / 3, kx = tap - ky * 3;
             const int dq = ky * HWD + kx;
             int a_row[TM], a_key[TM];
@@ -742,31 +810,60 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
                     a_key[i] = (((((l31 & 7) + kx) >> 1) & 3) | ((((l31 >> 3) + ky) & 1) << 2)) << 4;
             }
             const char* sb = smem + rd * B_BYTES;
-            f16x8 af[2][TM], bf[2][TN];
+            constexpr bool ALLK = TM * TN <= 2;      // at most two MFMAs per k-step: nothing to hide a fragment read behind
+            constexpr int FD = ALLK ? 4 : 2;
+            f16x8 af[FD][TM], bf[FD][TN];
+            auto rdfrag = [&](auto slot_c, const int ks) {
+                constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + ((hi << 4) ^ a_key[i]));
+                for (int i = 0; i < TM; ++i)
+                    af[slot][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + (((2 * ks + hi) << 4) ^ a_key[i]));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + ((hi ^ swz_b) << 4));
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int cur = s & 1, nxt = cur ^ 1;
-                if (s < 3) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        af[nxt][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + (((2 * (s + 1) + hi) << 4) ^ a_key[i]));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + (((2 * (s + 1) + hi) ^ swz_b) << 4));
-                }
+                for (int j = 0; j < TN; ++j)
+                    bf[slot][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + (((2 * ks + hi) ^ swz_b) << 4));
+            };
+            auto mfmas = [&](auto slot_c) {
+                constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         if constexpr (SWAP)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[slot][j], af[slot][i], acc[i][j], 0, 0, 0);
                         else
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[slot][i], bf[slot][j], acc[i][j], 0, 0, 0);
                     }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            if constexpr (ALLK) {
+                using I2 = std::integral_constant<int, 2>;
+                using I3 = std::integral_constant<int, 3>;
+                rdfrag(I0{}, 0); rdfrag(I1{}, 1); rdfrag(I2{}, 2); rdfrag(I3{}, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
+                if (t + NSB - 1 < nt) dma_b(kt_begin + t + NSB - 1, wr);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(I0{}); mfmas(I1{}); mfmas(I2{}); mfmas(I3{});
+            } else {
+                rdfrag(I0{}, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
+                if (t + NSB - 1 < nt) dma_b(kt_begin + t + NSB - 1, wr);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ks += 2) {
+                    rdfrag(I1{}, ks + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(I0{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks + 2 < 4) {
+                        rdfrag(I0{}, ks + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    mfmas(I1{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             rd = (rd + 1 == NSB) ? 0 : rd + 1;
             wr = (wr + 1 == NSB) ? 0 : wr + 1;
@@ -1070,6 +1167,8 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     p.colstats_out = d->colstats_out;
     p.ln_stats = d->ln_stats;
     p.ln_s = d->ln_s;
+    p.ln_prefetch = mdx_opt(MDX_OPT_GEMM_LN_PREFETCH) ? 1 : 0;
+    p.dense_issue = mdx_opt(MDX_OPT_GEMM_DENSE_ISSUE) ? 1 : 0;
     p.ln_nt = d->ln_nt;
     p.ln_eps = d->ln_eps;
     p.bn_hint = d->tile_n;

@@ -59,6 +59,8 @@ struct GemmParams {
     const f16* w_sub;
     unsigned w_sub_bytes;
     int c8_sub;      // resolved: this launch runs the sub-pixel form on the conv8p core
+    int dense_issue; // dense launches issue their K tiles through the scalar offset (option gemm_dense_issue)
+    int ln_prefetch; // LayerNorm-fold consumer: the tile's statistics partials and S[n] are touched before the K loop (option gemm_ln_prefetch)
 };
 
 }  // namespace mdx_int

@@ -75,6 +75,9 @@ enum MdxOpt {
     MDX_OPT_GN_BOOST_MB,         // column-statistics GroupNorm on tensors of at least this many MB launches four times the pixel slabs (40; 0 = never)
     MDX_OPT_ATTN_OCC3,           // 1: the D <= 64 attention kernels are built for three blocks per CU (<= 168 VGPRs) instead of two
     MDX_OPT_ATTN_KV_SPLIT,       // split-KV attention (mdx_attention_splitkv_f16 with a workspace): 0 never, 1 auto (fill the chip's block slots), >= 2 force that many splits
+    MDX_OPT_GN_PREFETCH,         // 1: the GroupNorm kernels fetch their affine parameters (and, where a thread's pixels fit its registers, the pixels) at the top of the kernel, ahead of the statistics (0 = the round-4 order: parameters after the statistics, small tensors read twice)
+    MDX_OPT_GEMM_DENSE_ISSUE,    // 1: dense launches of the generic GEMM kernel (ksize 1, stride 1, one source) keep the per-lane source offset fixed and put the K offset in the DMA instructions' scalar operand (0 = the general tap / source decode per K tile)
+    MDX_OPT_GEMM_LN_PREFETCH,    // 1: LayerNorm-fold consumers (mdx_gemm_desc.ln_stats) fetch their rows' statistics partials and S[n] before the K loop (0 = at the head of the epilogue)
     MDX_OPT_COUNT
 };
 int mdx_opt(int id);
@@ -123,6 +126,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // destination = wave-uniform `lds` + lane*16.
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_uniform, unsigned voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MDX_LDS_PTR(lds_wave_uniform), 16, voff, 0, 0, 0);
+}
+
+// The same with a wave-uniform byte offset in the instruction's SCALAR offset operand: `voff` can then stay fixed across the K loop
+// and the issue costs no per-lane arithmetic.
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_uniform, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, MDX_LDS_PTR(lds_wave_uniform), 16, voff, soff, 0, 0);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {

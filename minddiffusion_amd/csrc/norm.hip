@@ -40,6 +40,10 @@ struct GnParams {
     const float* cs1;
     const float* cs2;
     int nrb1, nrb2;
+    // latency diet (round 5; library option gn_prefetch): the affine parameters (gamma / beta / FiLM rows: cold in HBM, 1.7 GB of
+    // weights stream through the caches between two uses) and the first batch of pixels are fetched at the TOP of the kernel,
+    // so that their misses overlap the statistics' round trips instead of following them.  Same arithmetic, same bits.
+    int pre;
 };
 
 __device__ __forceinline__ f16x8 gn_load(const GnParams& p, int b, int pix, int col) {
@@ -147,6 +151,33 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
     const int tid = threadIdx.x;
     const int ng = chs / p.cpg;
     const int g0 = col0 * 8 / p.cpg;
+    const int p0 = blockIdx.x * p.pix;
+    const int p1 = min(p.HW, p0 + p.pix);
+    const int trows = 256 / cols;
+    const int tc = tid % cols, tr = tid / cols;
+    // (p.pre) this thread's channels' affine parameters (chs <= 512: two per thread) and its first four pixels, in flight
+    // while the statistics are folded below
+    float pg[2] = {0.f, 0.f}, pb[2] = {0.f, 0.f}, pm[2] = {0.f, 0.f}, pf[2] = {0.f, 0.f};
+    f16x8 v0[4];
+    if (p.pre) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * 256;
+            if (c < chs) {
+                pg[i] = p.gamma[col0 * 8 + c];
+                pb[i] = p.beta[col0 * 8 + c];
+                if (p.scale) {
+                    pm[i] = p.scale[(size_t)b * p.mod_ld + col0 * 8 + c];
+                    pf[i] = p.shift[(size_t)b * p.mod_ld + col0 * 8 + c];
+                }
+            }
+        }
+        if (tr < trows) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (p0 + tr + u * trows < p1) v0[u] = gn_load(p, b, p0 + tr + u * trows, col0 + tc);
+        }
+    }
     if (p.cs1) {
         // statistics = the producers' per-column {sum, sumsq} of every row block of this sample, folded per channel (fixed
         // order), then per group: no pass over the tensor.  The channel concat keeps its two sources' partial arrays apart.
@@ -228,23 +259,38 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
         }
     }
     __syncthreads();
-    for (int c = tid; c < chs; c += 256) {
-        const int g = c / p.cpg;
-        float a = p.gamma[col0 * 8 + c] * gstat[g * 2 + 1];
-        float sh = p.beta[col0 * 8 + c] - gstat[g * 2] * a;
-        if (p.scale) {   // (x_hat*gamma + beta) * (1 + scale) + shift
-            const float m1 = 1.0f + p.scale[(size_t)b * p.mod_ld + col0 * 8 + c];
-            a *= m1;
-            sh = sh * m1 + p.shift[(size_t)b * p.mod_ld + col0 * 8 + c];
+    if (p.pre) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * 256;
+            if (c < chs) {
+                const int g = c / p.cpg;
+                float a = pg[i] * gstat[g * 2 + 1];
+                float sh = pb[i] - gstat[g * 2] * a;
+                if (p.scale) {   // (x_hat*gamma + beta) * (1 + scale) + shift
+                    const float m1 = 1.0f + pm[i];
+                    a *= m1;
+                    sh = sh * m1 + pf[i];
+                }
+                ss[c * 2] = a;
+                ss[c * 2 + 1] = sh;
+            }
         }
-        ss[c * 2] = a;
-        ss[c * 2 + 1] = sh;
+    } else {
+        for (int c = tid; c < chs; c += 256) {
+            const int g = c / p.cpg;
+            float a = p.gamma[col0 * 8 + c] * gstat[g * 2 + 1];
+            float sh = p.beta[col0 * 8 + c] - gstat[g * 2] * a;
+            if (p.scale) {   // (x_hat*gamma + beta) * (1 + scale) + shift
+                const float m1 = 1.0f + p.scale[(size_t)b * p.mod_ld + col0 * 8 + c];
+                a *= m1;
+                sh = sh * m1 + p.shift[(size_t)b * p.mod_ld + col0 * 8 + c];
+            }
+            ss[c * 2] = a;
+            ss[c * 2 + 1] = sh;
+        }
     }
     __syncthreads();
-    const int p0 = blockIdx.x * p.pix;
-    const int p1 = min(p.HW, p0 + p.pix);
-    const int trows = 256 / cols;
-    const int tc = tid % cols, tr = tid / cols;
     if (tr >= trows) return;
     float sc[8], sh[8];
 #pragma unroll
@@ -253,6 +299,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
         sh[e] = ss[(tc * 8 + e) * 2 + 1];
     }
     int pix = p0 + tr;
+    if (p.pre) {      // the batch fetched at the top
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (pix + u * trows < p1) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (float)v0[u][e] * sc[e] + sh[e];
+                    if (p.silu) f = silu_f(f);
+                    o[e] = (f16)f;
+                }
+                *reinterpret_cast<f16x8*>(p.y + ((size_t)b * p.HW + pix + u * trows) * p.C + (col0 + tc) * 8) = o;
+            }
+        }
+        pix += 4 * trows;
+    }
     for (; pix + 3 * trows < p1; pix += 4 * trows) {
         f16x8 v[4];
 #pragma unroll
@@ -347,7 +409,11 @@ __device__ __forceinline__ f16x8 gn_slab_load(const MdxSplitInfo& sp, int b, int
 
 // NT = threads per block: 1024, or 256 for launches whose (column block, sample) grid fills the chip on its own (UNet batch >= 8:
 // 512+ blocks) -- a quarter of the threads per barrier, four times the blocks per CU.
-template <bool SLAB, int NT = GNF_THREADS>
+// KEEPN > 0 (tensor input, round 5): every thread owns at most KEEPN pixels (checked on the host), loads them ONCE with all loads
+// in flight together and keeps them in registers for the second pass, like the SLAB form: the launch is one round trip of
+// loads instead of two.  The additions run in the same pixel order as the two-pass loops: same bits.
+constexpr int GNF_KEEPN = 6;      // (gn_fused applies up to HW * L * 16 <= 64 KiB: at most 5 pixels per thread)
+template <bool SLAB, int NT = GNF_THREADS, int KEEPN = 0>
 __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnParams p, const MdxSplitInfo sp) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [trows][chs][2] partials, then the folds
     const int b = blockIdx.y, cb = blockIdx.x;
@@ -358,12 +424,39 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnParams p, const Md
     const int trows = NT / cols;
     const int tc = tid % cols, tr = tid / cols;
     const bool active = tr < trows;
-    f16x8 keep[SLAB ? GNF_KEEP : 1];
+    constexpr int KN = SLAB ? GNF_KEEP : (KEEPN > 0 ? KEEPN : 1);
+    f16x8 keep[KN];
+    // (p.pre) this thread's channel's affine parameters (chs <= min(512, NT): one per thread), fetched first: see GnParams.pre
+    float pg = 0.f, pb = 0.f, pm = 0.f, pf = 0.f;
+    if (p.pre && tid < chs) {
+        pg = p.gamma[col0 * 8 + tid];
+        pb = p.beta[col0 * 8 + tid];
+        if (p.scale) {
+            pm = p.scale[(size_t)b * p.mod_ld + col0 * 8 + tid];
+            pf = p.shift[(size_t)b * p.mod_ld + col0 * 8 + tid];
+        }
+    }
     if (active) {
         float s[8], q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
         int pix = tr;
+        if constexpr (!SLAB && KEEPN > 0) {
+#pragma unroll
+            for (int k = 0; k < KEEPN; ++k)
+                if (tr + k * trows < p.HW) keep[k] = gn_load(p, b, tr + k * trows, col0 + tc);
+#pragma unroll
+            for (int k = 0; k < KEEPN; ++k)
+                if (tr + k * trows < p.HW) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = (float)keep[k][e];
+                        s[e] += f;
+                        q[e] += f * f;
+                    }
+                }
+            pix = p.HW;      // nothing left for the loops below
+        }
         if constexpr (SLAB) {
 #pragma unroll
             for (int k = 0; k < GNF_KEEP; ++k) {
@@ -476,17 +569,32 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnParams p, const Md
         }
     }
     __syncthreads();
-    for (int c = tid; c < chs; c += NT) {
-        const int g = c / p.cpg;
-        float a = p.gamma[col0 * 8 + c] * gstat[g * 2 + 1];
-        float sh = p.beta[col0 * 8 + c] - gstat[g * 2] * a;
-        if (p.scale) {   // (x_hat*gamma + beta) * (1 + scale) + shift
-            const float m1 = 1.0f + p.scale[(size_t)b * p.mod_ld + col0 * 8 + c];
-            a *= m1;
-            sh = sh * m1 + p.shift[(size_t)b * p.mod_ld + col0 * 8 + c];
+    if (p.pre) {
+        if (tid < chs) {
+            const int g = tid / p.cpg;
+            float a = pg * gstat[g * 2 + 1];
+            float sh = pb - gstat[g * 2] * a;
+            if (p.scale) {   // (x_hat*gamma + beta) * (1 + scale) + shift
+                const float m1 = 1.0f + pm;
+                a *= m1;
+                sh = sh * m1 + pf;
+            }
+            ss[tid * 2] = a;
+            ss[tid * 2 + 1] = sh;
         }
-        ss[c * 2] = a;
-        ss[c * 2 + 1] = sh;
+    } else {
+        for (int c = tid; c < chs; c += NT) {
+            const int g = c / p.cpg;
+            float a = p.gamma[col0 * 8 + c] * gstat[g * 2 + 1];
+            float sh = p.beta[col0 * 8 + c] - gstat[g * 2] * a;
+            if (p.scale) {   // (x_hat*gamma + beta) * (1 + scale) + shift
+                const float m1 = 1.0f + p.scale[(size_t)b * p.mod_ld + col0 * 8 + c];
+                a *= m1;
+                sh = sh * m1 + p.shift[(size_t)b * p.mod_ld + col0 * 8 + c];
+            }
+            ss[c * 2] = a;
+            ss[c * 2 + 1] = sh;
+        }
     }
     __syncthreads();
     if (!active) return;
@@ -506,9 +614,9 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnParams p, const Md
         }
         *reinterpret_cast<f16x8*>(p.y + ((size_t)b * p.HW + pix) * p.C + (col0 + tc) * 8) = o;
     };
-    if constexpr (SLAB) {
+    if constexpr (SLAB || KEEPN > 0) {
 #pragma unroll
-        for (int k = 0; k < GNF_KEEP; ++k)
+        for (int k = 0; k < KN; ++k)
             if (tr + k * trows < p.HW) apply(keep[k], tr + k * trows);
         return;
     }
@@ -663,6 +771,7 @@ static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const 
     p.cs2 = cs2;
     p.nrb1 = nrb1;
     p.nrb2 = nrb2;
+    p.pre = mdx_opt(MDX_OPT_GN_PREFETCH) ? 1 : 0;
     hipStream_t st = (hipStream_t)s;
     if (cs1) {
         // one launch: gn_apply with its statistics folded from the producers' column partials.  Minimal column blocks
@@ -730,6 +839,18 @@ static int groupnorm_impl(const void* x1, int C1, const void* x2, int C2, const 
                 }
                 hipLaunchKernelGGL((gn_fused_kernel<false, 256>), dim3(p.ncb, B), dim3(256), lds4, st, p, MdxSplitInfo{});
                 MDX_LAUNCH_CHECK("mdx_groupnorm_f16(fused, 256 threads)");
+                return MDX_OK;
+            }
+            // every thread's pixels fit its registers (HW <= 8 rows of threads: the 8 x 8 ... 32 x 32 levels): one pass of loads
+            if (p.pre && (HW + GNF_THREADS / p.cw - 1) / (GNF_THREADS / p.cw) <= GNF_KEEPN) {
+                static MdxPerDeviceOnce attrk_once;
+                if (attrk_once.first()) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<false, GNF_THREADS, GNF_KEEPN>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                }
+                hipLaunchKernelGGL((gn_fused_kernel<false, GNF_THREADS, GNF_KEEPN>), dim3(p.ncb, B), dim3(GNF_THREADS), lds, st, p,
+                                   MdxSplitInfo{});
+                MDX_LAUNCH_CHECK("mdx_groupnorm_f16(fused, one pass)");
                 return MDX_OK;
             }
             static MdxPerDeviceOnce attr_once;
@@ -803,6 +924,7 @@ extern "C" int mdx_groupnorm_from_splitk_f16(const mdx_gemm_desc* prod, const fl
     p.y = (f16*)y;
     p.eps = eps;
     p.silu = silu;
+    p.pre = mdx_opt(MDX_OPT_GN_PREFETCH) ? 1 : 0;
     constexpr size_t lds = ((size_t)GNF_THREADS * 8 * 2 + (size_t)GNF_FOLD * 512 * 2 + 512 * 2 + 64 * 2 + 512 * 2) * sizeof(float);
     static MdxPerDeviceOnce attr_once;
     if (attr_once.first()) {

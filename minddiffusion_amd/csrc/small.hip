@@ -20,8 +20,9 @@ extern "C" const char* mdx_last_error(void) { return g_err; }
 static const char* const g_opt_names[MDX_OPT_COUNT] = {"gemm_tuned", "gemm_bm", "gemm_bn", "gemm_ring", "gemm_halo", "gemm_halo8",
                                                         "gemm_splitk_fixup_max", "gemm_spread", "halo_nsb", "gn_min_blocks",
                                                         "gn_fused", "gn_col_chunks", "gemm_conv8p", "gemm_conv8p_min_m", "gemm_subpixel_min_tiles", "gemm_conv8p_var", "attn8", "attn8_min_blocks",
-                                                        "gn_wide_rows", "gn_fused_small", "gn_boost_mb", "attn_occ3", "attn_kv_split"};
-static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1, 4, 1, 4096, 32, 0, 0, 192, 0, 0, 40, 1, 1};
+                                                        "gn_wide_rows", "gn_fused_small", "gn_boost_mb", "attn_occ3", "attn_kv_split",
+                                                        "gn_prefetch", "gemm_dense_issue", "gemm_ln_prefetch"};
+static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1, 4, 1, 4096, 32, 0, 0, 192, 0, 0, 40, 1, 1, 1, 1, 1};
 
 int mdx_opt(int id) { return g_opt[id]; }
 
@@ -456,7 +457,8 @@ extern "C" int mdx_probe_l2_stream(const void* src, size_t total_bytes, unsigned
 
 // ------------------------------------------------------------------ VALU issue-rate probe (tools/exp/r04n_valu_probe.py)
 namespace {
-// kind 0: v_fma_f32, 1: v_exp_f32, 2: v_pk_fma_f32 (two results), 3: v_cvt_pk_f16_f32, 4: v_max3_f32 -- eight independent chains per lane
+// kind 0: v_fma_f32, 1: v_exp_f32, 2: v_pk_fma_f32 (two results), 3: v_cvt_pk_f16_f32, 4: v_max3_f32, 5: v_exp_f16, 6: v_pk_fma_f16 (two
+// results), 7: v_pk_max_f16 (two results) -- eight independent chains per lane
 template <int KIND>
 __global__ __launch_bounds__(256) void valu_probe_kernel(int iters, float* sink) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -468,6 +470,11 @@ __global__ __launch_bounds__(256) void valu_probe_kernel(int iters, float* sink)
         y[i] = f32x2{x[i], -x[i]};
     }
     const f32x2 c2 = {0.999f, 1.001f}, d2 = {1e-6f, -1e-6f};
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    h2v hx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hx[i] = h2v{(_Float16)x[i], (_Float16)(-x[i])};
+    const h2v hc = {(_Float16)0.999f, (_Float16)1.001f}, hd = {(_Float16)1e-3f, (_Float16)-1e-3f};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -478,24 +485,35 @@ __global__ __launch_bounds__(256) void valu_probe_kernel(int iters, float* sink)
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                 const h2 h = {(_Float16)x[i], (_Float16)x[(i + 1) & 7]};
                 x[i] = (float)h[0] + (float)h[1];
-            } else x[i] = __builtin_fmaxf(__builtin_fmaxf(x[i], x[(i + 1) & 7]), x[(i + 2) & 7]) * 0.5f;
+            } else if (KIND == 4) x[i] = __builtin_fmaxf(__builtin_fmaxf(x[i], x[(i + 1) & 7]), x[(i + 2) & 7]) * 0.5f;
+            else if (KIND == 5) {      // v_exp_f16: is a half-precision exponential cheaper than v_exp_f32?  (round 5, attention softmax)
+                _Float16 r;
+                asm volatile("v_exp_f16 %0, %1" : "=v"(r) : "v"(hx[i][0]));
+                hx[i][0] = r;
+            } else if (KIND == 6) hx[i] = __builtin_elementwise_fma(hx[i], hc, hd);      // v_pk_fma_f16 (two results)
+            else {                     // 7: v_pk_max_f16 (two results) -- the row-maximum fold on packed halves
+                hx[i] = __builtin_elementwise_max(hx[i], hx[(i + 1) & 7]);
+            }
         }
     }
     float a = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a += x[i] + y[i].x + y[i].y;
+    for (int i = 0; i < 8; ++i) a += x[i] + y[i].x + y[i].y + (float)hx[i][0] + (float)hx[i][1];
     if (a == 123.456f) sink[0] = a;
 }
 }  // namespace
 
 extern "C" int mdx_probe_valu_rate(int kind, int iters, int nblocks, float* sink, mdx_stream_t s) {
-    MDX_REQUIRE(sink && iters > 0 && nblocks > 0 && kind >= 0 && kind <= 4, "mdx_probe_valu_rate: bad arguments");
+    MDX_REQUIRE(sink && iters > 0 && nblocks > 0 && kind >= 0 && kind <= 7, "mdx_probe_valu_rate: bad arguments");
     hipStream_t st = (hipStream_t)s;
     switch (kind) {
         case 0: hipLaunchKernelGGL(valu_probe_kernel<0>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
         case 1: hipLaunchKernelGGL(valu_probe_kernel<1>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
         case 2: hipLaunchKernelGGL(valu_probe_kernel<2>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
         case 3: hipLaunchKernelGGL(valu_probe_kernel<3>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 5: hipLaunchKernelGGL(valu_probe_kernel<5>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 6: hipLaunchKernelGGL(valu_probe_kernel<6>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 7: hipLaunchKernelGGL(valu_probe_kernel<7>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
         default: hipLaunchKernelGGL(valu_probe_kernel<4>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
     }
     MDX_LAUNCH_CHECK("mdx_probe_valu_rate");
