@@ -16,7 +16,7 @@ timeout 300 python -m pytest tests/test_unet_gpu.py -m gpu -q -x --durations=6 \
     -k "tiny_unet_forward or constructor_variants or sd2_full_size_single_step or wukong_full_size_single_step or sd2_768_single_step" > $OUT/pytest_unet.log 2>&1
 tail -12 $OUT/pytest_unet.log; stamp unet tests
 
-for rep in 1 2; do
+for rep in 1; do
   MDX_LIBRARY=$BASE timeout 200 python tools/eval_ab.py --model sd2 --batch 2 --latent 64 --rounds 5 --iters 20 --arms "r4lib:" 2>&1 | grep -v amdgpu.ids | tee -a $OUT/ab_sd2_b2.txt
   timeout 300 python tools/eval_ab.py --model sd2 --batch 2 --latent 64 --rounds 5 --iters 20 \
       --arms "new:" "dense0:gemm_dense_issue=0" "gnpre0:gn_prefetch=0" "lnpre0:gemm_ln_prefetch=0" "allopt0:gemm_dense_issue=0,gn_prefetch=0,gemm_ln_prefetch=0" 2>&1 | grep -v amdgpu.ids | tee -a $OUT/ab_sd2_b2.txt
