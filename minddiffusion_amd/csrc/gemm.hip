@@ -25,6 +25,12 @@
 #include "mdx_common.h"
 #include "gemm_internal.h"
 
+// experiment switch (round 5): 1 = fragment reads of a tap pinned with sched_barriers (all four k-steps up front on tiles with
+// <= 2 MFMAs per k-step), 0 = the round-4 loop (reads left to the machine scheduler)
+#ifndef MDX_HALO_LOOP
+#define MDX_HALO_LOOP 1
+#endif
+
 #include <stdlib.h>
 
 #include <algorithm>
@@ -411,18 +417,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         const bool refill = t + NS - 1 < nt;
+        if (refill) stage_tile(kt_begin + t + NS - 1, wr);
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (ALLK) {
             using I2 = std::integral_constant<int, 2>;
             using I3 = std::integral_constant<int, 3>;
             rdfrag(I0{}, 0); rdfrag(I1{}, 1); rdfrag(I2{}, 2); rdfrag(I3{}, 3);
             __builtin_amdgcn_sched_barrier(0);
-            if (refill) stage_tile(kt_begin + t + NS - 1, wr);
-            __builtin_amdgcn_sched_barrier(0);
             mfmas(I0{}); mfmas(I1{}); mfmas(I2{}); mfmas(I3{});
         } else {
             rdfrag(I0{}, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (refill) stage_tile(kt_begin + t + NS - 1, wr);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS; ks += 2) {
@@ -781,6 +785,9 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     for (int c = c_begin; c < c_end; ++c) {
         const int hb = (c - c_begin) & 1;
         const bool more = c + 1 < c_end;
+#if MDX_HALO_LOOP
+#pragma unroll      // (the pinned form is not unrolled on the compiler's own judgement; the tap decode is nine constants only when it is)
+#endif
         for (int tap = 0; tap < 9; ++tap, ++t) {
             // weight tiles t .. t+NSB-2 (and at most one halo slice, older than tile t+1) are outstanding
             if (NSB >= 3 && t + 1 < nt)
@@ -795,8 +802,12 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
             }
             __builtin_amdgcn_s_barrier();
             if (t == 0) trace_mark(p, 2);
-            // (round 5: fragment reads ahead of the DMA issue, pinned by sched_barriers -- see gemm_kernel's main loop.  The reads take
-            // halo buffer hb and ring stage rd, the DMAs write halo buffer hb ^ 1 and stage wr.)
+            // (round 5: DMA issue first -- the weight stream is latency x ring-depth bound, every instruction in front of the issue is
+            // added to the chain: measured +10...35 % with the fragment reads in front -- then the fragment reads, pinned by
+            // sched_barriers: see gemm_kernel's main loop)
+            if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
+            if (t + NSB - 1 < nt) dma_b(kt_begin + t + NSB - 1, wr);
+            __builtin_amdgcn_sched_barrier(0);
             const int ky = tap / 3, kx = tap - ky * 3;
             const int dq = ky * HWD + kx;
             int a_row[TM], a_key[TM];
@@ -810,6 +821,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
                     a_key[i] = (((((l31 & 7) + kx) >> 1) & 3) | ((((l31 >> 3) + ky) & 1) << 2)) << 4;
             }
             const char* sb = smem + rd * B_BYTES;
+#if MDX_HALO_LOOP
             constexpr bool ALLK = TM * TN <= 2;      // at most two MFMAs per k-step: nothing to hide a fragment read behind
             constexpr int FD = ALLK ? 4 : 2;
             f16x8 af[FD][TM], bf[FD][TN];
@@ -841,15 +853,9 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
                 using I3 = std::integral_constant<int, 3>;
                 rdfrag(I0{}, 0); rdfrag(I1{}, 1); rdfrag(I2{}, 2); rdfrag(I3{}, 3);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
-                if (t + NSB - 1 < nt) dma_b(kt_begin + t + NSB - 1, wr);
-                __builtin_amdgcn_sched_barrier(0);
                 mfmas(I0{}); mfmas(I1{}); mfmas(I2{}); mfmas(I3{});
             } else {
                 rdfrag(I0{}, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
-                if (t + NSB - 1 < nt) dma_b(kt_begin + t + NSB - 1, wr);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < 4; ks += 2) {
@@ -865,6 +871,34 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#else
+            f16x8 af[2][TM], bf[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + ((hi << 4) ^ a_key[i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + ((hi ^ swz_b) << 4));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                if (s < 3) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        af[nxt][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + (((2 * (s + 1) + hi) << 4) ^ a_key[i]));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + (((2 * (s + 1) + hi) ^ swz_b) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (SWAP)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                    }
+            }
+#endif
             rd = (rd + 1 == NSB) ? 0 : rd + 1;
             wr = (wr + 1 == NSB) ? 0 : wr + 1;
         }
