@@ -789,8 +789,12 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
 #pragma unroll      // (the pinned form is not unrolled on the compiler's own judgement; the tap decode is nine constants only when it is)
 #endif
         for (int tap = 0; tap < 9; ++tap, ++t) {
-            // weight tiles t .. t+NSB-2 (and at most one halo slice, older than tile t+1) are outstanding
-            if (NSB >= 3 && t + 1 < nt)
+            // weight tiles t .. t+NSB-2 (and at most one halo slice per tap, each older than the weight tile issued with it) are
+            // outstanding: all but the youngest (tiles ahead) x BJ instructions must have landed -- that covers tile t and, with a
+            // four-stage ring, one instruction of tile t+1 when a halo slice sits between the two (conservative, never short)
+            if (NSB >= 4 && t + 2 < nt)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * BJ) : "memory");
+            else if (NSB >= 3 && t + 1 < nt)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BJ) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1581,7 +1585,9 @@ void launch_halo_bdir_w4(const GemmParams& p, dim3 grid, hipStream_t st) {
 
 template <int BM, int BN, int PW = 16>
 void launch_halo_cfg(const GemmParams& p, int nsb, bool swap, dim3 grid, hipStream_t st) {
-    if (nsb == 3) {
+    if (nsb == 4) {      // (round 5) the weight stream of a lone block is latency x tiles-in-flight bound: a fourth stage
+        if (swap) launch_halo<BM, BN, 4, true, PW>(p, grid, st); else launch_halo<BM, BN, 4, false, PW>(p, grid, st);
+    } else if (nsb == 3) {
         if (swap) launch_halo<BM, BN, 3, true, PW>(p, grid, st); else launch_halo<BM, BN, 3, false, PW>(p, grid, st);
     } else {
         if (swap) launch_halo<BM, BN, 2, true, PW>(p, grid, st); else launch_halo<BM, BN, 2, false, PW>(p, grid, st);
@@ -2015,8 +2021,8 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         // -5...-25 % against two stages at the UNet shapes, batch 2 and 16) and for 256-pixel patches, which own the CU; 128 x 128
         // tiles keep two (a third stage would evict the second block)
         int nsb = (c.bm == 256 || bn == 64) ? 3 : 2;
-        if (st_req == 2 || st_req == 3) nsb = st_req;
-        if (mdx_opt(MDX_OPT_HALO_NSB) >= 2 && mdx_opt(MDX_OPT_HALO_NSB) <= 3) nsb = mdx_opt(MDX_OPT_HALO_NSB);
+        if (st_req >= 2 && st_req <= 4) nsb = st_req;
+        if (mdx_opt(MDX_OPT_HALO_NSB) >= 2 && mdx_opt(MDX_OPT_HALO_NSB) <= 4) nsb = mdx_opt(MDX_OPT_HALO_NSB);
         if (d->w_frag) {
             MDX_REQUIRE(c.bm == 128, "mdx_gemm_f16: fragment-major weights run on 128-row HALO tiles only (got tile_m %d)", c.bm);
             // 128-column tiles whose split-K partials go to slabs (no in-kernel reduce): waves side by side along N

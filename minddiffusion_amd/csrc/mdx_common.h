@@ -60,7 +60,7 @@ enum MdxOpt {
     MDX_OPT_GEMM_HALO8,          // 1: 8x8 images may use the two-sample HALO tile
     MDX_OPT_GEMM_SPLITK_FIXUP_MAX,   // split-K launches of at most this many splits reduce in the kernel (4)
     MDX_OPT_GEMM_SPREAD,         // 1: single-M-tile launches deal (tile, split) items round-robin to the XCDs
-    MDX_OPT_HALO_NSB,            // 0 = auto | 2 | 3: weight ring depth of the HALO kernel
+    MDX_OPT_HALO_NSB,            // 0 = auto | 2 | 3 | 4: weight ring depth of the HALO kernel
     MDX_OPT_GN_MIN_BLOCKS,       // GroupNorm: narrow the column blocks until the grid has this many blocks (512)
     MDX_OPT_GN_FUSED,            // 1: small tensors use the one-launch GroupNorm
     MDX_OPT_GN_COL_CHUNKS,       // column-statistics GroupNorm: a column block spans at least this many 16-byte chunks of a pixel row (4)

@@ -144,7 +144,7 @@ def main():
                         continue
                     # depth of the LDS ring; 10 | 11 = the same depths with eight waves per block (generic 128-row tiles)
                     generic = not halo and not (halo8 and bm == 128)
-                    for st in (((2, 3, 4, 10, 11) if bm == 128 else (2, 3, 4, 5, 6)) if generic else (2, 3)):
+                    for st in (((2, 3, 4, 10, 11) if bm == 128 else (2, 3, 4, 5, 6)) if generic else (2, 3, 4)):
                         try:
                             t = time_desc(ops, cand(bm, ns, bn, st), flush, args.reps, pre)
                         except Exception as e:      # unsupported combination
