@@ -52,6 +52,7 @@ const char* mdx_last_error(void);
  * launch they affect, not thread safe).  The library itself reads NO environment variables.  Names:
  *   gemm_tuned (1)  gemm_bm (0 = auto)  gemm_bn (0)  gemm_ring (0 = auto, 2..5)  gemm_halo (1)  gemm_halo8 (1)
  *   gemm_splitk_fixup_max (4)  gemm_spread (1)  halo_nsb (0 = auto)  gn_min_blocks (512)  gn_fused (1)
+ *   attn_fast_stage (1): the attention kernel issues full KV tiles with fixed per-lane offsets + a scalar tile offset
  *   gemm_dense_issue (1): dense launches of the generic GEMM kernel issue their K tiles with a fixed per-lane offset + a scalar K offset
  *   gn_prefetch (1)  gemm_ln_prefetch (1): round-5 "latency diet" -- parameters that are cold in HBM (GroupNorm gamma / beta /
  *   FiLM rows, LayerNorm-fold S[n] and row statistics) are fetched at the top of the kernel instead of behind the dependency

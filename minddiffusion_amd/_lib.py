@@ -145,7 +145,7 @@ _ENV_OPTIONS = {
     "MDX_GEMM_SUBPIXEL_MIN_TILES": ("gemm_subpixel_min_tiles", int), "MDX_GEMM_CONV8P_VAR": ("gemm_conv8p_var", int),
     "MDX_ATTN8": ("attn8", int), "MDX_ATTN8_MIN_BLOCKS": ("attn8_min_blocks", int),
     "MDX_GN_WIDE_ROWS": ("gn_wide_rows", int), "MDX_GN_BOOST_MB": ("gn_boost_mb", int), "MDX_ATTN_OCC3": ("attn_occ3", int), "MDX_ATTN_KV_SPLIT": ("attn_kv_split", int),
-    "MDX_GN_PREFETCH": ("gn_prefetch", int), "MDX_GEMM_LN_PREFETCH": ("gemm_ln_prefetch", int),
+    "MDX_ATTN_FAST_STAGE": ("attn_fast_stage", int), "MDX_GN_PREFETCH": ("gn_prefetch", int), "MDX_GEMM_LN_PREFETCH": ("gemm_ln_prefetch", int),
     "MDX_GEMM_DENSE_ISSUE": ("gemm_dense_issue", int),
 }
 

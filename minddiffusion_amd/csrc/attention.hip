@@ -40,6 +40,7 @@ struct AttnParams {
     int nsplit, qblocks;
     char* ws_part;               // [item][split]{ fp16 O~[128][D], float2 {m * scale_log2, l}[128] }
     unsigned* tickets;           // [item] arrival counters: zero on entry, left zero
+    int fast_stage;              // full KV tiles are issued with fixed per-lane offsets + a scalar tile offset (option attn_fast_stage)
 };
 
 constexpr int BQ = 128;
@@ -52,6 +53,7 @@ constexpr int ATTN_MAX_SPLITS_K = 8;      // most KV splits of one item (mdx_att
 // two co-resident waves ~2200 per pair (tools/attn_bench.py), so the SIMD still has issue slots to give.
 template <int D, int OCC>
 __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
+    mdx_kernarg_touch<sizeof(AttnParams)>();
     static_assert(D % 8 == 0 && D <= 160, "head dim must be a multiple of 8, <= 160");
     constexpr int KS = (D + 15) / 16;          // k-steps of QK^T (contraction over d, zero-padded to 16)
     constexpr int DT = (D + 31) / 32;          // 32-row d tiles of O^T
@@ -126,6 +128,44 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
                 dma16(rs_v, sb + K_BYTES + inst * 1024, off);
             }
         }
+    };
+    // FULL tiles (every key of the tile exists: all but a ragged last one) -- round 5: the per-lane source offsets are the same in
+    // every tile up to a UNIFORM tile offset, so they are computed once and the tile offset rides in the DMA instruction's scalar
+    // operand.  stage_tile above spends ~13 VALU instructions per DMA (two 64-bit multiplies among them) -- 4 DMAs per wave and
+    // tile at D = 64, a sixth of the VALU work of a kernel that is VALU-bound.
+    // measured (tools/attn_bench.py, profiles/r05_attn_fast_stage.txt): D = 40 515 -> 499 us, D = 64 1013 -> 1027 us (the three-blocks-per-CU
+    // register budget of D = 64 turns the extra offsets into spills) -- so only where the budget has room
+    constexpr bool FASTST = D == 40 || D == 80;
+    unsigned k_voff[FASTST ? K_DMA : 1], v_voff[FASTST ? V_DMA : 1];
+    if constexpr (FASTST) {
+#pragma unroll
+    for (int j = 0; j < K_DMA; ++j) {
+        const int row = (wave * K_DMA + j) * K_RPI + lane / KCH;
+        const int chunk = (lane % KCH) ^ kkey(row);
+        k_voff[j] = (chunk * 8 < D) ? (unsigned)(((size_t)row * p.k_ld + chunk * 8) * 2) : MDX_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < V_DMA; ++j) {
+        const int row = (wave * V_DMA + j) * 8 + (lane >> 3);
+        const unsigned chunk = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+        v_voff[j] = (row < D) ? (unsigned)(((size_t)row * p.vt_ld + chunk * 8) * 2) : MDX_OOB;
+    }
+    }
+    const unsigned k_tile_bytes = (unsigned)BKV * (unsigned)p.k_ld * 2u;
+    auto stage_full = [&](int t, int buf) {
+        if constexpr (!FASTST) return;
+        char* sb = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < K_DMA; ++j) dma16s(rs_k, sb + (wave * K_DMA + j) * 1024, k_voff[j], (unsigned)t * k_tile_bytes);
+#pragma unroll
+        for (int j = 0; j < V_DMA; ++j) {
+            const int inst = wave * V_DMA + j;
+            if (inst * 8 < (LROW ? D : V_ROWS)) dma16s(rs_v, sb + K_BYTES + inst * 1024, v_voff[j], (unsigned)t * (BKV * 2u));
+        }
+    };
+    const int nk_full = p.Nk / BKV;      // tiles t < nk_full are full
+    auto stage = [&](int t, int buf) {
+        if (FASTST && p.fast_stage && t < nk_full) stage_full(t, buf); else stage_tile(t, buf);
     };
 
     f32x16 acc_o[DT];
@@ -260,19 +300,19 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
         }
     }
     // tile t lives in LDS buffer t & 1; tile t + 1 is staged while tile t is computed
-    stage_tile(t_begin, 0);
+    stage(t_begin, 0);
     __syncthreads();
     int t = t_begin;
     for (; t + 2 <= nfull_l; t += 2) {
-        stage_tile(t + 1, 1);
+        stage(t + 1, 1);
         tile(B0{}, std::false_type{}, t);
         __syncthreads();
-        if (t + 2 < t_end) stage_tile(t + 2, 0);
+        if (t + 2 < t_end) stage(t + 2, 0);
         tile(B1{}, std::false_type{}, t + 1);
         __syncthreads();
     }
     for (; t < t_end; ++t) {      // the (masked) tail: one tile for a ragged Nk, every tile for causal attention
-        if (t + 1 < t_end) stage_tile(t + 1, (t + 1) & 1);
+        if (t + 1 < t_end) stage(t + 1, (t + 1) & 1);
         const bool masked = t >= nfull;
         if (t & 1) {
             if (masked) tile(B1{}, std::true_type{}, t); else tile(B1{}, std::false_type{}, t);
@@ -408,6 +448,7 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
 // kept, parity-tested, as the record of that measurement.
 template <int D>
 __global__ __launch_bounds__(512) void attn8_kernel(const AttnParams p) {
+    mdx_kernarg_touch<sizeof(AttnParams)>();
     static_assert(D % 8 == 0 && D <= 160, "head dim must be a multiple of 8, <= 160");
     constexpr int KS = (D + 15) / 16;
     constexpr int DT = (D + 31) / 32;
@@ -746,6 +787,7 @@ static int attention_impl(const void* q, long q_bs, int q_ld, const void* k, lon
             p.ws_part = (char*)ws + tb;
         }
     }
+    p.fast_stage = mdx_opt(MDX_OPT_ATTN_FAST_STAGE) ? 1 : 0;
     dim3 grid(qblocks * p.nsplit, heads, B);
     hipStream_t st = (hipStream_t)s;
     // eight-wave form (attn8_kernel above; measured slower, opt-in): self-attention shapes, D <= 80 (D = 160 spills at two waves per SIMD)

@@ -69,6 +69,7 @@ constexpr size_t c8_lds_bytes() {
 // half-phase stagger 1044 / 1167 / 1213 (-12 %): the stagger is what the structure buys.
 template <int BN, int PH, int TAPS, int VAR = 1>
 __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
+    mdx_kernarg_touch<sizeof(GemmParams)>();
     constexpr int NJ = BN / 32;              // 16-column MFMA tiles per wave (a wave owns BN / 2 columns)
     constexpr int B_BYTES = BN * 128;
     constexpr int BINST = BN / 8;            // DMA instructions per weight tile (8 rows of 128 B each)

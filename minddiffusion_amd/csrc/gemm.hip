@@ -56,6 +56,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
     // CU: a wave's K-step is a serial chain (wait -> barrier -> DMA issue -> ds_read -> MFMA), so a lone 4-wave block
     // leaves each SIMD idle for most of it; eight waves halve every wave's share of the DMA issue and MFMAs and give
     // each SIMD a second wave to overlap with.
+    mdx_kernarg_touch<sizeof(GemmParams)>();
     constexpr int WROWS = BM / (NW / 2);    // rows per wave row
     constexpr int TM = WROWS / 32;          // 32-row MFMA tiles per wave along m
     constexpr int TN = BN / 64;             // 32-wide MFMA tiles per wave along n
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     constexpr int BJ = BN / 8 / NW;
     static_assert(BJ >= 1, "weight tile too small for this many loader waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    mdx_kernarg_touch<sizeof(GemmParams)>();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1033,6 +1035,7 @@ __device__ __forceinline__ void splitk_sum8(const GemmParams& p, const float* ba
 
 // split-K reduce + fused epilogue: one thread per (m, 8 output columns)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+    mdx_kernarg_touch<sizeof(GemmParams)>();
     const bool geglu = p.epilogue == MDX_EPI_GEGLU;
     const int ncols = geglu ? p.N / 2 : p.N;
     const int cpr = ncols / 8;
@@ -1142,6 +1145,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 constexpr int CS_ROWS = 64;     // rows per colstats row block of a split-K launch (mdx_gemm_query reports it)
 
 __global__ __launch_bounds__(256) void splitk_reduce_colstats_kernel(const GemmParams p) {
+    mdx_kernarg_touch<sizeof(GemmParams)>();
     __shared__ float part[32][64][2];
     const int tid = threadIdx.x;
     const int chunk = tid & 7, rl = tid >> 3;

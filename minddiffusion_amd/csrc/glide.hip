@@ -118,6 +118,7 @@ struct GlideStep {
 };
 
 __global__ __launch_bounds__(256) void glide_step_kernel(const GlideStep p) {
+    mdx_kernarg_touch<sizeof(GlideStep)>();
     const size_t total = (size_t)p.B * 3 * p.HW;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int pix = (int)(i % p.HW);

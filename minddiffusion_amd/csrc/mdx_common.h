@@ -75,6 +75,7 @@ enum MdxOpt {
     MDX_OPT_GN_BOOST_MB,         // column-statistics GroupNorm on tensors of at least this many MB launches four times the pixel slabs (40; 0 = never)
     MDX_OPT_ATTN_OCC3,           // 1: the D <= 64 attention kernels are built for three blocks per CU (<= 168 VGPRs) instead of two
     MDX_OPT_ATTN_KV_SPLIT,       // split-KV attention (mdx_attention_splitkv_f16 with a workspace): 0 never, 1 auto (fill the chip's block slots), >= 2 force that many splits
+    MDX_OPT_ATTN_FAST_STAGE,     // 1: the attention kernel issues its full KV tiles with per-lane offsets computed once + a scalar tile offset (0 = per-tile address arithmetic)
     MDX_OPT_GN_PREFETCH,         // 1: the GroupNorm kernels fetch their affine parameters (and, where a thread's pixels fit its registers, the pixels) at the top of the kernel, ahead of the statistics (0 = the round-4 order: parameters after the statistics, small tensors read twice)
     MDX_OPT_GEMM_DENSE_ISSUE,    // 1: dense launches of the generic GEMM kernel (ksize 1, stride 1, one source) keep the per-lane source offset fixed and put the K offset in the DMA instructions' scalar operand (0 = the general tap / source decode per K tile)
     MDX_OPT_GEMM_LN_PREFETCH,    // 1: LayerNorm-fold consumers (mdx_gemm_desc.ln_stats) fetch their rows' statistics partials and S[n] before the K loop (0 = at the head of the epilogue)
@@ -139,3 +140,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 }
 
 #define MDX_OOB 0x80000000u
+
+// Kernel-argument warm-up (round 5 experiment, -DMDX_KERNARG_TOUCH=1): a launch's parameter block (GemmParams: ~430 bytes = 7
+// cache lines) is read by scalar loads wherever the compiler first needs a field, each first touch of a line a miss behind an
+// s_waitcnt -- the ISA of gemm_kernel has eight such waits in its first 700 instructions.  One dword of every line is requested
+// here, at the top of the kernel, all in flight together behind ONE wait; the later loads hit the scalar cache.
+#ifndef MDX_KERNARG_TOUCH
+#define MDX_KERNARG_TOUCH 1
+#endif
+template <int BYTES>
+__device__ __forceinline__ void mdx_kernarg_touch() {
+#if MDX_KERNARG_TOUCH
+    typedef __attribute__((address_space(4))) const int* ka_ptr;
+    const ka_ptr ka = (ka_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    int acc = 0;
+#pragma unroll
+    for (int o = 0; o < BYTES; o += 64) acc |= ka[o / 4];
+    asm volatile("" ::"s"(acc));
+#endif
+}

@@ -56,6 +56,7 @@ __device__ __forceinline__ f16x8 gn_load(const GnParams& p, int b, int pix, int 
 // accumulators stay in registers; a fixed-order LDS fold then produces per-group partials
 // (deterministic: no atomics anywhere).
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnParams p) {
+    mdx_kernarg_touch<sizeof(GnParams)>();
     extern __shared__ __attribute__((aligned(16))) float red[];  // [trows][cols*8][2]
     const int b = blockIdx.z, cb = blockIdx.y;
     const int p0 = blockIdx.x * p.pix;
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnParams p) {
 // 8 lanes per group (fixed shuffle order), builds per-channel scale/shift in LDS, then streams the slab.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
     extern __shared__ __attribute__((aligned(16))) float ss[];  // [cols*8][2] scale/shift, then [32][2] group stats
+    mdx_kernarg_touch<sizeof(GnParams)>();
     const int b = blockIdx.z, cb = blockIdx.y;
     const int col0 = cb * p.cw;
     const int cols = min(p.cw, p.CC - col0);
@@ -416,6 +418,7 @@ constexpr int GNF_KEEPN = 6;      // (gn_fused applies up to HW * L * 16 <= 64 K
 template <bool SLAB, int NT = GNF_THREADS, int KEEPN = 0>
 __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnParams p, const MdxSplitInfo sp) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [trows][chs][2] partials, then the folds
+    mdx_kernarg_touch<sizeof(GnParams) + sizeof(MdxSplitInfo)>();
     const int b = blockIdx.y, cb = blockIdx.x;
     const int col0 = cb * p.cw;
     const int cols = min(p.cw, p.CC - col0);

@@ -20,9 +20,9 @@ extern "C" const char* mdx_last_error(void) { return g_err; }
 static const char* const g_opt_names[MDX_OPT_COUNT] = {"gemm_tuned", "gemm_bm", "gemm_bn", "gemm_ring", "gemm_halo", "gemm_halo8",
                                                         "gemm_splitk_fixup_max", "gemm_spread", "halo_nsb", "gn_min_blocks",
                                                         "gn_fused", "gn_col_chunks", "gemm_conv8p", "gemm_conv8p_min_m", "gemm_subpixel_min_tiles", "gemm_conv8p_var", "attn8", "attn8_min_blocks",
-                                                        "gn_wide_rows", "gn_fused_small", "gn_boost_mb", "attn_occ3", "attn_kv_split",
+                                                        "gn_wide_rows", "gn_fused_small", "gn_boost_mb", "attn_occ3", "attn_kv_split", "attn_fast_stage",
                                                         "gn_prefetch", "gemm_dense_issue", "gemm_ln_prefetch"};
-static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1, 4, 1, 4096, 32, 0, 0, 192, 0, 0, 40, 1, 1, 1, 1, 1};
+static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1, 4, 1, 4096, 32, 0, 0, 192, 0, 0, 40, 1, 1, 1, 1, 1, 1};
 
 int mdx_opt(int id) { return g_opt[id]; }
 
@@ -156,6 +156,7 @@ struct StepParams {
 };
 
 __global__ __launch_bounds__(256) void sampler_step_kernel(const StepParams p) {
+    mdx_kernarg_touch<sizeof(StepParams)>();
     const size_t total = (size_t)p.B * p.C * p.HW;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int pix = (int)(i % p.HW);

@@ -197,6 +197,7 @@ __device__ __forceinline__ void warmer_wave(const char* wstream, const BarSched&
 
 template <int C, int TM, int D>
 __global__ __launch_bounds__((C / 32 + 1) * 64) void st_tail_kernel(const StTailParams p) {
+    mdx_kernarg_touch<sizeof(StTailParams)>();
     constexpr int NW = C / 32;
     constexpr int NT = NW * 64;
     constexpr int BM = 32 * TM;
@@ -594,6 +595,7 @@ constexpr BarSched make_head_sched() {
 
 template <int C, int TM>
 __global__ __launch_bounds__((C / 32 + 1) * 64) void st_head_kernel(const StHeadParams p) {
+    mdx_kernarg_touch<sizeof(StHeadParams)>();
     constexpr int NW = C / 32;
     constexpr int NT = NW * 64;
     constexpr int BM = 32 * TM;
