@@ -818,6 +818,11 @@ def test_library_options_replace_environment_variables():
     with pytest.raises(_lib.MdxError, match="unknown option"):
         ops.set_option("no_such_option", 1)
     assert lib.mdx_set_option(b"gemm_bm", 0) == 0
+    # round 5: the issue-order switches exist, default on, and the option table and its name table stay in step (the last name
+    # resolves, so no name is missing in front of it)
+    for name in ("gn_prefetch", "gemm_dense_issue", "gemm_ln_prefetch", "attn_fast_stage"):
+        assert ops.get_option(name) == 1, name
+    assert ops.get_option("halo_nsb") == 0 and ops.get_option("attn_kv_split") == 1 and ops.get_option("gn_boost_mb") == 40
 
 
 def test_unet_plan_fuses_the_320_channel_transformer_blocks():

@@ -1350,3 +1350,81 @@ def test_conv3x3_shape_that_shares_M_with_a_256_row_tuned_row(ops, B, H, W, Cin,
     bad.workspace, bad.workspace_bytes = d.workspace, d.workspace_bytes
     qb = ops.gemm_query(bad)
     assert qb[0] != 256, qb          # a forced 256-row tile on a launch it does not apply to is not honoured
+
+
+# --------------------------------------------------------------------------- round 5: the "latency diet" options move loads, not arithmetic
+@pytest.mark.parametrize("opt", ["gn_prefetch", "gemm_dense_issue", "gemm_ln_prefetch", "attn_fast_stage"])
+def test_round5_issue_order_options_do_not_change_a_bit(ops, opt):
+    """gn_prefetch / gemm_dense_issue / gemm_ln_prefetch / attn_fast_stage (include/mdx.h) change WHEN a kernel requests its
+    operands and parameters -- scalar-offset DMA issue, parameters ahead of the statistics, touches ahead of the K loop -- never
+    the order of a sum: the outputs of the kernels they touch must be bit-identical with the option on and off."""
+    rng = np.random.RandomState(11)
+
+    def run_all():
+        outs = []
+        # GroupNorm: apply form with two sources, one-launch form (small tensor), FiLM-free
+        for (B, H, W, C1, C2) in [(2, 16, 16, 640, 320), (2, 8, 8, 1280, 0), (1, 64, 64, 320, 0)]:
+            C = C1 + C2
+            x = h16(np.random.RandomState(C + H).standard_normal((B, C, H, W)) * 1.5 + 0.3)
+            g = np.random.RandomState(1).standard_normal(C).astype(np.float32)
+            b = np.random.RandomState(2).standard_normal(C).astype(np.float32)
+            x1 = dev16(nhwc(x[:, :C1]))
+            x2 = dev16(nhwc(x[:, C1:])) if C2 else None
+            outs.append(ops.groupnorm(x1, x2, dev32(g), dev32(b), 1e-5, True).clone())
+        # dense GEMMs (64 x 64 / 128 x 64 / 128 x 128 tiles through the tile rule), bias + residual, a split-K one
+        for (M, N, K, sk) in [(512, 1280, 1280, 1), (2048, 640, 640, 1), (4096, 320, 1280, 1), (128, 1280, 2560, 4)]:
+            r = np.random.RandomState(M + N)
+            a = h16(r.standard_normal((M, K)))
+            w = h16(r.standard_normal((N, K)) / math.sqrt(K))
+            bv = r.standard_normal(N).astype(np.float32)
+            res = h16(r.standard_normal((M, N)))
+            outs.append(ops.gemm(dev16(a), pack_dense(w), N, 1, M, 1, K, bias=dev32(bv), residual=dev16(res), residual_ld=N,
+                                 splitk=sk).clone())
+        # LayerNorm fold: producer with row statistics -> plain consumer
+        M, C, K0 = 512, 640, 256
+        r = np.random.RandomState(5)
+        a0, w0 = h16(r.standard_normal((M, K0))), h16(r.standard_normal((C, K0)) / math.sqrt(K0))
+        g = (1 + 0.3 * r.standard_normal(C)).astype(np.float32)
+        be = (0.3 * r.standard_normal(C)).astype(np.float32)
+        w1, b1 = h16(r.standard_normal((C, C)) / math.sqrt(C)), r.standard_normal(C).astype(np.float32)
+        x = torch.empty((M, C), dtype=torch.float16, device=DEV)
+        stats = torch.zeros((M, C // 64, 2), dtype=torch.float32, device=DEV)
+        d0 = ops.make_gemm_desc(dev16(a0), pack_dense(w0), C, 1, M, 1, K0, x, C, stats_out=stats)
+        ws0 = ops.new_gemm_workspace(ops.gemm_workspace_bytes(d0), DEV)
+        d0.workspace, d0.workspace_bytes = ws0.data_ptr(), ws0.numel() * 4
+        ops.gemm_run(d0)
+        wg, s, cb = ops.fold_layernorm(dev16(w1), dev32(g), dev32(be), dev32(b1))
+        out = torch.empty((M, C), dtype=torch.float16, device=DEV)
+        d1 = ops.make_gemm_desc(x, ops.pack_gemm_weight(wg), C, 1, M, 1, C, out, C, bias=cb, ln_stats=stats, ln_s=s)
+        ws1 = ops.new_gemm_workspace(ops.gemm_workspace_bytes(d1), DEV)
+        d1.workspace, d1.workspace_bytes = ws1.data_ptr(), ws1.numel() * 4
+        ops.gemm_run(d1)
+        outs.append(out.clone())
+        # attention at the head dims that take the scalar-offset tile issue (40, 80) and one that does not (64); ragged key tail
+        for (B, heads, Nq, Nk, D) in [(2, 8, 256, 256, 40), (1, 8, 128, 200, 80), (1, 2, 256, 320, 64)]:
+            Cc = heads * D
+            r = np.random.RandomState(Nq + D)
+            q, k, v = (h16(r.standard_normal((B, n, Cc))) for n in (Nq, Nk, Nk))
+            ld = (Nk + 7) // 8 * 8
+            vt = np.zeros((B, Cc, ld), np.float32)
+            vt[:, :, :Nk] = v.transpose(0, 2, 1)
+            qd, kd, vtd = dev16(q), dev16(k), dev16(vt)
+            o = torch.empty((B, Nq, Cc), dtype=torch.float16, device=DEV)
+            ops.attention(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), o.data_ptr(), B, heads, D, Nq, Nk, D ** -0.5,
+                          Nq * Cc, Cc, Nk * Cc, Cc, Cc * ld, ld, Nq * Cc, Cc)
+            outs.append(o.clone())
+        torch.cuda.synchronize()
+        return outs
+
+    default = ops.get_option(opt)
+    try:
+        ops.set_option(opt, 1)
+        on = run_all()
+        ops.set_option(opt, 0)
+        off = run_all()
+    finally:
+        ops.set_option(opt, default)
+    assert len(on) == len(off)
+    for i, (a, b) in enumerate(zip(on, off)):
+        assert torch.equal(a, b), f"output {i} differs between {opt} = 1 and 0"
+    assert all(torch.isfinite(a.float()).all() for a in on)
