@@ -30,6 +30,11 @@
 #ifndef MDX_HALO_LOOP
 #define MDX_HALO_LOOP 1
 #endif
+// timing ablations of the HALO tap loop (tools/exp/r05_halo_ablate.sh; WRONG RESULTS, never in the product build): 1 = no MFMAs,
+// 2 = no fragment reads, 3 = no DMA issue inside the loop, 4 = no barrier
+#ifndef MDX_HALO_ABLATE
+#define MDX_HALO_ABLATE 0
+#endif
 
 #include <stdlib.h>
 
@@ -806,13 +811,17 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... and are rewritten before anyone passes the barrier
                 }
             }
+#if MDX_HALO_ABLATE != 4
             __builtin_amdgcn_s_barrier();
+#endif
             if (t == 0) trace_mark(p, 2);
             // (round 5: DMA issue first -- the weight stream is latency x ring-depth bound, every instruction in front of the issue is
             // added to the chain: measured +10...35 % with the fragment reads in front -- then the fragment reads, pinned by
             // sched_barriers: see gemm_kernel's main loop)
+#if MDX_HALO_ABLATE != 3
             if (more && tap < HJ) dma_halo(tap, c + 1, hb ^ 1);
             if (t + NSB - 1 < nt) dma_b(kt_begin + t + NSB - 1, wr);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             const int ky = tap / 3, kx = tap - ky * 3;
             const int dq = ky * HWD + kx;
@@ -833,15 +842,28 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
             f16x8 af[FD][TM], bf[FD][TN];
             auto rdfrag = [&](auto slot_c, const int ks) {
                 constexpr int slot = decltype(slot_c)::value;
+#if MDX_HALO_ABLATE == 2
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { f16x8 tt; asm volatile("" : "=v"(tt)); af[slot][i] = tt; }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { f16x8 tt; asm volatile("" : "=v"(tt)); bf[slot][j] = tt; }
+#else
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     af[slot][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + (((2 * ks + hi) << 4) ^ a_key[i]));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     bf[slot][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + (((2 * ks + hi) ^ swz_b) << 4));
+#endif
             };
             auto mfmas = [&](auto slot_c) {
                 constexpr int slot = decltype(slot_c)::value;
+#if MDX_HALO_ABLATE == 1
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { const f16x8 tt = af[slot][i]; asm volatile("" ::"v"(tt)); }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { const f16x8 tt = bf[slot][j]; asm volatile("" ::"v"(tt)); }
+#else
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -851,6 +873,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
                         else
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[slot][i], bf[slot][j], acc[i][j], 0, 0, 0);
                     }
+#endif
             };
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
