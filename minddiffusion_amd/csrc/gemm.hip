@@ -15,8 +15,9 @@
 //  * LDS image is lane-linear per DMA (8 rows x 128 B); the bank-conflict XOR swizzle
 //    (chunk ^= (row>>1)&7; halo: keyed on the halo column) is applied on the source side and again on the
 //    ds_read_b128 side.  Weights are stored tile-major and pre-swizzled so each DMA reads 1 KiB contiguous.
-//  * 2-5 stage LDS ring, counted `s_waitcnt vmcnt(N)` + raw `s_barrier` (DMAs stay in flight across the
-//    barrier), fragments of k-step s+1 prefetched during the MFMAs of k-step s, XCD-aware tile order.
+//  * 2-6 stage LDS ring, counted `s_waitcnt vmcnt(N)` + raw `s_barrier` (DMAs stay in flight across the
+//    barrier); per K tile: ring-refill DMA issue, then the tile's fragment reads pinned with sched_barriers, then the MFMAs
+//    (round 5); dense launches issue through the DMA's scalar offset; XCD-aware tile order; kernel arguments warmed at entry.
 //  * Epilogue is staged through LDS so that global stores are full 16-B / 128-B-row coalesced;
 //    bias (fetched before the K loop), per-sample time-embedding bias, residual add, GEGLU / GELU / QuickGELU, the
 //    transposed (V^T) store and the split q|k row-major + V^T output are fused there.
@@ -25,11 +26,6 @@
 #include "mdx_common.h"
 #include "gemm_internal.h"
 
-// experiment switch (round 5): 1 = fragment reads of a tap pinned with sched_barriers (all four k-steps up front on tiles with
-// <= 2 MFMAs per k-step), 0 = the round-4 loop (reads left to the machine scheduler)
-#ifndef MDX_HALO_LOOP
-#define MDX_HALO_LOOP 1
-#endif
 // timing ablations of the HALO tap loop (tools/exp/r05_halo_ablate.sh; WRONG RESULTS, never in the product build): 1 = no MFMAs,
 // 2 = no fragment reads, 3 = no DMA issue inside the loop, 4 = no barrier
 #ifndef MDX_HALO_ABLATE
@@ -381,10 +377,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_kernel(const Ge
         // Order inside a K tile (round 5).  A block that has its SIMDs to itself -- nearly every launch at UNet batch 2 -- runs the
         // chain wait -> barrier -> DMA issue -> ds_read -> MFMA serially, one instruction per ~3 ns, and the ISA of round 4 showed
         // the machine scheduler sinking every fragment read to its use: each MFMA waited for a ds_read issued right before it, KS
-        // LDS round trips per K tile with nothing to hide them.  Now (i) the fragment reads of k-step 0 -- of ALL KS k-steps on
-        // tiles with at most two MFMAs per k-step, which have nothing to hide a read behind -- are issued BEFORE the DMA
-        // instructions that refill the ring (they read stage rd, the DMAs write stage wr: no hazard beyond the barrier above), so
-        // their LDS round trip overlaps the DMA issue, and (ii) sched_barriers pin the reads where they are written.
+        // LDS round trips per K tile with nothing to hide them.  Now: (i) the ring-refill DMAs are issued FIRST (the operand
+        // stream is latency x ring-depth bound: with the reads in front of the issue the convs lost 10-35 %), (ii) then the
+        // fragment reads of the tile -- of ALL KS k-steps on tiles with at most two MFMAs per k-step, which have nothing to hide a
+        // read behind; a double buffer on 128 x 128 -- pinned where they are written by sched_barriers, (iii) then the MFMAs.
         const char* sb = smem + rd * STAGE;
         constexpr bool ALLK = (TM * TN <= 2) && !GNA;
         constexpr int FD = ALLK ? KS : 2;
@@ -792,9 +788,8 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     for (int c = c_begin; c < c_end; ++c) {
         const int hb = (c - c_begin) & 1;
         const bool more = c + 1 < c_end;
-#if MDX_HALO_LOOP
-#pragma unroll      // (the pinned form is not unrolled on the compiler's own judgement; the tap decode is nine constants only when it is)
-#endif
+#pragma unroll      // (the pinned form is not unrolled on the compiler's own judgement; the tap decode is nine constants only when it is:
+                    // rolled, the convs of UNet batch 2 were 10-35 % slower -- profiles/r05_kloop_ab.txt)
         for (int tap = 0; tap < 9; ++tap, ++t) {
             // weight tiles t .. t+NSB-2 (and at most one halo slice per tap, each older than the weight tile issued with it) are
             // outstanding: all but the youngest (tiles ahead) x BJ instructions must have landed -- that covers tile t and, with a
@@ -836,7 +831,6 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
                     a_key[i] = (((((l31 & 7) + kx) >> 1) & 3) | ((((l31 >> 3) + ky) & 1) << 2)) << 4;
             }
             const char* sb = smem + rd * B_BYTES;
-#if MDX_HALO_LOOP
             constexpr bool ALLK = TM * TN <= 2;      // at most two MFMAs per k-step: nothing to hide a fragment read behind
             constexpr int FD = ALLK ? 4 : 2;
             f16x8 af[FD][TM], bf[FD][TN];
@@ -900,34 +894,6 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-#else
-            f16x8 af[2][TM], bf[2][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + ((hi << 4) ^ a_key[i]));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + ((hi ^ swz_b) << 4));
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int cur = s & 1, nxt = cur ^ 1;
-                if (s < 3) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        af[nxt][i] = *reinterpret_cast<const f16x8*>(smem + a_row[i] + (((2 * (s + 1) + hi) << 4) ^ a_key[i]));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        bf[nxt][j] = *reinterpret_cast<const f16x8*>(sb + b_row_off + j * 32 * 128 + (((2 * (s + 1) + hi) ^ swz_b) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if constexpr (SWAP)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
-                        else
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-                    }
-            }
-#endif
             rd = (rd + 1 == NSB) ? 0 : rd + 1;
             wr = (wr + 1 == NSB) ? 0 : wr + 1;
         }
