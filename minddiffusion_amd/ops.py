@@ -717,7 +717,15 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
             # (any non-null value), or the row blocks the query reports are those of a different tile / split choice than the
             # launch will make (a 64-row split-K reduce writing into a buffer sized for 128-row tiles).
             d.colstats_out = 8
+            # ... and with an AMPLE workspace: the planners size the shared workspace again after this pass (to the largest ideal need
+            # of any descriptor), so the launch will take the variant's ideal form -- with the workspace of the first sizing the query
+            # can report a fallback (e.g. an un-split 128-row tile where the tuned row splits five ways and its reduce kernel writes
+            # 64-row blocks: found by tools/shape_sweep.py --model glide at a 32-pixel base, round 5 -- the launch then refused
+            # the statistics buffer as too small)
+            keep_ws = d.workspace_bytes
+            d.workspace_bytes = 1 << 40
             rows = gemm_query(d)[5]
+            d.workspace_bytes = keep_ws
             if rows <= 0 or HW % rows or HW // rows > 4096:
                 d.colstats_out = 0
                 return None

@@ -401,6 +401,32 @@ def test_config4_glide_base_batch16_and_superres_batch8_full_size():
     check("config4_glide_superres_B8_row2_vs_B1_hip", gotu[2:3], oneu, rel_l2=4e-3, max_abs=2e-2)
 
 
+def test_glide_base_at_a_32_pixel_image_plans_and_matches_its_batch1_rows():
+    """Round-5 regression (found by tools/shape_sweep.py --model glide): at a 32 x 32 image and batch 2 the full-size base UNet has a
+    conv whose column-statistics launch variant resolves to a tile-table row that splits K five ways (reduce kernel, 64-row statistics
+    blocks).  The GroupNorm wiring asked for the row-block count while the shared workspace still had its first size -- too small for
+    that split, so the query reported the un-split 128-row form -- and the launch then refused the statistics buffer
+    ('colstats_out holds 16 row blocks, this launch writes 32').  The wiring now asks with an ample workspace (ops.py).  Checked:
+    the plan builds, runs, and every row equals its own batch-1 evaluation to fp16 rounding."""
+    from minddiffusion_amd.glide.default_options import model_and_diffusion_defaults
+    from minddiffusion_amd.glide.diffusion_creator import create_model
+    from minddiffusion_amd.weights import synthetic_unet_params_device
+    net = create_model(**model_and_diffusion_defaults())
+    net.load_state_dict(synthetic_unet_params_device(net.parameter_shapes(), seed=0, device=DEV))
+    net.use_graph = False
+    rng = np.random.RandomState(32)
+    B = 3
+    x = torch.tensor(rng.randn(B, 3, 32, 32).astype(np.float32), device=DEV)
+    tok = torch.tensor(rng.randint(1, 50000, (B, 128)).astype(np.int32), device=DEV)
+    msk = torch.ones((B, 128), dtype=torch.int32, device=DEV)
+    t = torch.full((B,), 500.0, device=DEV)
+    ones = [net.forward_nhwc(x[r:r + 1].clone(), t[:1], tok[r:r + 1], msk[r:r + 1]).clone() for r in range(B)]
+    for b in (2, 3):
+        full = net.forward_nhwc(x[:b].clone(), t[:b], tok[:b], msk[:b]).clone()
+        for r in range(b):
+            check(f"glide_base_32px_B{b}_row{r}_vs_B1", full[r:r + 1], ones[r], rel_l2=4e-3, max_abs=5e-2)
+
+
 def test_config4_glide_full_size_loops():
     """BASELINE configs[4], the LOOPS on the full-size models (Taichu-GLIDE/model/glide_text2im/main_funcs.py:21-69): ten
     guided ancestral steps of the 385 M-parameter base model (learned variance, x0 clipping, per-step random unconditional

@@ -15,6 +15,43 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def sweep_glide(args):
+    """The two Taichu-GLIDE UNets (base at --latents pixels, default 64; up-sampler at 4x that with a low-res input of the base size):
+    every row of batch B against its own batch-1 evaluation."""
+    from bench import build_glide
+    dev = "cuda:0"
+    dm, sr = build_glide(dev)
+    lo, _, hi = args.batches.partition("-")
+    batches = list(range(int(lo), int(hi or lo) + 1))
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    bad = 0
+    for hw in [int(v) for v in args.latents.split(",")]:
+        for name, net, size, low in (("glide-base", dm.model, hw, None), ("glide-up", sr.model, 4 * hw, sr.model.low_size)):
+            net.use_graph = False
+            rng = np.random.RandomState(size)
+            Bm = max(batches)
+            x = torch.tensor(rng.randn(Bm, 3, size, size).astype(np.float32), device=dev)
+            tok = torch.tensor(rng.randint(1, 50000, (Bm, 128)).astype(np.int32), device=dev)
+            msk = torch.ones((Bm, 128), dtype=torch.int32, device=dev)
+            lr = torch.tensor(rng.randn(Bm, 3, low, low).astype(np.float32), device=dev) if low else None
+            t = torch.full((Bm,), 500.0, device=dev)
+            kw = lambda a, b: dict(low_res=lr[a:b].clone()) if low else {}
+            ones = [net.forward_nhwc(x[r:r + 1].clone(), t[:1], tok[r:r + 1], msk[r:r + 1], **kw(r, r + 1)).clone() for r in range(Bm)]
+            for B in batches:
+                if B == 1:
+                    continue
+                full = net.forward_nhwc(x[:B].clone(), t[:B], tok[:B], msk[:B], **kw(0, B))
+                errs = [rel(full[r:r + 1], ones[r]) for r in range(B)]
+                flag = "" if max(errs) <= args.tol else "   <-- MISMATCH rows " + str([r for r, e in enumerate(errs) if e > args.tol])
+                bad += bool(flag)
+                print(f"{name} {size:3d} px B {B:2d}  worst {max(errs):.2e}{flag}", flush=True)
+                net._plans.pop((B, size, size), None)
+            net._plans.clear()
+            torch.cuda.empty_cache()
+    print("mismatching (size, batch) pairs:", bad)
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="sd2")
@@ -22,6 +59,8 @@ def main():
     ap.add_argument("--batches", default="2-16")
     ap.add_argument("--tol", type=float, default=4e-3)
     args = ap.parse_args()
+    if args.model == "glide":
+        return sweep_glide(args)
     from minddiffusion_amd.configs import SD2_UNET, WUKONG_UNET
     from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
     from minddiffusion_amd.weights import synthetic_unet_params_device
