@@ -415,8 +415,12 @@ class Text2ImUNet:
         P.emb_all = torch.empty((B, self._emb_total), dtype=f32, device=dev)
         emit(lambda: ops.timestep_embedding(P.t_static, mc, out=t_emb), "small")
         emit(lambda: ops.dense_small(t_emb, w["te0.w"], w["te0.b"], act_out=True, out=cat_in[:, :ted]), "small")
-        emit(lambda: ops.dense_small(cat_in, w["te2proj.w"], w["te2proj.b"], out=emb), "small")
-        emit(lambda: ops.dense_small(emb, w["emb.w"], w["emb.b"], act_in=True, out=P.emb_all), "small")
+        # (round 5) the SiLU in front of every emb_layer (unet.py:163-170) is applied ONCE, on the way out of the GEMV that produces
+        # emb -- `emb` feeds nothing else here -- instead of on the way into the emb_layers GEMV, where every one of its ~25 000
+        # output columns re-evaluated it on all B x 768 inputs (the 159 us "small" op of profiles/r05_glide_op_profile.txt, every
+        # step).  Same value either way: silu of the same fp32 number.
+        emit(lambda: ops.dense_small(cat_in, w["te2proj.w"], w["te2proj.b"], act_out=True, out=emb), "small")
+        emit(lambda: ops.dense_small(emb, w["emb.w"], w["emb.b"], out=P.emb_all), "small")
 
         def resblock(pre, x, x2, cin, cout, mode, h, wd):
             """unet.py:178-218 (scale-shift norm; up/down act on BOTH h and x)."""
