@@ -539,10 +539,31 @@ def run_config(config, args, rank, world, device, steps, warmup, cpu):
             tflop_per_unit = cfg["tflop_per_image"]
             Pb, Ps = dm.model._plan(2 * batch, 64, 64), sr.model._plan(batch, 256, 256)
             result["config"]["hip_graph"] = Pb.graph is not None and Ps.graph is not None
-            acc = family_fractions(family_profile(Pb), float(dm.num_timesteps))
-            acc = family_fractions(family_profile(Ps), float(sr.num_timesteps), acc)
+            # (round 6) a step runs the plan's BODY only: the text transformer, the encoder_kv projections and the time-embedding
+            # chain of all steps run once per loop (Text2ImUNet.begin_loop) and are timed below as `loop_prefix_ms`, not folded
+            # into the per-family figures
+            from minddiffusion_amd.glide import diffusion_creator as _DC
+            tables = _DC._LOOP_TABLES
+            acc = family_fractions(family_profile(Pb, Pb.main[Pb.n_emb:] if tables else None), float(dm.num_timesteps))
+            acc = family_fractions(family_profile(Ps, Ps.main[Ps.n_emb:] if tables else None), float(sr.num_timesteps), acc)
             roof = roofline_from_families(acc, f"{dm.num_timesteps} base evaluations at batch {2 * batch} + "
                                                f"{sr.num_timesteps} super-resolution evaluations at batch {batch}")
+            if tables:
+                tk = np.random.RandomState(1).randint(1, 50000, (2 * batch, 128)).astype(np.int32)
+                mk = np.ones((2 * batch, 128), np.int32)
+                un = np.random.RandomState(2).randint(1, 50000, (dm.num_timesteps, 128)).astype(np.int32)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                for _ in range(2):      # second pass timed (the first builds the table plans)
+                    ev[0].record()
+                    dm.begin_loop(tk, mk, un)
+                    ev[1].record()
+                    sr.begin_loop(tk[:batch], mk[:batch])
+                    ev[2].record()
+                torch.cuda.synchronize()
+                dm.end_loop(); sr.end_loop()
+                result["config"]["loop_prefix_ms"] = {"base": round(ev[0].elapsed_time(ev[1]), 3), "super_res": round(ev[1].elapsed_time(ev[2]), 3),
+                                                      "note": "once per loop (text transformer on all prompts incl. the 60 unconditional ones, "
+                                                              "encoder_kv tables, emb table of all steps); inside the timed region, outside `families`"}
         whole = units_per_s / world * tflop_per_unit
         roof["whole_path"] = {"achieved": round(whole, 2), "frac": round(whole / MFMA_PEAK_TFLOPS, 4),
                               "algorithmic_tflop_per_unit": tflop_per_unit,

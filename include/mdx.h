@@ -12,7 +12,8 @@
  *    including workspaces; the library never allocates device memory and never
  *    synchronises -- with ONE exception: the arrival counters of the in-kernel split-K reduce
  *    (16 KiB per distinct workspace address, carved from 1 MiB chunks that are zeroed when they
- *    are allocated; see mdx_gemm_desc.workspace and mdx_gemm_release_counters).  All work is
+ *    are allocated; see mdx_gemm_desc.workspace and mdx_gemm_release_counters) for a workspace the
+ *    caller has NOT bound counters of its own to (mdx_gemm_bind_counters: with it, no exception).  All work is
  *    enqueued on the caller's stream (hipStream_t passed as void*), so calls are capturable
  *    into a hipGraph.
  *  - Activations are NHWC ("token-major") fp16: [B][H*W][C]; the reference's NCHW fp32
@@ -48,8 +49,11 @@ typedef void* mdx_stream_t; /* hipStream_t */
 
 int mdx_version(void);
 const char* mdx_last_error(void);
-/* Tuning / experiment switches of the library (process-global ints; defaults = what the product runs; set before the first
- * launch they affect, not thread safe).  The library itself reads NO environment variables.  Names:
+/* Tuning / experiment switches of the library.  PROCESS-GLOBAL MUTABLE STATE -- the one place the library departs from "re-entrant
+ * per call, no global state" (SURVEY 8(b)): plain ints shared by every thread, stream and device of the process, read when a
+ * launch is resolved (so a captured graph holds the values of its capture).  Defaults = what the product runs; they exist for A/B
+ * measurements and the tuner.  Set them before the first launch they affect, from one thread; a host that needs two settings at
+ * once needs two processes.  The library itself reads NO environment variables.  Names:
  *   gemm_tuned (1)  gemm_bm (0 = auto)  gemm_bn (0)  gemm_ring (0 = auto, 2..5)  gemm_halo (1)  gemm_halo8 (1)
  *   gemm_splitk_fixup_max (4)  gemm_spread (1)  halo_nsb (0 = auto)  gn_min_blocks (512)  gn_fused (1)
  *   attn_fast_stage (1): the attention kernel issues full KV tiles with fixed per-lane offsets + a scalar tile offset
@@ -240,6 +244,13 @@ int mdx_gemm_release_counters(void);
  * precondition (nothing in flight, no live graph captured with this workspace).  Returns the number of sets released (0 = the
  * workspace never carried a split launch).  The counters' device is taken from the workspace POINTER, not the calling thread. */
 int mdx_gemm_release_workspace(const void* workspace);
+/* Caller-owned arrival counters: binds `counters` -- MDX_GEMM_WS_HEAD bytes of ZEROED device memory on the workspace's device,
+ * 16-byte aligned, alive and untouched by the caller until mdx_gemm_release_workspace(workspace) -- to the workspace ADDRESS.
+ * Launches on a bound workspace take their tickets there, and the library then allocates NOTHING for them: the ownership rule
+ * above holds without its exception (what a host that captures graphs on its own allocator wants; minddiffusion_amd/ops.py
+ * new_gemm_workspace binds a set to every workspace it creates).  Every launch leaves the counters zero.  Rebinding the same
+ * pair is a no-op; binding another set replaces the previous one (nothing may be in flight, no live graph captured with it). */
+int mdx_gemm_bind_counters(const void* workspace, void* counters);
 /* Bytes of split-K workspace mdx_gemm_f16 wants for this problem under its auto heuristic (0 if none). */
 size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d);
 /* Host-only validation of a descriptor (no launch): MDX_OK or MDX_E_INVALID with mdx_last_error() set. */
@@ -430,6 +441,26 @@ int mdx_glide_superres_input_f16(const float* x, const float* low, void* out, in
 int mdx_glide_step_f32(const float* x, const void* out_c, const void* out_u, int ld, float guidance_scale,
                        const float* coef8, int mode, float noise_scale, const float* noise, float* x_next,
                        float* pred_x0, int B, int H, int W, mdx_stream_t s);
+
+/* Taichu-GLIDE sampling loops know every prompt before the first step (main_funcs.py:21-44 draws the unconditional prompt of
+ * step k inside the loop, but from a stream that does not depend on the model): the text transformer (xf.py:126-154) and every
+ * AttentionBlock's encoder_kv projection (unet.py:289-297) of ALL steps' prompts run once per loop into tables, and each step
+ * copies its prompt's rows into the text slots of the blocks' key / value buffers -- ONE launch for all blocks:
+ *   for slot in [0, nslots), b in [b0, b0 + nb):  entry e = entry0 + (b - b0) * entry_per_b (entry_per_b in {0, 1})
+ *     dst[b * dst_batch_bytes + r * dst_pitch + 0..row_bytes) = src[e * src_entry_bytes + r * src_pitch + 0..row_bytes),  r < rows
+ * (keys: rows = text tokens, row_bytes = 2 C, both pitches 2 C; transposed values: rows = C, row_bytes = 2 text tokens,
+ * dst_pitch = 2 (text + image tokens)).  `slots_dev` is a DEVICE array (caller-owned); every pointer and byte count a multiple
+ * of 16.  blocks_per_copy = grid blocks that share one (slot, b) copy. */
+typedef struct mdx_glide_kv_slot {
+    const void* src;
+    void* dst;
+    long src_entry_bytes;
+    long dst_batch_bytes;
+    long src_pitch, dst_pitch;
+    int rows, row_bytes;
+} mdx_glide_kv_slot;
+int mdx_glide_kv_select_f16(const mdx_glide_kv_slot* slots_dev, int nslots, long entry0, int entry_per_b, int b0, int nb,
+                            int blocks_per_copy, mdx_stream_t s);
 
 /* Causal self-attention (key j visible to query i iff j <= i): the text encoder's triu(-inf) mask
  * (ldm/modules/encoders/text_encoder.py:136-139, MultiheadAttention :43-66).  Same arguments; Nq must equal Nk. */

@@ -89,6 +89,7 @@ SIGNATURES = {
     "mdx_gemm_f16": (c_int, [ctypes.POINTER(GemmDesc), c_void_p]),
     "mdx_gemm_workspace_bytes": (c_size_t, [ctypes.POINTER(GemmDesc)]),
     "mdx_gemm_release_workspace": (c_int, [c_void_p]),
+    "mdx_gemm_bind_counters": (c_int, [c_void_p, c_void_p]),
     "mdx_st_tail_sched_barriers": (c_int, [c_int, c_int]),
     "mdx_st_head_sched_barriers": (c_int, [c_int, c_int]),
     "mdx_gemm_release_counters": (c_int, []),
@@ -123,6 +124,7 @@ SIGNATURES = {
     "mdx_glide_superres_input_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mdx_glide_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_float, c_void_p,
                                    c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mdx_glide_kv_select_f16": (c_int, [c_void_p, c_int, c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "mdx_pack_b_operand_f16": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p]),
     "mdx_vae_gaussian_sample_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mdx_softmax_rows_f16": (c_int, [c_void_p, c_long, c_int, c_int, c_float, c_void_p]),

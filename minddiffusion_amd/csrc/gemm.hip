@@ -1686,6 +1686,7 @@ struct Resolved {
 struct TicketPools {
     std::mutex mu;
     std::map<std::pair<int, const void*>, unsigned*> slot;
+    std::map<std::pair<int, const void*>, bool> caller_owned;      // slots bound by mdx_gemm_bind_counters: never recycled / freed here
     struct Dev { char* next = nullptr; int left = 0; hipStream_t zero_stream = nullptr; std::vector<unsigned*> free_slots; };
     std::map<int, Dev> dev;
     std::vector<std::pair<int, void*>> chunks;
@@ -1752,14 +1753,42 @@ static int ticket_slot(const void* ws, unsigned** out) {
     return MDX_OK;
 }
 
+// Caller-owned arrival counters (include/mdx.h): `counters` = MDX_GEMM_WS_HEAD bytes of ZEROED device memory on the workspace's
+// device, bound to the workspace ADDRESS until mdx_gemm_release_workspace(workspace).  Launches on a bound workspace take their
+// tickets there and the library makes no device allocation for them: a host that owns every byte (a graph-capturing caller on its
+// own allocator) binds one set per workspace and the "one exception" of the ownership rule never fires.
+extern "C" int mdx_gemm_bind_counters(const void* workspace, void* counters) {
+    MDX_REQUIRE(workspace && counters && ((uintptr_t)counters % 16) == 0,
+                "mdx_gemm_bind_counters: workspace and a 16-byte aligned counters buffer of MDX_GEMM_WS_HEAD zeroed bytes are required");
+    const int dv = ticket_device_of(workspace);
+    MDX_REQUIRE(ticket_device_of(counters) == dv, "mdx_gemm_bind_counters: the counters must live on the workspace's device");
+    std::lock_guard<std::mutex> lk(g_tickets.mu);
+    const auto key = std::make_pair(dv, workspace);
+    const auto it = g_tickets.slot.find(key);
+    if (it != g_tickets.slot.end()) {
+        if (it->second == counters) return MDX_OK;
+        // a library-owned set was handed to this address by an earlier launch: give it back, the caller's replaces it
+        if (!g_tickets.caller_owned.count(key)) g_tickets.dev[dv].free_slots.push_back(it->second);
+        g_tickets.slot.erase(it);
+    }
+    g_tickets.slot.emplace(key, static_cast<unsigned*>(counters));
+    g_tickets.caller_owned[key] = true;
+    return MDX_OK;
+}
+
 // Hands the arrival counters of ONE workspace back for reuse (include/mdx.h): call it when the workspace is freed.  Nothing may be
 // in flight on it and every hipGraph captured with it must have been destroyed (a captured launch holds the counters' address).
+// A caller-owned set (mdx_gemm_bind_counters) is only unbound: its memory is the caller's.
 extern "C" int mdx_gemm_release_workspace(const void* workspace) {
     std::lock_guard<std::mutex> lk(g_tickets.mu);
     int n = 0;
     for (auto it = g_tickets.slot.begin(); it != g_tickets.slot.end();) {
         if (it->first.second == workspace) {
-            g_tickets.dev[it->first.first].free_slots.push_back(it->second);
+            const auto own = g_tickets.caller_owned.find(it->first);
+            if (own != g_tickets.caller_owned.end())
+                g_tickets.caller_owned.erase(own);
+            else
+                g_tickets.dev[it->first.first].free_slots.push_back(it->second);
             it = g_tickets.slot.erase(it);
             ++n;
         } else {
@@ -1786,6 +1815,7 @@ extern "C" int mdx_gemm_release_counters(void) {
     (void)hipSetDevice(dv);
     g_tickets.chunks.clear();
     g_tickets.slot.clear();
+    g_tickets.caller_owned.clear();
     g_tickets.dev.clear();
     return MDX_OK;
 }

@@ -149,7 +149,36 @@ __global__ __launch_bounds__(256) void glide_step_kernel(const GlideStep p) {
     }
 }
 
+// Text-key tables -> the text slots of every AttentionBlock's key / value buffers (mdx_glide_kv_select_f16): grid (z, slot, b).
+// One 2-D copy per (slot, batch row): `rows` rows of `row_bytes` (multiples of 16) from table entry e = entry0 + b * entry_per_b.
+__global__ __launch_bounds__(256) void kv_select_kernel(const mdx_glide_kv_slot* __restrict__ slots, long entry0, int entry_per_b,
+                                                        int b0) {
+    const mdx_glide_kv_slot sl = slots[blockIdx.y];
+    const int b = b0 + (int)blockIdx.z;
+    const long e = entry0 + (long)blockIdx.z * entry_per_b;
+    const char* src = reinterpret_cast<const char*>(sl.src) + e * sl.src_entry_bytes;
+    char* dst = reinterpret_cast<char*>(sl.dst) + (long)b * sl.dst_batch_bytes;
+    const int vpr = sl.row_bytes >> 4;                 // 16-byte vectors per row
+    const long total = (long)sl.rows * vpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / vpr;
+        const int v = (int)(i - r * vpr);
+        *reinterpret_cast<uint4*>(dst + r * sl.dst_pitch + v * 16) = *reinterpret_cast<const uint4*>(src + r * sl.src_pitch + v * 16);
+    }
+}
+
 }  // namespace
+
+extern "C" int mdx_glide_kv_select_f16(const mdx_glide_kv_slot* slots_dev, int nslots, long entry0, int entry_per_b, int b0,
+                                       int nb, int blocks_per_copy, mdx_stream_t s) {
+    MDX_REQUIRE(slots_dev && nslots > 0 && nslots <= 65535 && nb > 0 && nb <= 65535 && b0 >= 0 && entry0 >= 0 &&
+                    (entry_per_b == 0 || entry_per_b == 1) && blocks_per_copy > 0 && blocks_per_copy <= 1024,
+                "mdx_glide_kv_select_f16: bad arguments");
+    hipLaunchKernelGGL(kv_select_kernel, dim3(blocks_per_copy, nslots, nb), dim3(256), 0, (hipStream_t)s, slots_dev, entry0,
+                       entry_per_b, b0);
+    MDX_LAUNCH_CHECK("mdx_glide_kv_select_f16");
+    return MDX_OK;
+}
 
 extern "C" int mdx_avgpool2x2_f16(const void* x, void* y, int B, int H, int W, int C, mdx_stream_t s) {
     MDX_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0,

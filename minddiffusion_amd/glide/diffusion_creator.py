@@ -79,6 +79,20 @@ class _Schedule:
                 self.coef2[i], np.sqrt(np.float32(ab_prev)), np.sqrt(np.float32(1.0) - np.float32(ab_prev)))
 
 
+_LOOP_TABLES = __import__("os").environ.get("MDX_GLIDE_LOOP_TABLES", "1") != "0"     # 0: every step recomputes text + time embedding (A/B)
+
+
+def _stamp(a):
+    """Something that changes when the array's content may have.  Device tensors count their in-place writes (`_version`);
+    everything on the host -- numpy arrays AND CPU tensors, whose `_version` does not move when the memory is edited through
+    the numpy array `torch.from_numpy` shares it with, or through `.data` -- is hashed (128 ints per prompt: cheap)."""
+    if isinstance(a, torch.Tensor):
+        if a.is_cuda:
+            return ("v", a._version, tuple(a.shape))
+        a = a.detach().numpy()
+    return ("h", hash(np.ascontiguousarray(a).tobytes()))
+
+
 class GenerativePSampleDiffusionModel:
     """gaussian_diffusion.py:36-49: ancestral sampling step with classifier-free guidance."""
 
@@ -90,12 +104,58 @@ class GenerativePSampleDiffusionModel:
         self.pics_generated = shape[0] // 2
         self.num_timesteps = schedule.num_timesteps
         self.generator = None
+        self._loop = None
+
+    # ---- whole-loop tables (Text2ImUNet.begin_loop): the loop (main_funcs.gaussian_p_sample_loop) announces every step's
+    # unconditional prompt before its first step; a step whose arguments are the announced ones skips the text transformer, the
+    # encoder_kv projections and the time-embedding chain.  Anything else falls back to the full per-step evaluation.
+    def begin_loop(self, token, mask, uncond_tokens, uncond_masks=None):
+        P = self.pics_generated
+        S = self.num_timesteps
+        unc = np.ascontiguousarray(np.asarray(uncond_tokens)[:S], dtype=np.int32)
+        if unc.shape[0] != S:
+            raise ValueError(f"begin_loop: {unc.shape[0]} unconditional prompts for {S} steps")
+        um = None if uncond_masks is None else np.ascontiguousarray(np.asarray(uncond_masks)[:S], dtype=np.int32)
+        order = list(range(S))[::-1]                       # main_funcs.py:36: i = S - 1 ... 0
+        t_values = [float(self.schedule.timestep_map[i]) for i in order]
+        tok = torch.as_tensor(token)[:P]
+        msk = torch.as_tensor(mask)[:P]
+        ctx = self.model.begin_loop(2 * P, self.shape[2], self.shape[3], t_values, tok, msk, unc, um)
+        self._loop = dict(ctx=ctx, token=token, mask=mask, stamp=(_stamp(token), _stamp(mask)), unc=unc, um=um,
+                          index={i: k for k, i in enumerate(order)})
+
+    def end_loop(self):
+        self._loop = None
+
+    def _loop_step(self, i, token, mask, random_token, random_mask):
+        """k if step i may take the loop tables: same prompt objects with unchanged content, and the announced unconditional
+        prompt (compared by content: 128 ints)."""
+        lp = self._loop
+        if lp is None or i not in lp["index"] or token is not lp["token"] or mask is not lp["mask"]:
+            return None
+        k = lp["index"][i]
+        rt = np.asarray(random_token.cpu() if isinstance(random_token, torch.Tensor) else random_token).reshape(-1)
+        rm = np.asarray(random_mask.cpu() if isinstance(random_mask, torch.Tensor) else random_mask).reshape(-1)
+        if not np.array_equal(rt, lp["unc"][k]) or not (np.all(rm == 1) if lp["um"] is None else np.array_equal(rm, lp["um"][k])):
+            return None
+        if lp["stamp"] != (_stamp(token), _stamp(mask)):
+            return None
+        return k
 
     def __call__(self, x, timesteps, token, mask, random_token=None, random_mask=None, is_train=False, noise=None):
         P = self.pics_generated
         dev = self.model.device
         i = int(torch.as_tensor(timesteps).reshape(-1)[0])
         xs = x[:P].contiguous()
+        k = self._loop_step(i, token, mask, random_token, random_mask) if _LOOP_TABLES else None
+        if k is not None and tuple(xs.shape) == (P,) + tuple(self.shape[1:]):
+            out = self.model.loop_step(self._loop["ctx"], k, torch.cat([xs, xs], 0))
+            if noise is None and i != 0:
+                noise = torch.randn(xs.shape, device=dev, dtype=torch.float32, generator=self.generator)
+            sample, pred = torch.empty_like(xs), torch.empty_like(xs)
+            ops.glide_step(xs, out[:P], out[P:], out.shape[-1], self.guidance_scale, self.schedule.coef8(i), 0,
+                           0.0 if i == 0 else 1.0, None if i == 0 else noise[:P].contiguous(), sample, pred)
+            return torch.cat([sample, sample], 0), torch.cat([pred, pred], 0)
         tok = torch.as_tensor(token)[:P].to(dev, torch.int32)
         msk = torch.as_tensor(mask)[:P].to(dev, torch.int32)
         rt = torch.as_tensor(random_token).to(dev, torch.int32).reshape(1, -1).expand(P, -1)   # guider.py:46-47
@@ -111,6 +171,7 @@ class GenerativePSampleDiffusionModel:
 
 
 _TEXT_CACHE = __import__("os").environ.get("MDX_GLIDE_TEXT_CACHE", "1") != "0"      # 0: recompute the text transformer every step (A/B)
+_TEXT_EPOCHS = __import__("itertools").count(1)      # process-wide, monotonically increasing text-prefix epochs
 
 
 class DDimSampleDiffusionModel:
@@ -123,29 +184,47 @@ class DDimSampleDiffusionModel:
         self.num_timesteps = schedule.num_timesteps
         self._text = None         # (token object, mask object, their versions / digests, device copies, epoch)
         self._epoch = 0
+        self._loop = None
 
-    @staticmethod
-    def _stamp(a):
-        """Something that changes when the array's content may have: torch tensors count their in-place writes; anything else is
-        hashed (128 ints per prompt)."""
-        if isinstance(a, torch.Tensor):
-            return ("v", a._version, tuple(a.shape))
-        import numpy as _np
-        return ("h", hash(_np.ascontiguousarray(a).tobytes()))
+    _stamp = staticmethod(lambda a: _stamp(a))
+
+    def begin_loop(self, token, mask):
+        """main_funcs.ddim_sample_loop announces its loop: text transformer, encoder_kv projections and the time-embedding chain
+        of all `num_timesteps` steps run once (Text2ImUNet.begin_loop)."""
+        P = int(self.shape[0])
+        S = self.num_timesteps
+        order = list(range(S))[::-1]
+        t_values = [float(self.schedule.timestep_map[i]) for i in order]
+        ctx = self.model.begin_loop(P, self.shape[2], self.shape[3], t_values, torch.as_tensor(token)[:P], torch.as_tensor(mask)[:P])
+        self._loop = dict(ctx=ctx, token=token, mask=mask, stamp=(_stamp(token), _stamp(mask)), P=P,
+                          index={i: k for k, i in enumerate(order)})
+
+    def end_loop(self):
+        self._loop = None
 
     def __call__(self, x, timesteps, token, mask, samples, is_train=False):
         dev = self.model.device
         i = int(torch.as_tensor(timesteps).reshape(-1)[0])
         P = x.shape[0]
+        lp = getattr(self, "_loop", None)
+        if (_LOOP_TABLES and lp is not None and i in lp["index"] and token is lp["token"] and mask is lp["mask"] and P == lp["P"]
+                and tuple(x.shape) == tuple(self.shape) and lp["stamp"] == (_stamp(token), _stamp(mask))):
+            out = self.model.loop_step(lp["ctx"], lp["index"][i], x, low_res=samples[:P].to(dev, torch.float32).contiguous())
+            sample, pred = torch.empty_like(x), torch.empty_like(x)
+            ops.glide_step(x.contiguous(), out, None, out.shape[-1], 1.0, self.schedule.coef8(i), 1, 0.0, None, sample, pred)
+            return sample, pred
         t = torch.full((P,), float(self.schedule.timestep_map[i]), device=dev)
         # the loop (main_funcs.py:47-69) hands the SAME token / mask objects to every one of its 27 steps: the model's text
         # transformer then runs once per loop instead of once per step (Text2ImUNet.forward_nhwc text_epoch)
         tx = self._text
         if (tx is None or tx[0] is not token or tx[1] is not mask or tx[2] != (self._stamp(token), self._stamp(mask), P)):
-            self._epoch += 1
+            # the epoch is drawn from ONE process-wide counter: (id(self), per-object counter) could repeat when a second sampler
+            # object is allocated at a collected one's address and restarts its counter -- the model would then keep the previous
+            # prompt's text prefix
+            self._epoch = next(_TEXT_EPOCHS)
             tx = self._text = (token, mask, (self._stamp(token), self._stamp(mask), P),
                                torch.as_tensor(token)[:P].to(dev, torch.int32).contiguous(),
-                               torch.as_tensor(mask)[:P].to(dev, torch.int32).contiguous(), (id(self), self._epoch))
+                               torch.as_tensor(mask)[:P].to(dev, torch.int32).contiguous(), ("ddim", self._epoch))
         out = self.model.forward_nhwc(x, t, tx[3], tx[4], low_res=samples[:P].to(dev, torch.float32).contiguous(),
                                       text_epoch=tx[5] if _TEXT_CACHE else None)
         sample, pred = torch.empty_like(x), torch.empty_like(x)

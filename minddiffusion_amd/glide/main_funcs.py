@@ -13,13 +13,23 @@ def gaussian_p_sample_loop(diffusion_model, token, mask, shape, num_timesteps, t
     img = noise.to(dev, torch.float32) if noise is not None else torch.randn(tuple(shape), device=dev)
     rng = rng or np.random.RandomState()
     ones = np.ones((text_ctx,), np.int32)
-    for k, i in enumerate(list(range(num_timesteps))[::-1]):
-        random_token = (uncond_tokens[k] if uncond_tokens is not None
-                        else rng.randint(1, vocab_len - 1, (text_ctx,)).astype(np.int32))
-        sample, _ = diffusion_model(x=img, timesteps=torch.tensor([i], dtype=torch.int32), token=token, mask=mask,
-                                    random_token=random_token, random_mask=ones,
-                                    noise=None if step_noises is None else step_noises[k])
-        img = sample
+    # every step's unconditional prompt, drawn in the loop's order from the same stream the per-step draws of main_funcs.py:37 use
+    # (they depend on nothing the model computes): knowing them all, the model runs its text transformer once per loop
+    # (GenerativePSampleDiffusionModel.begin_loop) instead of once per step
+    draws = [np.asarray(uncond_tokens[k]).astype(np.int32) if uncond_tokens is not None
+             else rng.randint(1, vocab_len - 1, (text_ctx,)).astype(np.int32) for k in range(num_timesteps)]
+    announce = hasattr(diffusion_model, "begin_loop") and num_timesteps == getattr(diffusion_model, "num_timesteps", -1)
+    if announce:
+        diffusion_model.begin_loop(token, mask, np.stack(draws))
+    try:
+        for k, i in enumerate(list(range(num_timesteps))[::-1]):
+            sample, _ = diffusion_model(x=img, timesteps=torch.tensor([i], dtype=torch.int32), token=token, mask=mask,
+                                        random_token=draws[k], random_mask=ones,
+                                        noise=None if step_noises is None else step_noises[k])
+            img = sample
+    finally:
+        if announce:
+            diffusion_model.end_loop()
     return img
 
 
@@ -31,8 +41,15 @@ def ddim_sample_loop(super_res_model, up_shape, samples, token, mask, num_timest
         img = noise.to(dev, torch.float32)
     else:
         img = torch.randn(tuple(up_shape), device=dev) * 0.997
-    for i in list(range(num_timesteps))[::-1]:
-        sample, _ = super_res_model(x=img, timesteps=torch.tensor([i], dtype=torch.int32), token=token, mask=mask,
-                                    samples=samples)
-        img = sample
+    announce = hasattr(super_res_model, "begin_loop") and num_timesteps == getattr(super_res_model, "num_timesteps", -1)
+    if announce:
+        super_res_model.begin_loop(token, mask)
+    try:
+        for i in list(range(num_timesteps))[::-1]:
+            sample, _ = super_res_model(x=img, timesteps=torch.tensor([i], dtype=torch.int32), token=token, mask=mask,
+                                        samples=samples)
+            img = sample
+    finally:
+        if announce:
+            super_res_model.end_loop()
     return img

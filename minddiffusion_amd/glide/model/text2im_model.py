@@ -348,9 +348,11 @@ class Text2ImUNet:
             if out is None:
                 out = A.get((rows_b, tokens, nout))
                 out_ld = nout
+            # text-only launches never split K: their sums must not depend on how many prompt rows a pass carries (the whole-loop
+            # tables of begin_loop run the same GEMMs on other row counts and promise the same bits)
             gemm(a=src, w=wt, N=nout, B=rows_b, H=tokens, W=1, c1=cin - c2, out=out, out_ld=out_ld, a2=src2, c2=c2,
                  bias=bias, residual=residual, residual_ld=nout if residual is not None else 0, epilogue=epilogue,
-                 out_mode=out_mode, out_bs=out_bs)
+                 out_mode=out_mode, out_bs=out_bs, splitk=1 if (text_mode[0] or late_text[0]) else 0)
             return out
 
         def conv3(src, cin, cout, wt, bias, h, wd, upsample=0, residual=None, skip=None, wsub=None):
@@ -421,6 +423,7 @@ class Text2ImUNet:
         # step).  Same value either way: silu of the same fp32 number.
         emit(lambda: ops.dense_small(cat_in, w["te2proj.w"], w["te2proj.b"], act_out=True, out=emb), "small")
         emit(lambda: ops.dense_small(emb, w["emb.w"], w["emb.b"], out=P.emb_all), "small")
+        n_emb_mark = len(main)    # ops [n_text, n_emb) turn (timestep, last text token) into P.emb_all: a loop runs them once (begin_loop)
 
         def resblock(pre, x, x2, cin, cout, mode, h, wd):
             """unet.py:178-218 (scale-shift norm; up/down act on BOTH h and x)."""
@@ -572,6 +575,8 @@ class Text2ImUNet:
                 if c_["meta"] >= nt:
                     c_["meta"] += len(late_main)
             P.n_text = nt + len(late_main)
+            n_emb_mark += len(late_main)
+        P.n_emb = n_emb_mark
         P.kv_keep = kv_keep
         P.gn_ws = torch.empty(gn_need[0], dtype=f32, device=dev)
         P.colstats = {}
@@ -585,11 +590,13 @@ class Text2ImUNet:
             for d in descs:
                 d.workspace = P.gemm_ws.data_ptr()
                 d.workspace_bytes = P.gemm_ws.numel() * 4
+        ops.check_colstats_wiring(descs)
         ops.account_gemm_launches(meta)
         P.main, P.meta, P.descs, P.arena = main, meta, descs, A
         P.keep = (t_emb, cat_in, emb, xf_out)
-        P.graph, P.graph_main, P.graph_failed = None, None, False
+        P.graph, P.graph_main, P.graph_body, P.graph_failed = None, None, None, False
         P.text_epoch = None       # what the text prefix was last run for (forward_nhwc)
+        P.loop_epoch = None       # the begin_loop() context whose text rows the key / value buffers hold
         self._plans[key] = P
         return P
 
@@ -615,19 +622,10 @@ class Text2ImUNet:
                 raise MdxError("SuperResText2ImUNet needs low_res")
             P.low_static.copy_(low_res)
         P.text_epoch = None       # (an exception below must not leave a half-written prefix marked valid)
+        P.loop_epoch = None       # (this call rewrites the text rows a begin_loop() context may have placed)
         body = P.main[P.n_text:] if cached else P.main
         if self.use_graph and not P.graph_failed:
-            if P.graph is None:
-                try:
-                    for op in P.main:
-                        op()
-                    torch.cuda.synchronize()
-                    P.graph = ops.capture_graph(P.main)
-                    P.graph_main = ops.capture_graph(P.main[P.n_text:])
-                except Exception as e:  # pragma: no cover
-                    P.graph, P.graph_main, P.graph_failed = None, None, True
-                    import warnings
-                    warnings.warn(f"hipGraph capture failed, running eagerly: {e}")
+            self._ensure_graphs(P)
             if P.graph is not None:
                 (P.graph_main if cached else P.graph).replay()
                 P.text_epoch = text_epoch
@@ -635,6 +633,206 @@ class Text2ImUNet:
         for op in body:
             op()
         P.text_epoch = text_epoch
+        return P.out_nhwc
+
+    def _ensure_graphs(self, P):
+        """First use of a plan: one eager pass (whatever the static inputs hold), then three captures of the same op list -- the
+        whole step, the step without its text prefix (text_epoch), the step without text prefix AND time embedding (begin_loop)."""
+        if P.graph is not None or P.graph_failed or not self.use_graph:
+            return
+        try:
+            for op in P.main:
+                op()
+            torch.cuda.synchronize()
+            P.graph = ops.capture_graph(P.main)
+            P.graph_main = ops.capture_graph(P.main[P.n_text:])
+            P.graph_body = ops.capture_graph(P.main[P.n_emb:])
+        except Exception as e:  # pragma: no cover
+            P.graph, P.graph_main, P.graph_body, P.graph_failed = None, None, None, True
+            import warnings
+            warnings.warn(f"hipGraph capture failed, running eagerly: {e}")
+
+    # ------------------------------------------------------------------ whole-loop tables (round 6)
+    # The sampling loops know every prompt and every timestep before their first step: main_funcs.py:21-44 draws the unconditional
+    # prompt of step k inside the loop, but from numpy's stream, independent of the model; the conditional prompts are constants.
+    # So everything of a step that depends on (prompt, timestep) alone is computed ONCE per loop --
+    #   * the text transformer (text2im_model.py:88-99, xf.py:126-154) on the conditional prompts and, in one pass of S x ctx rows,
+    #     on all S unconditional prompts;
+    #   * every AttentionBlock's encoder_kv projection of those rows (unet.py:289-297), as tables [rows, ctx, C] / [rows, C, ctx];
+    #   * emb = time_embed(t) + transformer_proj(xf_out[:, -1]) and all ResBlocks' emb_layers (text2im_model.py:102-105,
+    #     unet.py:163-170) for all S x N (step, row) pairs: the table the LDM path calls time_embedding_table --
+    # and a step is: copy emb row-set k, ONE launch that drops prompt k's key / value rows into the blocks' text slots
+    # (mdx_glide_kv_select_f16), replay of the plan's body.  Same kernels on the same values: results are bit-identical to the
+    # per-step recomputation (tests/test_glide_gpu.py) as long as the text GEMMs do not split K differently, which the table pass
+    # rules out (splitk = 1; the per-step launches of the benchmarked shapes resolve to unsplit table rows).
+    class _TextPlan:
+        pass
+
+    def _attn_layers(self):
+        return [(pre, layer[1]) for pre, layer in self._named_layers() if layer[0] == "attn"]
+
+    def _text_plan(self, R):
+        """Text transformer + every AttentionBlock's encoder_kv projection on R prompt rows: static token / mask inputs, an op
+        list, and the outputs `last` [R, xw] fp32 (xf_out[:, -1]), k[j] [R, ctx, C_j], vt[j] [R, C_j, ctx] (walk order)."""
+        if not hasattr(self, "_text_plans"):
+            self._text_plans = {}
+        if R in self._text_plans:
+            return self._text_plans[R]
+        if self.w is None:
+            raise MdxError("load_state_dict() must be called before the first forward")
+        dev, w = self.device, self.w
+        ctx, xw, xh = self.text_ctx, self.xf_width, self.xf_heads
+        T = Text2ImUNet._TextPlan()
+        A = _Arena(dev)
+        main, descs = [], []
+        T.tok_static = torch.zeros((R, ctx), dtype=torch.int32, device=dev)
+        T.mask_static = torch.ones((R, ctx), dtype=torch.int32, device=dev)
+
+        def dense(src, tokens, cin, nout, wt, bias=None, residual=None, epilogue=ops.EPI_NONE, out=None, out_ld=None,
+                  out_mode=ops.OUT_ROWMAJOR):
+            if out is None:
+                out = A.get((R, tokens, nout))
+                out_ld = nout
+            d = ops.make_gemm_desc(a=src, w=wt, N=nout, B=R, H=tokens, W=1, c1=cin, out=out, out_ld=out_ld, bias=bias,
+                                   residual=residual, residual_ld=nout if residual is not None else 0, epilogue=epilogue,
+                                   out_mode=out_mode, splitk=1)
+            descs.append(d)
+            main.append(lambda d=d: ops.gemm_run(d))
+            return out
+
+        x_tok = A.get((R, ctx, xw))
+        main.append(lambda: ops.glide_text_embed(T.tok_static, T.mask_static, w["tok"], w["pos"], w["pad"], out=x_tok))
+        ln = A.get((R, ctx, xw))
+        for l in range(self.xf_layers):
+            t = f"transformer.resblocks.{l}."
+            main.append(lambda t=t, x_tok=x_tok: ops.layernorm(x_tok, w[t + "ln_1.g"], w[t + "ln_1.b"], XF_LN_EPS, out=ln))
+            qk = dense(ln, ctx, xw, 2 * xw, w[t + "qk.w"], bias=w[t + "qk.b"])
+            vt = A.get((R, xw, ctx))
+            dense(ln, ctx, xw, xw, w[t + "v.w"], bias=w[t + "v.b"], out=vt, out_ld=ctx, out_mode=ops.OUT_TRANSPOSED)
+            ao = A.get((R, ctx, xw))
+            main.append(lambda qk=qk, vt=vt, ao=ao: ops.attention(
+                qk.data_ptr(), qk.data_ptr() + xw * 2, vt.data_ptr(), ao.data_ptr(), R, xh, 64, ctx, ctx, 64 ** -0.5,
+                ctx * 2 * xw, 2 * xw, ctx * 2 * xw, 2 * xw, xw * ctx, ctx, ctx * xw, xw))
+            x2 = dense(ao, ctx, xw, xw, w[t + "proj.w"], bias=w[t + "proj.b"], residual=x_tok)
+            A.release(qk); A.release(vt); A.release(ao); A.release(x_tok)
+            main.append(lambda t=t, x2=x2: ops.layernorm(x2, w[t + "ln_2.g"], w[t + "ln_2.b"], XF_LN_EPS, out=ln))
+            hfc = dense(ln, ctx, xw, 4 * xw, w[t + "fc.w"], bias=w[t + "fc.b"], epilogue=ops.EPI_GELU)
+            x_tok = dense(hfc, ctx, 4 * xw, xw, w[t + "fc2.w"], bias=w[t + "fc2.b"], residual=x2)
+            A.release(hfc); A.release(x2)
+        xf_out = torch.empty((R, ctx, xw), dtype=f16, device=dev)
+        main.append(lambda x_tok=x_tok: ops.layernorm(x_tok, w["final_ln.g"], w["final_ln.b"], XF_LN_EPS, out=xf_out))
+        T.last = torch.empty((R, xw), dtype=f32, device=dev)
+        main.append(lambda: T.last.copy_(xf_out[:, -1]))
+        T.k, T.vt = [], []
+        for pre, c in self._attn_layers():
+            kb = torch.empty((R, ctx, c), dtype=f16, device=dev)
+            vb = torch.empty((R, c, ctx), dtype=f16, device=dev)
+            dense(xf_out, ctx, xw, c, w[pre + "ek.w"], bias=w[pre + "ek.b"], out=kb, out_ld=c)
+            dense(xf_out, ctx, xw, c, w[pre + "ev.w"], bias=w[pre + "ev.b"], out=vb, out_ld=ctx, out_mode=ops.OUT_TRANSPOSED)
+            T.k.append(kb)
+            T.vt.append(vb)
+        need = max([ops.gemm_workspace_bytes(d) for d in descs] + [16])
+        T.gemm_ws = ops.new_gemm_workspace(need, dev)
+        for d in descs:
+            d.workspace = T.gemm_ws.data_ptr()
+            d.workspace_bytes = T.gemm_ws.numel() * 4
+        T.main, T.descs, T.arena, T.xf_out, T.R = main, descs, A, xf_out, R
+        self._text_plans[R] = T
+        return T
+
+    class _Loop:
+        pass
+
+    def begin_loop(self, N, H, W, t_values, tokens, mask, step_tokens=None, step_mask=None):
+        """Prepare a sampling loop of S = len(t_values) steps on N rows (see the block comment above).
+        tokens / mask [Pc, ctx]: the prompts of rows [0, Pc), the same at every step.  step_tokens / step_mask [S, ctx] (optional):
+        step k's prompt for ALL rows [Pc, N) (main_funcs.py:37-41: one random unconditional prompt per step, repeated over the
+        batch, guider.py:46-47); without them Pc must equal N.  t_values[k]: the timestep the UNet sees at step k.
+        Returns the context loop_step() takes; a later begin_loop() or forward_nhwc() on this plan invalidates it."""
+        P = self._plan(N, H, W)
+        dev = self.device
+        S = len(t_values)
+        tokens = torch.as_tensor(tokens).to(dev, torch.int32)
+        Pc = int(tokens.shape[0])
+        if step_tokens is None and Pc != N:
+            raise MdxError(f"begin_loop: {Pc} prompts for {N} rows and no per-step prompts for the rest")
+        if step_tokens is not None and not 0 < Pc < N:
+            raise MdxError(f"begin_loop: per-step prompts need 0 < constant prompts ({Pc}) < rows ({N})")
+        self._ensure_graphs(P)
+        if not hasattr(self, "_loop_epochs"):
+            self._loop_epochs = 0
+        self._loop_epochs += 1
+        L = Text2ImUNet._Loop()
+        L.epoch, L.N, L.Pc, L.S, L.plan = self._loop_epochs, N, Pc, S, P
+        ctx, xw, ted = self.text_ctx, self.xf_width, self.time_embed_dim
+        # ---- text tables
+        Tc = self._text_plan(Pc)
+        Tc.tok_static.copy_(tokens)
+        Tc.mask_static.copy_(torch.as_tensor(mask).to(dev, torch.int32))
+        for op in Tc.main:
+            op()
+        Tu = None
+        if step_tokens is not None:
+            Tu = self._text_plan(S)
+            Tu.tok_static.copy_(torch.as_tensor(step_tokens).to(dev, torch.int32))
+            if step_mask is None:
+                Tu.mask_static.fill_(1)
+            else:
+                Tu.mask_static.copy_(torch.as_tensor(step_mask).to(dev, torch.int32))
+            for op in Tu.main:
+                op()
+        # ---- emb table [S, N, emb_total]: the plan's three small ops on all S x N (timestep, last text token) rows
+        w = self.w
+        cat = torch.empty((S, N, ted + xw), dtype=f32, device=dev)
+        cat[:, :Pc, ted:] = Tc.last[None]
+        if Tu is not None:
+            cat[:, Pc:, ted:] = Tu.last[:, None]
+        cat2 = cat.view(S * N, ted + xw)
+        t_rows = torch.as_tensor([float(v) for v in t_values], dtype=f32, device=dev)[:, None].expand(S, N).contiguous().view(-1)
+        t_emb = ops.timestep_embedding(t_rows, self.model_channels)
+        ops.dense_small(t_emb, w["te0.w"], w["te0.b"], act_out=True, out=cat2[:, :ted])
+        emb = ops.dense_small(cat2, w["te2proj.w"], w["te2proj.b"], act_out=True)
+        L.emb_tab = ops.dense_small(emb, w["emb.w"], w["emb.b"]).view(S, N, self._emb_total)
+        # ---- key / value slots: the constant rows now, the per-step rows in loop_step
+        def slots(Tt):
+            ent = []
+            for j, (kbuf, vtb) in enumerate(P.kv_keep):
+                c, nk = kbuf.shape[2], kbuf.shape[1]
+                ent.append((Tt.k[j], kbuf, ctx * c * 2, nk * c * 2, c * 2, c * 2, ctx, c * 2))
+                ent.append((Tt.vt[j], vtb, c * ctx * 2, c * nk * 2, ctx * 2, nk * 2, c, ctx * 2))
+            return ops.glide_kv_slots(ent, dev)
+        L.tabs = (Tc, Tu)
+        if P.kv_keep:
+            sc, n = slots(Tc)
+            ops.glide_kv_select(sc, n, 0, 1, 0, Pc)
+            L.slots_c = sc
+            L.slots_u, L.nslots = slots(Tu) if Tu is not None else (None, n)
+        else:
+            L.slots_u, L.nslots = None, 0
+        P.text_epoch = None       # (the plan's own text prefix no longer describes what the key / value buffers hold)
+        P.loop_epoch = L.epoch
+        return L
+
+    def loop_step(self, L, k, x, low_res=None):
+        """Step k of a begin_loop() context: returns the plan's static NHWC fp16 output, like forward_nhwc."""
+        P = L.plan
+        if P.loop_epoch != L.epoch:
+            raise MdxError("loop_step: this loop context is stale (a later begin_loop / forward_nhwc used the plan)")
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            raise MdxError("x must be a CUDA(HIP) tensor (no CPU fallback)")
+        P.x_static.copy_(x)
+        if self.super_res:
+            if low_res is None:
+                raise MdxError("SuperResText2ImUNet needs low_res")
+            P.low_static.copy_(low_res)
+        P.emb_all.copy_(L.emb_tab[k])
+        if L.slots_u is not None:
+            ops.glide_kv_select(L.slots_u, L.nslots, k, 0, L.Pc, L.N - L.Pc)
+        if P.graph_body is not None:
+            P.graph_body.replay()
+        else:
+            for op in P.main[P.n_emb:]:
+                op()
         return P.out_nhwc
 
     def construct(self, x, timesteps, tokens=None, mask=None):

@@ -141,6 +141,10 @@ class _SamplerBase:
             c_cat = _first_tensor(cond["c_concat"])
             cond = cond["c_crossattn"]
             if isinstance(unconditional_conditioning, dict):
+                # WK plms.py:191-201 concatenates [uncond[k]; cond[k]] for EVERY dict key: an unconditional c_concat that differs from
+                # the conditional one goes into the unconditional half (inpaint.py passes the same tensor in both)
+                if unconditional_conditioning.get("c_concat") is not None:
+                    uc_cat = _first_tensor(unconditional_conditioning["c_concat"])
                 unconditional_conditioning = unconditional_conditioning["c_crossattn"]
         if key is None:
             cond = unconditional_conditioning = None

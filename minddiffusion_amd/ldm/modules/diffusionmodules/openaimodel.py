@@ -1042,6 +1042,7 @@ class UNetModel:
             for d in descs:
                 d.workspace = P.gemm_ws.data_ptr()
                 d.workspace_bytes = P.gemm_ws.numel() * 4
+        ops.check_colstats_wiring(descs)
         ops.account_gemm_launches(meta)     # last: the column-statistics wiring above can change a launch's table row
         P.main, P.ctxops, P.descs, P.meta = main, ctxops, descs, meta
         assert len(main) == len(meta)
@@ -1118,7 +1119,10 @@ class UNetModel:
             # construct(x, t) / construct(x, t, y=) of DiffusionWrapper keys None / 'concat' / 'adm' (WK ddpm.py:361-374): attn2's
             # to_k / to_v (Dense(context_dim, inner)) then see the block's own tokens, which only type-checks -- in the reference
             # as here -- when context_dim equals the transformer width at every attention level
-            bad = sorted({l[2] * l[3] for _, l in self._named_layers() if l[0] == "st" and l[2] * l[3] != self.context_dim})
+            if getattr(self, "_selfctx_bad", None) is None:      # (structure and context_dim are fixed at construction: checked once,
+                self._selfctx_bad = sorted({l[2] * l[3] for _, l in self._named_layers()      # not on every sampler step)
+                                            if l[0] == "st" and l[2] * l[3] != self.context_dim})
+            bad = self._selfctx_bad
             if bad:
                 raise MdxError(f"UNetModel: context=None makes attn2 attend to its own input (attention.py:133), which needs "
                                f"context_dim == transformer width; context_dim={self.context_dim}, widths {bad}")

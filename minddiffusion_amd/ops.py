@@ -260,6 +260,24 @@ def glide_step(x, out_c, out_u, ld, scale, coef8, mode, noise_scale, noise, x_ne
                "mdx_glide_step_f32")
 
 
+def glide_kv_slots(entries, device):
+    """Device array of struct mdx_glide_kv_slot (include/mdx.h) from (src, dst, src_entry_bytes, dst_batch_bytes, src_pitch,
+    dst_pitch, rows, row_bytes) tuples with tensor src / dst; returns (int64 tensor [n, 7] that holds the structs, n)."""
+    import numpy as np
+    rows = []
+    for src, dst, seb, dbb, sp, dp, r, rb in entries:
+        for v in (src.data_ptr(), dst.data_ptr(), seb, dbb, sp, dp, rb):
+            if v % 16:
+                raise _lib.MdxError("glide_kv_slots: pointers and byte counts must be multiples of 16")
+        rows.append([src.data_ptr(), dst.data_ptr(), seb, dbb, sp, dp, (int(r) & 0xffffffff) | (int(rb) << 32)])
+    return torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(device), len(rows)
+
+
+def glide_kv_select(slots, nslots, entry0, entry_per_b, b0, nb, blocks_per_copy=8):
+    _lib.check(_lib.load().mdx_glide_kv_select_f16(_ptr(slots), int(nslots), int(entry0), int(entry_per_b), int(b0), int(nb),
+                                                   int(blocks_per_copy), _stream()), "mdx_glide_kv_select_f16")
+
+
 def layernorm(x, gamma, beta, eps, out=None):
     _chk(x, f16, "x"); _chk(gamma, f32, "gamma"); _chk(beta, f32, "beta")
     C = x.shape[-1]
@@ -418,11 +436,23 @@ def gemm_workspace_bytes(desc):
     return int(_lib.load().mdx_gemm_workspace_bytes(ctypes.byref(desc)))
 
 
+_WS_HEAD = 16384      # MDX_GEMM_WS_HEAD (include/mdx.h): bytes of arrival counters per workspace
+
+
 def new_gemm_workspace(nbytes, device):
-    """A split-K workspace for mdx_gemm_f16 (fp32).  Needs no initialisation -- the arrival counters of the in-kernel split-K
-    reduce are library-owned (include/mdx.h, mdx_gemm_desc.workspace); zero-filled anyway so that a partial read before it is
-    written would at least be deterministic."""
-    return torch.zeros(max(int(nbytes), 16) // 4 + 1, dtype=f32, device=device)
+    """A split-K workspace for mdx_gemm_f16 (fp32) with its arrival counters: ONE zeroed torch allocation [16 KiB of counters |
+    workspace], the counters bound to the workspace address (mdx_gemm_bind_counters) -- so libmdx.so allocates no device memory
+    for launches on it (include/mdx.h, ownership rule) -- and unbound when the tensor dies (before the caching allocator can hand
+    the address to anything else).  The workspace itself needs no initialisation."""
+    import weakref
+    base = torch.zeros((_WS_HEAD + max(int(nbytes), 16)) // 4 + 1, dtype=f32, device=device)
+    ws = base[_WS_HEAD // 4:]
+    lib = _lib.load()
+    _lib.check(lib.mdx_gemm_bind_counters(ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(base.data_ptr())),
+               "mdx_gemm_bind_counters")
+    # unbind when the workspace tensor object dies (the plans hold exactly this object; its storage cannot be freed earlier)
+    weakref.finalize(ws, lib.mdx_gemm_release_workspace, ctypes.c_void_p(ws.data_ptr()))
+    return ws
 
 
 def gemm_query(desc):
@@ -731,6 +761,7 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
                 return None
             buf = torch.zeros((batch * (HW // rows), cx, 2), dtype=f32, device=device)
             d.colstats_out, d.colstats_cap = buf.data_ptr(), batch * (HW // rows)
+            d._cs_rows = rows       # (python-side) what the buffer was sized for: check_colstats_wiring() re-asks after the final sizing
             if HW // rows > 64 and not is_head and fold_many:
                 # > 64 row blocks per sample (GLIDE's 128 x 128 / 256 x 256 levels: 512 HALO patches): folding them in EVERY
                 # gn_apply block cost more than the statistics pass it saved (profiles/r02_e_ab.txt); they are folded ONCE by
@@ -797,6 +828,22 @@ def wire_groupnorm_colstats(gn_calls, meta, batch, device, table):
 
 # ---------------------------------------------------------------------------------------------------------------
 # Row-local fused SpatialTransformer tail (include/mdx.h: mdx_st_tail_f16, csrc/stchain.hip)
+def check_colstats_wiring(descs):
+    """Called by the planners AFTER the shared split-K workspace has its final size: wire_groupnorm_colstats sized every statistics
+    buffer for the row blocks the launch reports under an AMPLE workspace (its ideal form); the launch takes that form only if
+    the final workspace really holds it.  A planner that kept the first-sized workspace would fail at its first launch with a
+    colstats_cap mismatch -- fail here instead, with the descriptor named."""
+    for d in descs:
+        rows = getattr(d, "_cs_rows", None)
+        if rows is None or not d.colstats_out:
+            continue
+        now = gemm_query(d)[5]
+        if now != rows:
+            raise _lib.MdxError(f"GroupNorm statistics wiring: the launch M={d.B * d.H * d.W} N={d.N} k{d.ksize} writes {now}-row "
+                                f"blocks under the final workspace ({d.workspace_bytes} bytes) but its statistics buffer was sized "
+                                f"for {rows}-row blocks: size the workspace from gemm_workspace_bytes() AFTER the wiring pass")
+
+
 def pack_frag_weight(w2d):
     """[N, K] nn.Dense weight -> MFMA-fragment-major pieces [N/32 column tiles][K/16 k-steps][64 lanes * 8 halves]:
     piece (ct, s)[lane] = W[32 ct + lane % 32][16 s + 8 (lane // 32) + 0..7] -- the first operand of

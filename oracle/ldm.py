@@ -591,11 +591,14 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
     assert tuple(img.shape) == (b,) + tuple(shape)
     # dict conditioning = hybrid (WK inpaint.py:84-88): {"c_concat": [B,5,h,w], "c_crossattn": [B,T,D]}; the uncond dict
     # carries the SAME c_concat (inpaint.py:87-88), WK plms.py:188-205 concatenates key by key
-    c_cat = None
+    c_cat = uc_cat = None
     if isinstance(conditioning, dict):
         c_cat = torch.as_tensor(conditioning["c_concat"], dtype=torch.float32)
         conditioning = conditioning["c_crossattn"]
         if isinstance(unconditional_conditioning, dict):
+            # WK plms.py:191-201: [uncond[k]; cond[k]] for EVERY key -- the unconditional c_concat may differ from the conditional one
+            if unconditional_conditioning.get("c_concat") is not None:
+                uc_cat = torch.as_tensor(unconditional_conditioning["c_concat"], dtype=torch.float32)
             unconditional_conditioning = unconditional_conditioning["c_crossattn"]
     def as_cond(c):     # text context / extra input channels: fp32; class labels ('adm'): integers stay integers
         if c is None:
@@ -608,7 +611,10 @@ def sample(model, S, batch_size, shape, conditioning, x_T, sampler="plms", eta=0
         x0 = torch.as_tensor(x0, dtype=torch.float32)
 
     def wrap(c, n):
-        return c if c_cat is None else {"c_concat": torch.cat([c_cat] * n, 0), "c_crossattn": c}
+        if c_cat is None:
+            return c
+        parts = [c_cat] * n if (n == 1 or uc_cat is None) else [uc_cat, c_cat]      # batch = [uncond ; cond]
+        return {"c_concat": torch.cat(parts, 0), "c_crossattn": c}
     time_range = np.flip(ts)
     total = len(ts)
     intermediates = {"x_inter": [img], "pred_x0": [img]}

@@ -322,7 +322,7 @@ def test_inpaint_wukong_full_size():
                                        unconditional_conditioning={"c_concat": dev(inp["c_cat"]), "c_crossattn": dev(inp["uc"])},
                                        x0=dev(inp["c_cat"][:, 1:]), verbose=False)     # inpaint.py:104 passes x0 and no mask
     assert net._plans[(2 * B, 64, 64)].graph is not None, "the sampler replays a hipGraph of the 9-channel UNet at batch 8"
-    check("inpaint_wukong_full_plms30_B4_image0", got[:1], torch.tensor(z["final"].astype(np.float32)), rel_l2=1e-2, max_rel=2e-2)
+    check("inpaint_wukong_full_plms30_B4_image0", got[:1], torch.tensor(z["final"].astype(np.float32)), rel_l2=5e-3, max_rel=2e-2)
 
 
 # --------------------------------------------------------------------------------------------- config 3: SDv2 768, 4 images / GPU

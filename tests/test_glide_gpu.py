@@ -228,6 +228,97 @@ def test_tiny_p_sample_loop():
     check("glide_tiny_p_sample_loop", got, ref, rel_l2=1e-2)      # measured 4.2e-3 (round 2)
 
 
+def test_loop_tables_are_bit_identical_to_per_step_recomputation():
+    """Round 6 (Text2ImUNet.begin_loop): text transformer, encoder_kv projections and the time-embedding chain of ALL steps run
+    once per loop; a step copies its rows (mdx_glide_kv_select_f16) and replays the plan's body.  Same kernels on the same values:
+    the loop must end on the SAME BITS as the loop that recomputes everything every step -- base model (per-step random
+    unconditional prompts, a padded conditional prompt) and up-sampler -- and a step whose prompt is not the announced one must
+    fall back to the full evaluation, not serve the table."""
+    from minddiffusion_amd.glide import diffusion_creator as DC
+    from minddiffusion_amd.glide.main_funcs import ddim_sample_loop, gaussian_p_sample_loop
+    params = OG.init_params(OTINY, seed=2)
+    P, steps = 2, 10
+    dm = DC.init_diffusion_model(options=TINY, guidance_scale=3.0, shape=(2 * P, 3, 16, 16), params=params)
+    rng = np.random.RandomState(41)
+    x_T = rng.randn(P, 3, 16, 16).astype(np.float32)
+    tok = rng.randint(1, 99, (P, 16)).astype(np.int32)
+    mask = np.ones((P, 16), np.int32)
+    mask[1, 9:] = 0                                                     # a padded prompt: the padding embedding rows
+    unc = rng.randint(1, 99, (steps, 16)).astype(np.int32)
+    noises = [torch.tensor(n, device=DEV) for n in rng.randn(steps, P, 3, 16, 16).astype(np.float32)]
+    tok2, mask2 = torch.tensor(np.concatenate([tok, tok], 0)), torch.tensor(np.concatenate([mask, mask], 0))
+    x2 = torch.tensor(np.concatenate([x_T, x_T], 0))
+    run = lambda: gaussian_p_sample_loop(dm, tok2, mask2, (2 * P, 3, 16, 16), steps, text_ctx=16, noise=x2, vocab_len=100,
+                                         uncond_tokens=list(unc), step_noises=noises)[:P].clone()
+    keep = DC._LOOP_TABLES
+    try:
+        DC._LOOP_TABLES = True
+        calls = []
+        orig = dm.model.loop_step
+        dm.model.loop_step = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        fast = run()
+        dm.model.loop_step = orig
+        assert len(calls) == steps, f"the loop took the table path on {len(calls)} of {steps} steps"
+        DC._LOOP_TABLES = False
+        slow = run()
+        assert torch.equal(fast, slow), float((fast - slow).abs().max())
+        # a step that is handed ANOTHER unconditional prompt than the announced one is evaluated in full
+        DC._LOOP_TABLES = True
+        dm.begin_loop(tok2, mask2, unc)
+        other = (unc[0] + 3) % 90 + 1
+        a, _ = dm(x=x2.to(DEV), timesteps=torch.tensor([steps - 1], dtype=torch.int32), token=tok2, mask=mask2,
+                  random_token=other, random_mask=np.ones((16,), np.int32), noise=noises[0])
+        dm.end_loop()
+        b, _ = dm(x=x2.to(DEV), timesteps=torch.tensor([steps - 1], dtype=torch.int32), token=tok2, mask=mask2,
+                  random_token=other, random_mask=np.ones((16,), np.int32), noise=noises[0])
+        assert torch.equal(a, b)
+        # ---- up-sampler (constant prompts; S = 27 timesteps)
+        opts = dict(TINY, image_size=32, channel_mult=(1, 1, 2), noise_schedule="linear", timestep_respacing="fast27", low_size=8)
+        oopts = dict(OTINY, in_channels=6, image_size=32, channel_mult=(1, 1, 2), noise_schedule="linear",
+                     timestep_respacing="fast27")
+        sr = DC.init_super_res_model(options=opts, shape=(P, 3, 32, 32), params=OG.init_params(oopts, seed=4))
+        x = torch.tensor(rng.randn(P, 3, 32, 32).astype(np.float32) * 0.997)
+        low = torch.tensor(np.clip(rng.randn(P, 3, 8, 8) * 0.5, -1, 1).astype(np.float32), device=DEV)
+        tk, mk = torch.tensor(tok), torch.tensor(mask)
+        up = lambda: ddim_sample_loop(sr, (P, 3, 32, 32), low, tk, mk, 27, noise=x).clone()
+        DC._LOOP_TABLES = True
+        f2 = up()
+        DC._LOOP_TABLES = False
+        s2 = up()
+        assert torch.equal(f2, s2), float((f2 - s2).abs().max())
+    finally:
+        DC._LOOP_TABLES = keep
+
+
+def test_glide_kv_select_kernel():
+    """mdx_glide_kv_select_f16: table entries -> the text slots of key / transposed-value buffers, broadcast (entry_per_b = 0) and
+    per-row (entry_per_b = 1) forms, several slots of different widths in one launch; everything else in the buffers untouched."""
+    from minddiffusion_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    S, B, ctx = 5, 6, 16
+    ent, bufs = [], []
+    for c, T in ((64, 40), (96, 8), (128, 24)):
+        nk = ctx + T
+        kt = torch.randn((S, ctx, c), device=DEV, generator=g).half()
+        vt = torch.randn((S, c, ctx), device=DEV, generator=g).half()
+        kb = torch.randn((B, nk, c), device=DEV, generator=g).half()
+        vb = torch.randn((B, c, nk), device=DEV, generator=g).half()
+        ent.append((kt, kb, ctx * c * 2, nk * c * 2, c * 2, c * 2, ctx, c * 2))
+        ent.append((vt, vb, c * ctx * 2, c * nk * 2, ctx * 2, nk * 2, c, ctx * 2))
+        bufs.append((kt, vt, kb, vb, kb.clone(), vb.clone()))
+    slots, n = ops.glide_kv_slots(ent, DEV)
+    ops.glide_kv_select(slots, n, 3, 0, 2, 3)           # rows 2..4 <- entry 3
+    ops.glide_kv_select(slots, n, 1, 1, 0, 2, blocks_per_copy=3)     # rows 0, 1 <- entries 1, 2
+    torch.cuda.synchronize()
+    for kt, vt, kb, vb, kb0, vb0 in bufs:
+        ek, ev = kb0.clone(), vb0.clone()
+        ek[2:5, :ctx] = kt[3]
+        ev[2:5, :, :ctx] = vt[3]
+        ek[0, :ctx], ek[1, :ctx] = kt[1], kt[2]
+        ev[0, :, :ctx], ev[1, :, :ctx] = vt[1], vt[2]
+        assert torch.equal(kb, ek) and torch.equal(vb, ev)
+
+
 def test_tiny_p_sample_loop_60_steps():
     """The benchmarked LENGTH of the base loop (main_funcs.py:21-44 with timestep_respacing "60"): sixty guided ancestral
     steps with a fresh random unconditional prompt and fresh noise per step, on the tiny model (the oracle runs 120 rows)."""

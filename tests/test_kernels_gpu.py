@@ -373,6 +373,41 @@ def test_gemm_release_workspace_reuses_the_counters_under_a_recaptured_graph(ops
     assert lib.mdx_gemm_release_workspace(ctypes_ptr(ws2)) == 1
 
 
+def test_gemm_caller_owned_arrival_counters(ops):
+    """include/mdx.h mdx_gemm_bind_counters: a caller that owns every byte binds MDX_GEMM_WS_HEAD zeroed bytes to its workspace; the
+    in-kernel split-K reduce takes its tickets there and leaves them zero (a poisoned counter would prove the use, but it can reach
+    the kernel's corrupted-counter trap, which takes the process down), results equal the library-owned form bit for bit, release
+    only unbinds."""
+    from minddiffusion_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(29)
+    M, N, K = 256, 640, 2560
+    a = dev16(h16(rng.standard_normal((M, K))))
+    w = pack_dense(h16(rng.standard_normal((N, K)) / math.sqrt(K)))
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    n_ws = 16384 // 4 + 3 * 256 * 640 + 64
+    ws_lib = torch.full((n_ws,), float("nan"), dtype=torch.float32, device=DEV)          # library-owned counters
+    d0 = ops.make_gemm_desc(a, w, N, M, 1, 1, K, out, N, splitk=3, workspace=ws_lib)
+    assert ops.gemm_query(d0)[6] == 1
+    ops.gemm_run(d0)
+    torch.cuda.synchronize()
+    ref_bits = out.clone()
+    ws = torch.full((n_ws,), float("nan"), dtype=torch.float32, device=DEV)
+    counters = torch.zeros(16384 // 4, dtype=torch.int32, device=DEV)
+    _lib.check(lib.mdx_gemm_bind_counters(ctypes_ptr(ws), ctypes_ptr(counters)), "bind")
+    _lib.check(lib.mdx_gemm_bind_counters(ctypes_ptr(ws), ctypes_ptr(counters)), "bind again (no-op)")
+    d1 = ops.make_gemm_desc(a, w, N, M, 1, 1, K, out, N, splitk=3, workspace=ws)
+    for _ in range(3):
+        out.zero_()
+        ops.gemm_run(d1)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref_bits)
+        assert int(counters.abs().sum()) == 0            # every launch leaves them zero
+    assert lib.mdx_gemm_release_workspace(ctypes_ptr(ws)) == 1
+    assert lib.mdx_gemm_release_workspace(ctypes_ptr(ws)) == 0
+    assert lib.mdx_gemm_release_workspace(ctypes_ptr(ws_lib)) == 1
+
+
 def ctypes_ptr(t):
     import ctypes
     return ctypes.c_void_p(t.data_ptr())

@@ -7,7 +7,8 @@ host time for the GPU box, which is why round 3 only had 3-10 step versions of t
   config 3  SDv2, 96 x 96 latent, DDIM-50, CFG 7.5, 4 images               (configs[3] per-GPU share); image 0
   config 4  Taichu-GLIDE base 60 guided ancestral steps at 2P = 16 + up-sampler 27 DDIM steps at P = 8 on 256 x 256 (configs[4] share)
 
-Bar: rel-L2 <= 1e-2 at the latent level "after 50 steps".  Every fixture also carries the fp16-EMULATED oracle's end
+Bar: rel-L2 <= 5e-3 at the latent level "after 50 steps" for the latent-diffusion configs (measured 1.9e-3), 6e-3 for the two
+Taichu-GLIDE loops (measured 4.6e-3 / 3.8e-3; round 6 -- the bars were 1e-2 until then).  Every fixture also carries the fp16-EMULATED oracle's end
 point where it was run: d(fp32 oracle, fp16-emulated oracle) is logged beside the GPU's distances (what a reference running its shipped
 `use_fp16: True` would itself measure against the fp32 oracle).  Inputs are rebuilt from the seeds by the same functions the fixture
 script used (tests/golden/make_trajectory_goldens.py: inputs_config*).
@@ -79,8 +80,8 @@ def test_config1_sd2_512_ddim50_cfg9_full_size_vs_fixture():
                                            unconditional_guidance_scale=inp["scale"], unconditional_conditioning=dev(inp["uc"]),
                                            verbose=False)
     assert net._plans[(2, 64, 64)].graph is not None, "the benchmarked path replays a hipGraph"
-    check("traj_config1_sd2_512_ddim50_cfg9_latent", got, z["final"].astype(np.float32), rel_l2=1e-2, max_rel=2e-2)
-    check("traj_config1_sd2_512_ddim50_cfg9_pred_x0", inter["pred_x0"][-1], z["pred_x0"].astype(np.float32), rel_l2=1e-2)
+    check("traj_config1_sd2_512_ddim50_cfg9_latent", got, z["final"].astype(np.float32), rel_l2=5e-3, max_rel=2e-2)
+    check("traj_config1_sd2_512_ddim50_cfg9_pred_x0", inter["pred_x0"][-1], z["pred_x0"].astype(np.float32), rel_l2=5e-3)
     _three_way("config1_sd2_512_ddim50", got.cpu(), z, meta)
 
 
@@ -96,7 +97,7 @@ def test_config2_wukong_plms50_batch8_full_size_vs_fixture():
                                        unconditional_guidance_scale=inp["scale"],
                                        unconditional_conditioning={"c_crossattn": [dev(inp["uc"])]}, verbose=False)
     assert net._plans[(16, 64, 64)].graph is not None
-    check("traj_config2_wukong_plms50_B8_image0", got[:1], z["final"].astype(np.float32), rel_l2=1e-2, max_rel=2e-2)
+    check("traj_config2_wukong_plms50_B8_image0", got[:1], z["final"].astype(np.float32), rel_l2=5e-3, max_rel=2e-2)
     _three_way("config2_wukong_plms50", got[:1].cpu(), z, meta)
 
 
@@ -112,7 +113,7 @@ def test_config3_sd2_768_ddim50_batch4_full_size_vs_fixture():
                                        unconditional_guidance_scale=inp["scale"], unconditional_conditioning=dev(inp["uc"]),
                                        verbose=False)
     assert net._plans[(8, 96, 96)].graph is not None
-    check("traj_config3_sd2_768_ddim50_B4_image0", got[:1], z["final"].astype(np.float32), rel_l2=1e-2, max_rel=2e-2)
+    check("traj_config3_sd2_768_ddim50_B4_image0", got[:1], z["final"].astype(np.float32), rel_l2=5e-3, max_rel=2e-2)
     _three_way("config3_sd2_768_ddim50", got[:1].cpu(), z, meta)
 
 
@@ -143,7 +144,7 @@ def test_config4_glide_60_plus_27_full_size_vs_fixture():
                                   uncond_tokens=list(inp["unc"]), step_noises=[torch.tensor(n, device=DEV) for n in noises])[:P]
     # measured on MI355X (round 4): rel-L2 4.8e-3, 98 % of |d| <= 1.3e-2, max 3.1e-2 -- the 60-step schedule's fine steps contract
     # where the 10-step loop of test_configs_gpu.py (1.9e-2) does not
-    check("traj_config4_glide_base60_P8_image0", base[:1], z["base_final"].astype(np.float32), rel_l2=1e-2, abs_q=(0.98, 2e-2))
+    check("traj_config4_glide_base60_P8_image0", base[:1], z["base_final"].astype(np.float32), rel_l2=6e-3, abs_q=(0.98, 2e-2))
     del dm, bp
     torch.cuda.empty_cache()
     up = OG.init_params(OG.UPSAMPLE_OPTIONS, seed=1)
@@ -154,4 +155,4 @@ def test_config4_glide_60_plus_27_full_size_vs_fixture():
     up_x = np.concatenate([inp["up_x_T"], (rng.randn(P - 1, 3, 256, 256) * 0.997).astype(np.float32)], 0)
     got = ddim_sample_loop(sr, (P, 3, 256, 256), low.to(DEV), torch.tensor(tok), torch.tensor(mask), 27, noise=torch.tensor(up_x))
     # measured: rel-L2 3.8e-3, 98 % of |d| <= 6.8e-3 (max 0.36: a handful of elements at the +-1 clip)
-    check("traj_config4_glide_upsampler27_P8_image0", got[:1], z["up_final"].astype(np.float32), rel_l2=1e-2, abs_q=(0.98, 2e-2))
+    check("traj_config4_glide_upsampler27_P8_image0", got[:1], z["up_final"].astype(np.float32), rel_l2=6e-3, abs_q=(0.98, 2e-2))

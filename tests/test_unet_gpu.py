@@ -241,6 +241,36 @@ def test_tiny_inpaint_hybrid_trajectory(blend):
     check("tiny_inpaint_apply_model", e, eo, rel_l2=5e-3, max_abs=5e-2)
 
 
+def test_tiny_inpaint_hybrid_unconditional_c_concat_may_differ():
+    """WK plms.py:191-201 concatenates [uncond[k]; cond[k]] for every dict key: an unconditional c_concat that differs from the
+    conditional one (inpaint.py passes the same tensor in both, so nothing else exercises it) must reach the unconditional half of
+    the CFG batch.  Oracle = the same key-by-key concatenation; also checked: the result is NOT what the shared-c_concat run gives."""
+    from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentInpaintDiffusion
+    from minddiffusion_amd.ldm.models.diffusion.plms import PLMSSampler
+    cfg = dict(_tiny_cfg(), in_channels=9)
+    params = O.init_params(_oracle_cfg(cfg), seed=6)
+    net = _build(cfg, params, True)
+    model = LatentInpaintDiffusion(unet_config=net, linear_start=0.00085, linear_end=0.0120, timesteps=1000)
+    omodel = O.ModelOracle(O.UNetOracle(_oracle_cfg(cfg), params))
+    B, H, W, T, S = 2, 8, 8, 6, 5
+    rng = np.random.RandomState(18)
+    x_T = rng.randn(B, 4, H, W).astype(np.float32)
+    c = rng.randn(B, T, cfg["context_dim"]).astype(np.float32)
+    uc = np.repeat(rng.randn(1, T, cfg["context_dim"]).astype(np.float32), B, 0)
+    c_cat = np.concatenate([(rng.rand(B, 1, H, W) > 0.5).astype(np.float32), rng.randn(B, 4, H, W).astype(np.float32)], 1)
+    uc_cat = np.concatenate([np.ones((B, 1, H, W), np.float32), np.zeros((B, 4, H, W), np.float32)], 1)
+    ref, _ = O.sample(omodel, S, B, (4, H, W), {"c_concat": c_cat, "c_crossattn": c}, x_T, "plms", unconditional_guidance_scale=7.5,
+                      unconditional_conditioning={"c_concat": uc_cat, "c_crossattn": uc})
+    dev = lambda a: torch.tensor(a, device=DEV)
+    run = lambda ucc: PLMSSampler(model).sample(S, B, (4, H, W), conditioning={"c_concat": dev(c_cat), "c_crossattn": dev(c)},
+                                                x_T=dev(x_T), unconditional_guidance_scale=7.5,
+                                                unconditional_conditioning={"c_concat": dev(ucc), "c_crossattn": dev(uc)},
+                                                verbose=False)[0]
+    got, same = run(uc_cat), run(c_cat)
+    check("tiny_inpaint_hybrid_uncond_c_concat_differs", got, ref, rel_l2=1e-2, max_rel=1e-2)
+    assert float((got - same).norm() / same.norm()) > 5e-2, "the unconditional c_concat did not reach the unconditional half"
+
+
 def test_groupnorm_folds_into_proj_in_where_the_plan_says_so():
     """Planner option unet_gn_proj_fuse: SpatialTransformer.norm moves into proj_in (one launch less per transformer block, no
     normalised copy).  The fused plan has fewer ops than the unfused one, at least one launch carries "+groupnorm(in)", and both
