@@ -61,6 +61,8 @@ const char* mdx_last_error(void);
  *   gn_prefetch (1)  gemm_ln_prefetch (1): round-5 "latency diet" -- parameters that are cold in HBM (GroupNorm gamma / beta /
  *   FiLM rows, LayerNorm-fold S[n] and row statistics) are fetched at the top of the kernel instead of behind the dependency
  *   they used to follow; 0 restores the round-4 order for A/B runs (same results bit for bit either way)
+ *   gemm_lean_dense (1): round 6 -- dense row-major launches run the lean kernel of csrc/dense.hip (same tile program and bits as the
+ *   generic kernel; division-free prologue, the epilogue's global reads prefetched before the K loop); 0 = generic kernel, for A/B runs
  *   (the full list with defaults: csrc/mdx_common.h enum MdxOpt)
  * Unknown names return MDX_E_INVALID. */
 int mdx_set_option(const char* name, int value);
@@ -256,7 +258,7 @@ size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d);
 /* Host-only validation of a descriptor (no launch): MDX_OK or MDX_E_INVALID with mdx_last_error() set. */
 int mdx_gemm_check(const mdx_gemm_desc* d);
 /* What mdx_gemm_f16 WOULD launch for this descriptor (host only, nothing is launched):
- * out7 = {tile_m, tile_n, splitk, kernel (0 = generic implicit GEMM, 1 = HALO 3x3 conv), 1 if the choice came from the
+ * out7 = {tile_m, tile_n, splitk, kernel (0 = generic implicit GEMM, 1 = HALO 3x3 conv, 2 = the lean dense kernel), 1 if the choice came from the
  * measured tile table csrc/gemm_tuned.inc, rows per colstats_out row block (0 = this launch cannot produce column
  * statistics), 1 if a split launch reduces in the kernel (no reduce launch follows)}.  The parity tests assert with it that
  * the table rows are hit at the benchmarked shapes. */

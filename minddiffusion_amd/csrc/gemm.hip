@@ -1931,8 +1931,69 @@ static int colstats_rows(const GemmParams& p, const Resolved& r) {
     return p.HoWo % r.c.bm == 0 ? r.c.bm : 0;
 }
 
+// Launches the lean dense kernel (dense.hip) covers: dense (ksize 1, stride 1, one source, K tiles of whole 64-channel chunks),
+// row-major through the staged epilogue (unsplit or in-kernel reduce), four waves, plain / GEGLU epilogue, no per-sample row bias,
+// no out_bs, not the GroupNorm-on-A form; tile ids must fit the multiply-high decode.
+static bool lean_dense_eligible(const GemmParams& p, bool swap, bool fastk, bool nw8, int ntiles) {
+    if (!mdx_opt(MDX_OPT_GEMM_LEAN_DENSE) || !p.dense_issue) return false;
+    if (!(p.ksize == 1 && p.stride == 1 && !p.upsample && p.c2 == 0 && fastk && swap && !nw8)) return false;
+    if (p.gn_cs || p.rowbias || p.out_bs || p.skip_w) return false;
+    if (p.epilogue != MDX_EPI_NONE && p.epilogue != MDX_EPI_GEGLU) return false;
+    // buffer descriptors of the epilogue prefetches: 32-bit offsets
+    if ((size_t)p.M * (size_t)(p.residual ? p.residual_ld : 0) * 2 >= 0x80000000ull) return false;
+    if (p.ln_stats && (size_t)p.M * (size_t)p.ln_nt * 8 >= 0x80000000ull) return false;
+    return ntiles < 65536 && p.tiles_m < 65536 && p.tiles_n < 65536;
+}
+
+// Tile grid, ring depth and kernel form of a resolved launch of the generic / lean dense / HALO kernels (not conv8p): shared by
+// mdx_gemm_f16 and mdx_gemm_query, which reports the form.
+struct LaunchGeom {
+    dim3 grid;
+    int ntiles, ring, st_req;
+    bool fastk, nw8, swap, lean;
+};
+
+static bool lean_dense_has(int bm, int bn, int ring) {      // the instantiations dense.hip carries (launch_dense_ns)
+    if (ring < 2) return false;
+    if (bm == 64) return ring <= 6;
+    if (bm == 128 && bn == 64) return ring <= 4;
+    return bm == 128 && bn == 128 && ring <= 3;
+}
+
+static int launch_geometry(GemmParams& p, const Resolved& rs, LaunchGeom& g) {
+    const GemmCfg& c = rs.c;
+    const int bn = rs.bn, ns = rs.ns;
+    p.tiles_m = (p.M + c.bm - 1) / c.bm;
+    p.tiles_n = (p.N + bn - 1) / bn;
+    g.fastk = (p.cin % 64 == 0) && (p.c2 == 0 || p.c1 % 64 == 0);
+    MDX_REQUIRE(g.fastk || p.c2 == 0, "mdx_gemm_f16: two-source input needs c1 %% 64 == 0 and Cin %% 64 == 0");
+    g.ntiles = p.tiles_m * p.tiles_n;
+    p.tiles_per_xcd = (g.ntiles + 7) / 8;
+    p.inv_tiles_n = p.tiles_n > 1 ? (unsigned)((0x100000000ull + (unsigned)p.tiles_n - 1) / (unsigned)p.tiles_n) : 0u;
+    p.inv_tiles_m = p.tiles_m > 1 ? (unsigned)((0x100000000ull + (unsigned)p.tiles_m - 1) / (unsigned)p.tiles_m) : 0u;
+    p.res_bytes = p.residual ? (unsigned)std::min<size_t>((size_t)p.M * (size_t)p.residual_ld * 2, 0x7fffffffull) : 0u;
+    // share the bigger operand inside an XCD: unique activation bytes vs weight bytes
+    p.n_fastest = ((size_t)p.M * p.cin >= (size_t)p.N * p.K) ? 1 : 0;
+    g.grid = dim3(8 * p.tiles_per_xcd, ns);
+    p.spread = (p.tiles_m == 1 && mdx_opt(MDX_OPT_GEMM_SPREAD)) ? 1 : 0;
+    if (p.spread) g.grid = dim3(g.ntiles * ns, 1);
+    g.ring = c.ns;
+    g.nw8 = rs.stages >= 10;                           // eight waves per block (generic kernel, 128-row tiles)
+    g.st_req = g.nw8 ? rs.stages - 8 : rs.stages;      // requested ring depth (0 = the rule below)
+    if (!(mdx_opt(MDX_OPT_GEMM_RING) >= 2 && mdx_opt(MDX_OPT_GEMM_RING) <= 5)) {
+        // ring depth: three stages wherever they still leave two blocks per CU (every tile but 128 x 128: 3 x 24 KB), and for
+        // 128 x 128 tiles when the grid has at most one block per CU anyway; otherwise two.  tools/tune_gemm.py measures both
+        // depths per shape (round 2: 143 of 153 retuned rows chose three) and the table overrides this rule.
+        g.ring = (g.ntiles * ns <= 256 || c.bm + bn <= 192) ? 3 : 2;
+        if (g.st_req >= 2 && g.st_req <= 6) g.ring = g.st_req;
+    }
+    g.swap = (ns == 1 || rs.fixup) && (p.out_mode == MDX_OUT_ROWMAJOR);
+    g.lean = !rs.halo && lean_dense_eligible(p, g.swap, g.fastk, g.nw8, g.ntiles) && lean_dense_has(c.bm, bn, g.ring);
+    return MDX_OK;
+}
+
 // What mdx_gemm_f16 would launch for this descriptor (no launch): out7 = {tile_m, tile_n, splitk, kernel (0 generic implicit
-// GEMM, 1 HALO conv), from_tuned_table, colstats rows per block, in-kernel split-K reduce}.  Parity tests use it to assert that the measured tile table
+// GEMM, 1 HALO conv, 2 lean dense kernel of dense.hip), from_tuned_table, colstats rows per block, in-kernel split-K reduce}.  Parity tests use it to assert that the measured tile table
 // (gemm_tuned.inc) is actually hit at the benchmarked shapes; the UNet plan asks it where GroupNorm statistics can come from.
 extern "C" int mdx_gemm_query(const mdx_gemm_desc* d, int* out7) {
     GemmParams p{};
@@ -1945,7 +2006,14 @@ extern "C" int mdx_gemm_query(const mdx_gemm_desc* d, int* out7) {
     out7[0] = r.c.bm;
     out7[1] = r.bn;
     out7[2] = r.ns;
-    out7[3] = r.halo ? 1 : 0;
+    int form = r.halo ? 1 : 0;
+    if (!r.c8 && !r.halo) {
+        LaunchGeom lg;
+        rc = launch_geometry(p, r, lg);
+        if (rc != MDX_OK) return rc;
+        if (lg.lean) form = 2;
+    }
+    out7[3] = form;
     out7[4] = r.tuned ? 1 : 0;
     out7[5] = colstats_rows(p, r);
     out7[6] = r.fixup ? 1 : 0;
@@ -2014,29 +2082,16 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
         const int trc = ticket_slot(d->workspace, &p.tickets);
         if (trc != MDX_OK) return trc;
     }
-    p.tiles_m = (p.M + c.bm - 1) / c.bm;
-    p.tiles_n = (p.N + bn - 1) / bn;
-    const bool fastk = (p.cin % 64 == 0) && (p.c2 == 0 || p.c1 % 64 == 0);
-    MDX_REQUIRE(fastk || p.c2 == 0, "mdx_gemm_f16: two-source input needs c1 %% 64 == 0 and Cin %% 64 == 0");
-    const int ntiles = p.tiles_m * p.tiles_n;
-    p.tiles_per_xcd = (ntiles + 7) / 8;
-    // share the bigger operand inside an XCD: unique activation bytes vs weight bytes
-    p.n_fastest = ((size_t)p.M * p.cin >= (size_t)p.N * p.K) ? 1 : 0;
-    dim3 grid(8 * p.tiles_per_xcd, ns);
-    p.spread = (p.tiles_m == 1 && mdx_opt(MDX_OPT_GEMM_SPREAD)) ? 1 : 0;
-    if (p.spread) grid = dim3(ntiles * ns, 1);
+    LaunchGeom lg;
+    rc = launch_geometry(p, rs, lg);
+    if (rc != MDX_OK) return rc;
+    const bool fastk = lg.fastk, nw8 = lg.nw8, swap = lg.swap;
+    const int ntiles = lg.ntiles;
+    dim3 grid = lg.grid;
     p.trace = (g_gemm_trace && (size_t)grid.x * grid.y <= g_gemm_trace_slots) ? g_gemm_trace : nullptr;
     GemmCfg cc = c;
-    const bool nw8 = rs.stages >= 10;                      // eight waves per block (generic kernel, 128-row tiles)
-    const int st_req = nw8 ? rs.stages - 8 : rs.stages;    // requested ring depth (0 = the rule below)
-    if (!(mdx_opt(MDX_OPT_GEMM_RING) >= 2 && mdx_opt(MDX_OPT_GEMM_RING) <= 5)) {
-        // ring depth: three stages wherever they still leave two blocks per CU (every tile but 128 x 128: 3 x 24 KB), and for
-        // 128 x 128 tiles when the grid has at most one block per CU anyway; otherwise two.  tools/tune_gemm.py measures both
-        // depths per shape (round 2: 143 of 153 retuned rows chose three) and the table overrides this rule.
-        cc.ns = (ntiles * ns <= 256 || c.bm + bn <= 192) ? 3 : 2;
-        if (st_req >= 2 && st_req <= 6) cc.ns = st_req;
-    }
-    const bool swap = (ns == 1 || rs.fixup) && (p.out_mode == MDX_OUT_ROWMAJOR);
+    cc.ns = lg.ring;
+    const int st_req = lg.st_req;
     MDX_REQUIRE(!d->w_frag || halo, "mdx_gemm_f16: fragment-major weights (w_frag) are read by the HALO 3x3 conv only");
     bool ok;
     if (halo) {
@@ -2075,6 +2130,8 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
             if (bn == 128) launch_gna<128, 128>(p, gns, swap, grid, st); else launch_gna<128, 64>(p, gns, swap, grid, st);
         }
         ok = true;
+    } else if (lg.lean && mdx_dense_launch(p, cc.bm, bn, cc.ns, grid, st)) {
+        ok = true;      // dense.hip: the same tile program with a division-free prologue and the epilogue's reads prefetched
     } else if (cc.bm == 64)
         ok = (bn == 128) ? launch_bn<64, 128>(cc, p, swap, fastk, grid, st) : launch_bn<64, 64>(cc, p, swap, fastk, grid, st);
     else

@@ -61,12 +61,19 @@ struct GemmParams {
     int c8_sub;      // resolved: this launch runs the sub-pixel form on the conv8p core
     int dense_issue; // dense launches issue their K tiles through the scalar offset (option gemm_dense_issue)
     int ln_prefetch; // LayerNorm-fold consumer: the tile's statistics partials and S[n] are touched before the K loop (option gemm_ln_prefetch)
+    // lean dense kernel (dense.hip): tile_id / tiles_n and tile_id / tiles_m as a multiply-high (ceil(2^32 / d): exact for the < 2^16
+    // tile ids a launch has)
+    unsigned inv_tiles_n, inv_tiles_m;
+    unsigned res_bytes;      // bytes of the residual tensor ([M][residual_ld] fp16), for its buffer descriptor
 };
 
 }  // namespace mdx_int
 using mdx_int::GemmParams;
 
 // 8-phase 256-pixel conv core (conv8p.hip): eligibility + launch, called from mdx_gemm_f16 / mdx_gemm_query (gemm.hip)
+// lean dense kernel (dense.hip): dense row-major launches of the benchmarked tile shapes; false = this (tile, ring) has no lean
+// instantiation and the caller launches the generic kernel
+bool mdx_dense_launch(const GemmParams& p, int bm, int bn, int ns, dim3 grid, hipStream_t st);
 bool mdx_conv8p_eligible(const GemmParams& p);
 int mdx_conv8p_pick_bn(const GemmParams& p, int bn_hint);
 int mdx_conv8p_tiles(const GemmParams& p);
@@ -307,10 +314,15 @@ __device__ __forceinline__ bool splitk_last_block_reduce(const GemmParams& p, f3
 
 // Fused epilogue shared by the GEMM kernels.  SWAP: accumulators hold C^T (col = lane&31 -> m), staged through LDS
 // and stored row-major with bias / rowbias / residual / GEGLU / GELU; !SWAP: split-K partial slab or transposed store.
-template <int BM, int BN, bool SWAP, int NW, class RowMap>
+// Optional prefetches of the lean dense kernel (dense.hip), all issued BEFORE the K loop so that the epilogue of a lone block opens
+// with no global round trip: ln_pre = {mean, rstd} of this thread's row (tid < BM), lns_pre = S[n0 + tid] (tid < BN), xpre = the
+// residual (/ time-embedding) rows of this thread's first NXPRE store passes.
+template <int BM, int BN, bool SWAP, int NW, class RowMap, int NXPRE = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / (16 * NW)][BN / 64], char* smem,
                                               const RowMap rm, const int n0, const int split, const float (&bpre)[16],
-                                              const int row_block = 0, const int tile_lin = 0, const float* ln_pre = nullptr) {
+                                              const int row_block = 0, const int tile_lin = 0, const float* ln_pre = nullptr,
+                                              const float* lns_pre = nullptr, const Row8Extras* xpre = nullptr,
+                                              const bool ln_pre_valid = true, const bool lns_pre_valid = true) {
     constexpr int NT = NW * 64;           // threads per block
     constexpr int WROWS = BM / (NW / 2);  // rows of the block tile owned by one wave row (waves are (NW/2) x 2)
     constexpr int TM = WROWS / 32;
@@ -400,7 +412,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             // rstd_m * (acc - mean_m * S_n) in fp32 -- BEFORE the fp16 staging, so the cancellation costs no precision.
             float* lnrow = reinterpret_cast<float*>(smem + (size_t)BM * SLD * 2);      // [BM][2] mean, rstd
             float* lns = lnrow + 2 * BM;                                               // [BN]
-            if (ln_pre) {      // this thread's row (tid < BM) was folded before the K loop (gemm_ln_row_prefetch)
+            if (ln_pre && ln_pre_valid) {      // this thread's row (tid < BM) was folded from partials fetched before the K loop (dense.hip)
                 if (tid < BM) {
                     lnrow[2 * tid] = ln_pre[0];
                     lnrow[2 * tid + 1] = ln_pre[1];
@@ -413,7 +425,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     lnrow[2 * r + 1] = mr[1];
                 }
             }
-            for (int c = tid; c < BN; c += NT) lns[c] = (n0 + c < p.N) ? p.ln_s[n0 + c] : 0.f;
+            if (lns_pre && lns_pre_valid) {
+                if (tid < BN) lns[tid] = *lns_pre;
+            } else {
+                for (int c = tid; c < BN; c += NT) lns[c] = (n0 + c < p.N) ? p.ln_s[n0 + c] : 0.f;
+            }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -442,7 +458,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
             for (int e = 0; e < 8; ++e) bb[e] = bpre[e];   // fetched before the K loop (gemm_bias_prefetch)
             const int m = rm(r0);
-            if (m < p.M && n < p.N) xa = epilogue_prefetch_row8(p, m, n);
+            if constexpr (NXPRE > 0) {
+                xa = xpre[0];
+            } else {
+                if (m < p.M && n < p.N) xa = epilogue_prefetch_row8(p, m, n);
+            }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -534,8 +554,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     const int m = rm(row);
                     Row8Extras xn;
                     if (pass + 1 < BM / RPP) {
-                        const int m2 = rm(row + RPP);
-                        if (m2 < p.M && n < p.N) xn = epilogue_prefetch_row8(p, m2, n);
+                        if (pass + 1 < NXPRE) {
+                            xn = xpre[pass + 1 < NXPRE ? pass + 1 : 0];
+                        } else {
+                            const int m2 = rm(row + RPP);
+                            if (m2 < p.M && n < p.N) xn = epilogue_prefetch_row8(p, m2, n);
+                        }
                     }
                     float su = 0.f, sq = 0.f;
                     if (m < p.M && n < p.N) {

@@ -14,6 +14,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 constexpr int GN_MAX_C = 8192;
@@ -360,45 +362,74 @@ constexpr int GNF_KEEP = 6;      // SLAB variant: pixels a thread keeps in regis
 // (mdx_groupnorm_from_splitk_f16): element (m, n) = fp16( bias[n] + sum_z ws[z][m][n] + rowbias[b][n] + residual[m][n] ),
 // the additions in exactly the order of splitk_reduce_kernel, so the result is bit-identical to reduce-then-GroupNorm.  The
 // producer's fp16 output is stored on the way (later consumers read it), the values stay in registers for the second pass.
-__device__ __forceinline__ f16x8 gn_slab_load(const MdxSplitInfo& sp, int b, int m, int n) {
+// Round 6: every load of an element's chain -- bias, time-embedding row, residual and the first eight slabs -- is requested before the
+// first add.  The small operands go through buffer descriptors whose bounds check answers zero for an operand the producer does not
+// have (so the loads are unconditional: a conditional load merged with a default made the compiler wait for it on the spot, one
+// exposed L2 / HBM round trip per operand in a kernel that is nothing but round trips -- 64 blocks of 320 busy threads at the 8 x 8
+// level); the adds keep the order of splitk_reduce_kernel: same bits.
+struct GnSlabRsrc {
+    __amdgpu_buffer_rsrc_t bias, rowbias, residual;
+};
+
+__device__ __forceinline__ GnSlabRsrc gn_slab_rsrc(const MdxSplitInfo& sp) {
+    GnSlabRsrc r;
+    r.bias = make_rsrc(sp.bias, sp.bias ? (unsigned)sp.N * 4u : 0u);
+    r.rowbias = make_rsrc(sp.rowbias, sp.rowbias ? (unsigned)sp.B * (unsigned)sp.rowbias_ld * 4u : 0u);
+    const size_t rbytes = (size_t)sp.M * (size_t)sp.residual_ld * 2;
+    r.residual = make_rsrc(sp.residual, sp.residual ? (unsigned)(rbytes < 0x7fffffffull ? rbytes : 0x7fffffffull) : 0u);
+    return r;
+}
+
+typedef unsigned gn_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int UMAX>
+__device__ __forceinline__ f16x8 gn_slab_load(const MdxSplitInfo& sp, const GnSlabRsrc& rs, int b, int m, int n) {
+    const gn_u32x4 b0 = __builtin_amdgcn_raw_buffer_load_b128(rs.bias, (unsigned)n * 4u, 0, 0);
+    const gn_u32x4 b1 = __builtin_amdgcn_raw_buffer_load_b128(rs.bias, (unsigned)n * 4u, 16, 0);
+    const unsigned rbo = ((unsigned)b * (unsigned)sp.rowbias_ld + (unsigned)n) * 4u;
+    const gn_u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(rs.rowbias, rbo, 0, 0);
+    const gn_u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(rs.rowbias, rbo, 16, 0);
+    const gn_u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rs.residual, ((unsigned)m * (unsigned)sp.residual_ld + (unsigned)n) * 2u, 0, 0);
     float f[8];
-    if (sp.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(sp.bias + n), b1 = *reinterpret_cast<const float4*>(sp.bias + n + 4);
-        f[0] = b0.x; f[1] = b0.y; f[2] = b0.z; f[3] = b0.w; f[4] = b1.x; f[5] = b1.y; f[6] = b1.z; f[7] = b1.w;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    {
+        const f32x4 x0 = __builtin_bit_cast(f32x4, b0), x1 = __builtin_bit_cast(f32x4, b1);
+        f[0] = x0[0]; f[1] = x0[1]; f[2] = x0[2]; f[3] = x0[3]; f[4] = x1[0]; f[5] = x1[1]; f[6] = x1[2]; f[7] = x1[3];
     }
     const size_t slab = (size_t)sp.M * sp.N;
     const float* base = sp.ws + (size_t)m * sp.N + n;
-    // four slabs' loads in flight per thread (a runtime-trip loop of load-then-add made this a chain of nsplit L2 round trips:
-    // 10-20 at the 8 x 8 level); the additions stay in slab order, so the sum keeps its bits
+    // up to eight slabs' loads in flight per thread, then four / two / one; the additions stay in slab order, so the sum keeps its bits
     int z = 0;
-    for (; z + 4 <= sp.nsplit; z += 4) {
-        float4 a[4], c[4];
+    auto batch = [&](auto uc) {
+        constexpr int U = decltype(uc)::value;
+        float4 a[U], c[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             a[u] = *reinterpret_cast<const float4*>(base + (size_t)(z + u) * slab);
             c[u] = *reinterpret_cast<const float4*>(base + (size_t)(z + u) * slab + 4);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             f[0] += a[u].x; f[1] += a[u].y; f[2] += a[u].z; f[3] += a[u].w;
             f[4] += c[u].x; f[5] += c[u].y; f[6] += c[u].z; f[7] += c[u].w;
         }
+        z += U;
+    };
+    // (UMAX = 8 where a thread keeps at most two elements between the passes -- the 8 x 8 and 16 x 16 levels, where the launch is
+    // nothing but this chain; 4 with six kept elements: eight in flight spill under the 128-register cap of a 1024-thread block)
+    if constexpr (UMAX >= 8) {
+        while (z + 8 <= sp.nsplit) batch(std::integral_constant<int, 8>{});
+        if (z + 4 <= sp.nsplit) batch(std::integral_constant<int, 4>{});
+    } else {
+        while (z + 4 <= sp.nsplit) batch(std::integral_constant<int, 4>{});
     }
-    for (; z < sp.nsplit; ++z) {
-        const float4 s0 = *reinterpret_cast<const float4*>(base + (size_t)z * slab);
-        const float4 s1 = *reinterpret_cast<const float4*>(base + (size_t)z * slab + 4);
-        f[0] += s0.x; f[1] += s0.y; f[2] += s0.z; f[3] += s0.w; f[4] += s1.x; f[5] += s1.y; f[6] += s1.z; f[7] += s1.w;
-    }
+    if (z + 2 <= sp.nsplit) batch(std::integral_constant<int, 2>{});
+    if (z < sp.nsplit) batch(std::integral_constant<int, 1>{});
     if (sp.rowbias) {
-        const float4 r0 = *reinterpret_cast<const float4*>(sp.rowbias + (size_t)b * sp.rowbias_ld + n);
-        const float4 r1 = *reinterpret_cast<const float4*>(sp.rowbias + (size_t)b * sp.rowbias_ld + n + 4);
-        f[0] += r0.x; f[1] += r0.y; f[2] += r0.z; f[3] += r0.w; f[4] += r1.x; f[5] += r1.y; f[6] += r1.z; f[7] += r1.w;
+        const f32x4 x0 = __builtin_bit_cast(f32x4, r0), x1 = __builtin_bit_cast(f32x4, r1);
+        f[0] += x0[0]; f[1] += x0[1]; f[2] += x0[2]; f[3] += x0[3]; f[4] += x1[0]; f[5] += x1[1]; f[6] += x1[2]; f[7] += x1[3];
     }
     if (sp.residual) {
-        const f16x8 r = *reinterpret_cast<const f16x8*>(sp.residual + (size_t)m * sp.residual_ld + n);
+        const f16x8 r = __builtin_bit_cast(f16x8, rr);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] += (float)r[e];
     }
@@ -427,7 +458,7 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnParams p, const Md
     const int trows = NT / cols;
     const int tc = tid % cols, tr = tid / cols;
     const bool active = tr < trows;
-    constexpr int KN = SLAB ? GNF_KEEP : (KEEPN > 0 ? KEEPN : 1);
+    constexpr int KN = SLAB ? (KEEPN > 0 ? KEEPN : GNF_KEEP) : (KEEPN > 0 ? KEEPN : 1);      // SLAB: KEEPN = elements per thread (host-checked)
     f16x8 keep[KN];
     // (p.pre) this thread's channel's affine parameters (chs <= min(512, NT): one per thread), fetched first: see GnParams.pre
     float pg = 0.f, pb = 0.f, pm = 0.f, pf = 0.f;
@@ -461,11 +492,12 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnParams p, const Md
             pix = p.HW;      // nothing left for the loops below
         }
         if constexpr (SLAB) {
+            const GnSlabRsrc srs = gn_slab_rsrc(sp);
 #pragma unroll
-            for (int k = 0; k < GNF_KEEP; ++k) {
+            for (int k = 0; k < KN; ++k) {
                 const int px = tr + k * trows;
                 if (px < p.HW) {
-                    keep[k] = gn_slab_load(sp, b, b * p.HW + px, (col0 + tc) * 8);
+                    keep[k] = gn_slab_load<(KN <= 2 ? 8 : 4)>(sp, srs, b, b * p.HW + px, (col0 + tc) * 8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float f = (float)keep[k][e];
@@ -929,12 +961,20 @@ extern "C" int mdx_groupnorm_from_splitk_f16(const mdx_gemm_desc* prod, const fl
     p.silu = silu;
     p.pre = mdx_opt(MDX_OPT_GN_PREFETCH) ? 1 : 0;
     constexpr size_t lds = ((size_t)GNF_THREADS * 8 * 2 + (size_t)GNF_FOLD * 512 * 2 + 512 * 2 + 64 * 2 + 512 * 2) * sizeof(float);
-    static MdxPerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    hipLaunchKernelGGL(gn_fused_kernel<true>, dim3(p.ncb, sp.B), dim3(GNF_THREADS), lds, (hipStream_t)s, p, sp);
+    // elements a thread keeps between the passes: 1 (8 x 8 level), 2 (16 x 16), else up to GNF_KEEP -- fewer kept elements leave
+    // the registers for eight slabs' loads in flight (gn_slab_load)
+    const int trows = GNF_THREADS / p.cw;
+    const int per_thread = (p.HW + trows - 1) / trows;
+    auto launch = [&](auto kernel) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, dim3(p.ncb, sp.B), dim3(GNF_THREADS), lds, (hipStream_t)s, p, sp);
+    };
+    if (per_thread <= 1)
+        launch(&gn_fused_kernel<true, GNF_THREADS, 1>);
+    else if (per_thread <= 2)
+        launch(&gn_fused_kernel<true, GNF_THREADS, 2>);
+    else
+        launch(&gn_fused_kernel<true, GNF_THREADS, 0>);
     MDX_LAUNCH_CHECK("mdx_groupnorm_from_splitk_f16");
     return MDX_OK;
 }

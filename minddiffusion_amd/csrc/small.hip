@@ -21,8 +21,8 @@ static const char* const g_opt_names[MDX_OPT_COUNT] = {"gemm_tuned", "gemm_bm", 
                                                         "gemm_splitk_fixup_max", "gemm_spread", "halo_nsb", "gn_min_blocks",
                                                         "gn_fused", "gn_col_chunks", "gemm_conv8p", "gemm_conv8p_min_m", "gemm_subpixel_min_tiles", "gemm_conv8p_var", "attn8", "attn8_min_blocks",
                                                         "gn_wide_rows", "gn_fused_small", "gn_boost_mb", "attn_occ3", "attn_kv_split", "attn_fast_stage",
-                                                        "gn_prefetch", "gemm_dense_issue", "gemm_ln_prefetch"};
-static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1, 4, 1, 4096, 32, 0, 0, 192, 0, 0, 40, 1, 1, 1, 1, 1, 1};
+                                                        "gn_prefetch", "gemm_dense_issue", "gemm_ln_prefetch", "gemm_lean_dense"};
+static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1, 4, 1, 4096, 32, 0, 0, 192, 0, 0, 40, 1, 1, 1, 1, 1, 1, 1};
 
 int mdx_opt(int id) { return g_opt[id]; }
 

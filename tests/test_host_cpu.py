@@ -996,3 +996,41 @@ def test_subpixel_conv_weight_is_the_upsampled_conv():
             o = F.conv2d(xp[:, :, dy:dy + 6 + 1, dx:dx + 7 + 1], ws[dy, dx])
             out[:, :, dy::2, dx::2] = o
     assert torch.allclose(out, ref, atol=1e-5), float((out - ref).abs().max())
+
+
+def test_lean_dense_kernel_wait_counts_equal_the_loads_it_issues(tmp_path):
+    """csrc/dense.hip counts its epilogue prefetches in the FIRST wait of the K loop (s_waitcnt vmcnt(tiles in flight + E)): if the
+    compiler removed or added one of those loads, the wait would let the first K tile be read before it has landed.  Compile the file to
+    gfx950 assembly and check, for every instantiation, that the non-LDS buffer loads in front of the first barrier are exactly E, that
+    nothing spills, and that the first wait names E."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "dense.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT}/include",
+                    f"-I{ROOT}/minddiffusion_amd/csrc", "-Wno-unused-function", "-S", "--cuda-device-only", "-o", str(out),
+                    f"{ROOT}/minddiffusion_amd/csrc/dense.hip"], check=True, capture_output=True)
+    txt = out.read_text()
+    n = 0
+    for m in re.finditer(r"^_ZN12_GLOBAL__N_112dense_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d)EEEvN7mdx_int10GemmParamsE:\s*;", txt, re.M):
+        bm, bn, ns, pf = (int(m.group(i)) for i in (1, 2, 3, 4))
+        body = txt[m.end():txt.index(".end_amdhsa_kernel", m.end())]
+        lines = body.split("\n")
+        first_bar = next(i for i, l in enumerate(lines) if "s_barrier" in l)
+        pre = lines[:first_bar]
+        issued = sum(1 for l in pre if "buffer_load" in l and " lds" not in l)
+        assert not any("global_load" in l or "scratch_" in l for l in pre), (bm, bn, ns, pf)
+        passes = bm // (256 // (bn // 8))
+        nx = min(passes, 4) if pf >= 2 else 0
+        E = (4 if bn == 128 else 2) + nx + (24 if pf >= 3 else 0) + (1 if pf >= 2 else 0) + (2 if pf in (1, 2) else 0)
+        assert issued == E, f"dense_kernel<{bm},{bn},{ns},{pf}>: {issued} prefetch loads issued, the first wait counts {E}"
+        waits = [int(x) for l in pre for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", l)]
+        lpt = (bm + bn) // 8 // 4
+        assert waits and all((w - E) % lpt == 0 and 0 <= (w - E) // lpt <= ns - 2 for w in waits), (bm, bn, ns, pf, waits, E)
+        assert re.search(r"ScratchSize: (\d+)", txt[m.end():]).group(1) == "0", f"dense_kernel<{bm},{bn},{ns},{pf}> spills"
+        n += 1
+    assert n >= 50, n
+

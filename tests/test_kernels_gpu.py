@@ -373,6 +373,161 @@ def test_gemm_release_workspace_reuses_the_counters_under_a_recaptured_graph(ops
     assert lib.mdx_gemm_release_workspace(ctypes_ptr(ws2)) == 1
 
 
+def _lean_cases():
+    """(name, M, N, K, kwargs of make_gemm_desc incl. tile hints, feature) for the lean dense kernel of csrc/dense.hip."""
+    cases = []
+    for (tm, tn) in [(64, 64), (64, 128), (128, 64), (128, 128)]:
+        for st in ([2, 3, 4, 5, 6] if tm == 64 else ([2, 3, 4] if tn == 64 else [2, 3])):
+            cases.append((f"t{tm}x{tn}_s{st}_bias_res", 512, 640, 1280, dict(tile_m=tm, tile_n=tn, stages=st, splitk=1), "res"))
+    cases += [
+        ("plain_small", 128, 1280, 1280, dict(tile_m=64, tile_n=64, splitk=1), "bias"),
+        ("nobias", 512, 1280, 640, dict(tile_m=64, tile_n=64, splitk=1), "none"),
+        ("m_tail", 520, 1280, 1280, dict(tile_m=64, tile_n=64, splitk=1), "res"),                 # rows past M in the last tile
+        ("n_tail_128", 512, 320, 1280, dict(tile_m=64, tile_n=128, splitk=1), "res"),             # a half-empty 128-column tile
+        ("big_grid_no_pre", 8192, 640, 640, dict(tile_m=64, tile_n=64, splitk=1), "res"),         # > 512 blocks: the light form
+        ("big_grid_128", 8192, 1280, 640, dict(tile_m=128, tile_n=128, splitk=1), "res"),
+        ("stats", 512, 1280, 1280, dict(tile_m=64, tile_n=64, splitk=1), "stats"),
+        ("colstats", 512, 640, 1280, dict(tile_m=64, tile_n=64, splitk=1), "colstats"),
+        ("ln", 512, 1280, 1280, dict(tile_m=64, tile_n=64, splitk=1), "ln"),                     # 20 partials per row: held in registers
+        ("ln_128x64", 512, 1280, 640, dict(tile_m=128, tile_n=64, splitk=1), "ln"),
+        ("ln_long", 256, 640, 2560, dict(tile_m=64, tile_n=64, splitk=1), "ln"),                 # 40 partials: the epilogue folds
+        ("ln_big_grid", 8192, 960, 320, dict(tile_m=64, tile_n=64, splitk=1), "ln"),
+        ("geglu_ln", 512, 2560, 640, dict(tile_m=64, splitk=1), "geglu_ln"),
+        ("geglu", 2048, 5120, 640, dict(tile_m=64, splitk=1), "geglu"),
+        ("qkv_split", 512, 3 * 640, 640, dict(tile_m=64, tile_n=128, splitk=1), "nsplit_ln"),
+        ("splitk3", 256, 640, 2560, dict(tile_m=64, tile_n=64, splitk=3), "res"),
+        ("splitk4_ln", 128, 1280, 1280, dict(tile_m=64, tile_n=64, splitk=4), "ln"),
+        ("splitk2_geglu", 512, 2560, 1280, dict(tile_m=64, splitk=2), "geglu"),
+        ("auto_tiles", 2048, 640, 2560, dict(), "res"),                                 # the tile table's own choice
+        ("auto_tiles_spread", 64, 1280, 1280, dict(), "res"),                           # one row of M tiles: the 2-D SPREAD grid
+    ]
+    return cases
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])      # option gemm_lean_dense: prefetch levels 1 (product), 0, 2, 3 (csrc/dense.hip)
+@pytest.mark.parametrize("case", _lean_cases(), ids=lambda c: c[0])
+def test_lean_dense_kernel_is_bit_identical_to_the_generic_kernel(ops, case, level):
+    """csrc/dense.hip (round 6): dense row-major launches run a lean instantiation of the tile program -- division-free prologue,
+    the epilogue's global reads (bias, residual rows, LayerNorm partials, S[n]) requested before the K loop.  Same LDS image, same K
+    order, same epilogue arithmetic: every output (and every statistic it emits) must carry the generic kernel's BITS, for every
+    tile / ring instantiation, both prefetch forms (small / large grids), every epilogue feature, tails, and the in-kernel split-K
+    reduce; the result is also checked against numpy so that "identical" does not mean "identically wrong"."""
+    name, M, N, K, kw, feat = case
+    r = np.random.RandomState(sum(map(ord, name)))
+    a = h16(r.standard_normal((M, K)))
+    geglu = feat.startswith("geglu")
+    w = h16(r.standard_normal((N, K)) / math.sqrt(K))
+    bv = r.standard_normal(N).astype(np.float32)
+    No = N // 2 if geglu else N
+    res = h16(r.standard_normal((M, No)))
+    da = dev16(a)
+    args = dict(kw)
+    extra = {}
+    if feat in ("res",):
+        args.update(bias=dev32(bv), residual=dev16(res), residual_ld=No)
+    elif feat == "bias":
+        args.update(bias=dev32(bv))
+    elif feat == "stats":
+        extra["stats"] = torch.zeros((M, N // 64, 2), dtype=torch.float32, device=DEV)
+        args.update(bias=dev32(bv), residual=dev16(res), residual_ld=No, stats_out=extra["stats"])
+    elif feat == "colstats":
+        extra["cs"] = torch.zeros((M // 64, N, 2), dtype=torch.float32, device=DEV)
+        args.update(bias=dev32(bv), colstats_out=extra["cs"])
+    elif geglu:
+        args.update(bias=dev32(bv), epilogue=ops.EPI_GEGLU)
+    ln = feat.endswith("ln")
+    wp = None
+    if ln:
+        # producer statistics of the rows (what the GEMM in front would have written) + folded weights
+        xs = a.astype(np.float32).reshape(M, K // 64, 64)
+        st = np.stack([xs.sum(-1), (xs * xs).sum(-1)], -1).astype(np.float32)
+        g = (1 + 0.3 * r.standard_normal(K)).astype(np.float32)
+        be = (0.3 * r.standard_normal(K)).astype(np.float32)
+        wg, s_, cb = ops.fold_layernorm(dev16(w), dev32(g), dev32(be), None if feat == "nsplit_ln" else dev32(bv))
+        args.update(ln_stats=dev32(st), ln_s=s_)
+        if feat == "nsplit_ln":
+            args.pop("bias", None)
+            cb_np = cb.cpu().numpy()
+        else:
+            args["bias"] = cb
+        if not geglu:
+            wp = ops.pack_gemm_weight(wg)
+    if geglu:
+        # GEGLU packing: every 128-wide tile = 64 'a' columns | 64 gate columns (include/mdx.h)
+        src = wg.float().cpu().numpy() if ln else w.astype(np.float32)
+        half = N // 2
+        wi = np.empty_like(src)
+        bsrc = args["bias"].cpu().numpy()
+        bi = np.empty_like(bsrc)
+        for t in range(N // 128):
+            wi[t * 128:t * 128 + 64] = src[t * 64:t * 64 + 64]
+            wi[t * 128 + 64:t * 128 + 128] = src[half + t * 64:half + t * 64 + 64]
+            bi[t * 128:t * 128 + 64] = bsrc[t * 64:t * 64 + 64]
+            bi[t * 128 + 64:t * 128 + 128] = bsrc[half + t * 64:half + t * 64 + 64]
+        wp = ops.pack_gemm_weight(dev16(h16(wi)))
+        args["bias"] = dev32(bi)
+        if ln:
+            si = np.empty(N, np.float32)
+            sn = s_.cpu().numpy()
+            for t in range(N // 128):
+                si[t * 128:t * 128 + 64] = sn[t * 64:t * 64 + 64]
+                si[t * 128 + 64:t * 128 + 128] = sn[half + t * 64:half + t * 64 + 64]
+            args["ln_s"] = dev32(si)
+    elif not ln:
+        wp = pack_dense(w)
+    vt = None
+    if feat == "nsplit_ln":
+        C = N // 3
+        vt = torch.zeros((1, C, M), dtype=torch.float16, device=DEV)
+        args.update(out2=vt, out2_ld=M, n_split=2 * C, bias=cb)      # (the fold's W beta term is the projection's bias)
+
+    def run(lean):
+        ops.set_option("gemm_lean_dense", lean)
+        out = torch.zeros((M, (2 * N // 3) if feat == "nsplit_ln" else No), dtype=torch.float16, device=DEV)
+        if vt is not None:
+            vt.zero_()
+        for t_ in extra.values():
+            t_.zero_()
+        d = ops.make_gemm_desc(da, wp, N, 1, M, 1, K, out, out.shape[1], **args)
+        need = ops.gemm_workspace_bytes(d)
+        ws = ops.new_gemm_workspace(max(need, 16), DEV)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        form = ops.gemm_query(d)[3]
+        ops.gemm_run(d)
+        torch.cuda.synchronize()
+        return form, [out.clone()] + ([vt.clone()] if vt is not None else []) + [t_.clone() for t_ in extra.values()]
+
+    keep = ops.get_option("gemm_lean_dense")
+    try:
+        f1, lean = run(level)
+        f0, gen = run(0)
+    finally:
+        ops.set_option("gemm_lean_dense", keep)
+    assert f1 == 2 and f0 == 0, f"{name}: launch forms {f1} / {f0} (2 = lean dense kernel, 0 = generic)"
+    for i, (x, y) in enumerate(zip(lean, gen)):
+        assert torch.equal(x, y), (f"{name}: output {i} differs between the lean and the generic kernel: "
+                                   f"max |d| = {float((x.float() - y.float()).abs().max())}")
+    # and against numpy (fp16 inputs, fp32 accumulate)
+    af, wf = a.astype(np.float32), w.astype(np.float32)
+    if ln:
+        mu = af.mean(1, keepdims=True)
+        var = af.var(1, keepdims=True)
+        af = (af - mu) / np.sqrt(var + 1e-5) * g + be
+    y = af @ wf.T + (0 if feat in ("none", "nsplit_ln") else bv)
+    if geglu:
+        half = N // 2
+        gate = y[:, half:]
+        y = y[:, :half] * (0.5 * gate * (1 + np.tanh(0.7978845608028654 * (gate + 0.044715 * gate ** 3))))
+    if feat in ("res", "stats"):
+        y = y + res.astype(np.float32)
+    if feat == "nsplit_ln":
+        C = N // 3
+        check(f"lean_dense_{name}_qk", lean[0].float().cpu(), torch.tensor(y[:, :2 * C]), rel_l2=2e-3)
+        check(f"lean_dense_{name}_vt", lean[1][0].float().cpu(), torch.tensor(y[:, 2 * C:].T.copy()), rel_l2=2e-3)
+    else:
+        check(f"lean_dense_{name}", lean[0].float().cpu(), torch.tensor(y), rel_l2=2e-3 if ln else 1e-3)
+
+
 def test_gemm_caller_owned_arrival_counters(ops):
     """include/mdx.h mdx_gemm_bind_counters: a caller that owns every byte binds MDX_GEMM_WS_HEAD zeroed bytes to its workspace; the
     in-kernel split-K reduce takes its tickets there and leaves them zero (a poisoned counter would prove the use, but it can reach

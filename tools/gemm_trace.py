@@ -71,9 +71,13 @@ def main():
     ap.add_argument("--split", type=int, default=0)
     ap.add_argument("--warm", action="store_true", help="do not flush the caches: operands and output stay resident")
     ap.add_argument("--only", default="", help="comma list of shape-name substrings")
+    ap.add_argument("--lean", type=int, default=-1, help="0 / 1: library option gemm_lean_dense (round 6: csrc/dense.hip); -1 = default")
     args = ap.parse_args()
     from minddiffusion_amd import ops, _lib
     lib = _lib.load()
+    if args.lean >= 0:
+        ops.set_option("gemm_lean_dense", args.lean)
+    print(f"# gemm_lean_dense = {ops.get_option('gemm_lean_dense')}")
     B = args.batch
     shapes = [("proj16_1280", 16, 16, 1280, 1280, 1), ("proj32_640", 32, 32, 640, 640, 1),
               ("qk64_320", 64, 64, 320, 320, 1), ("conv16_1280_1280", 16, 16, 1280, 1280, 3),
