@@ -151,8 +151,9 @@ typedef struct mdx_gemm_desc {
                              into a token sub-range of a larger [B][tokens][C] buffer (GLIDE text|image keys) */
     void* out2;           /* split output (n_split > 0): columns [0, n_split) go row-major to `out` as usual, columns      */
     int out2_ld;          /* [n_split, N) go TRANSPOSED to out2[(b * (N - n_split) + n - n_split) * out2_ld + tok]:      */
-    int n_split;          /* q|k and V^T of a self-attention in ONE launch (attention.py:108-112).  Multiple of 128;
-                             bias only (no rowbias / residual / epilogue / out_bs). */
+    int n_split;          /* q|k and V^T of a self-attention in ONE launch (attention.py:108-112; Taichu-GLIDE unet.py:289-297 with
+                             out_bs: q | k of the image tokens behind the text keys).  Multiple of 128; bias only (no rowbias /
+                             residual / epilogue). */
     int asym_pad;         /* 3x3 stride-2 only: zero-pad bottom / right instead of all around (VAE Encoder Downsample,
                              ldm/modules/diffusionmodules/model.py:55-78) */
     /* nn.LayerNorm folded into the two GEMMs around it (BasicTransformerBlock, attention.py:176-185):

@@ -1250,7 +1250,10 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
     if (p.n_split) {
         MDX_REQUIRE(p.out2 && p.n_split > 0 && p.n_split < p.N && p.n_split % 128 == 0,
                     "mdx_gemm_f16: n_split must be a multiple of 128 inside (0, N) with out2 set");
-        MDX_REQUIRE(p.out_mode == MDX_OUT_ROWMAJOR && p.epilogue == MDX_EPI_NONE && !p.rowbias && !p.residual && !p.out_bs,
+        // (out_bs is allowed since round 6: the row-major part may land in a token sub-range of a larger [B][tokens][C] buffer --
+        // Taichu-GLIDE's q | k of the image tokens behind the text keys, unet.py:289-297; both store paths go through
+        // epilogue_apply_row8, which knows it)
+        MDX_REQUIRE(p.out_mode == MDX_OUT_ROWMAJOR && p.epilogue == MDX_EPI_NONE && !p.rowbias && !p.residual,
                     "mdx_gemm_f16: the split row-major | transposed output takes bias only");
         MDX_REQUIRE(p.out2_ld % 8 == 0 && p.out2_ld >= p.HoWo,
                     "mdx_gemm_f16: transposed part needs out2_ld %% 8 == 0 and out2_ld >= tokens");
@@ -1656,13 +1659,17 @@ extern "C" size_t mdx_gemm_workspace_bytes(const mdx_gemm_desc* d) {
     return head + (size_t)tl.ns * per;
 }
 
+static int mdx_internal_resolve_check(const mdx_gemm_desc* d, GemmParams& p);
+
 extern "C" int mdx_gemm_check(const mdx_gemm_desc* d) {
     GemmParams p{};
     int rc = fill_params(d, p);
     if (rc != MDX_OK) return rc;
     const bool fastk = (p.cin % 64 == 0) && (p.c2 == 0 || p.c1 % 64 == 0);
     MDX_REQUIRE(fastk || p.c2 == 0, "mdx_gemm_f16: two-source input needs c1 %% 64 == 0 and Cin %% 64 == 0");
-    return MDX_OK;
+    // ... and the launch form the descriptor resolves to must exist for it (round 6): a forced tile / a tile-table row whose kernel
+    // does not apply to this geometry is an error HERE, at plan time, not a launch that silently takes another form
+    return mdx_internal_resolve_check(d, p);
 }
 
 // Everything mdx_gemm_f16 decides before it launches: tile shape, split-K factor (clamped to the caller's workspace), kernel.
@@ -1919,6 +1926,11 @@ static int resolve_launch(const mdx_gemm_desc* d, GemmParams& p, Resolved& r) {
     p.tickets = r.fixup ? reinterpret_cast<unsigned*>(p.ws) : nullptr;
     if (r.ns > 1 && !r.fixup) p.ws += MDX_TICKET_SLOTS;     // [split][M][N] slabs of the reduce-kernel path start behind the head
     return MDX_OK;
+}
+
+static int mdx_internal_resolve_check(const mdx_gemm_desc* d, GemmParams& p) {
+    Resolved r;
+    return resolve_launch(d, p, r);
 }
 
 // Rows per colstats_out row block this launch would produce (0 = it cannot): the M tile for a single-pass launch (a HALO

@@ -218,6 +218,10 @@ class Text2ImUNet:
                 for idx, nm in enumerate("qkv"):
                     w[pre + nm + ".w"] = self._dense(qkv[:, idx].reshape(c, c))
                     w[pre + nm + ".b"] = qb[:, idx].reshape(c).contiguous()
+                # (round 6) one launch for the three image-token projections: rows [q | k | v] (mdx_gemm_desc.n_split = 2 c: q | k
+                # row-major, V transposed)
+                w[pre + "qkv.w"] = self._dense(torch.cat([qkv[:, 0].reshape(c, c), qkv[:, 1].reshape(c, c), qkv[:, 2].reshape(c, c)], 0))
+                w[pre + "qkv.b"] = torch.cat([qb[:, 0].reshape(c), qb[:, 1].reshape(c), qb[:, 2].reshape(c)], 0).contiguous()
                 ekv = self._dev(P[pre + "encoder_kv.conv.weight"], f16).reshape(heads, 2, 64, self.xf_width)
                 eb = self._dev(P[pre + "encoder_kv.conv.bias"], f32).reshape(heads, 2, 64)
                 for idx, nm in enumerate(("ek", "ev")):
@@ -480,27 +484,44 @@ class Text2ImUNet:
             nk = ctx + T
             a = A.get((B, T, c))
             gn(x, None, w[pre + "norm.g"], w[pre + "norm.b"], False, a)
-            q = dense(a, B, T, c, c, w[pre + "q.w"], bias=w[pre + "q.b"])
             # keys / values = [text | image]: the text rows (encoder_kv of xf_out, unet.py:289-297) depend on the tokens alone, so
             # they live in buffers of their own (not the arena: they must survive the step) and their two projections join the
             # plan's text prefix; only the image rows are written per step
-            kbuf = torch.zeros((B, nk, c), dtype=f16, device=dev)
             vtb = torch.zeros((B, c, nk), dtype=f16, device=dev)
-            kv_keep.append((kbuf, vtb))
-            dense(a, B, T, c, c, w[pre + "k.w"], bias=w[pre + "k.b"], out=kbuf[:, ctx:], out_ld=c, out_bs=nk * c)
-            dense(a, B, T, c, c, w[pre + "v.w"], bias=w[pre + "v.b"], out=vtb[:, :, ctx:], out_ld=nk,
-                  out_mode=ops.OUT_TRANSPOSED)
+            if ops.get_option("glide_qkv_merge") and T % 8 == 0:
+                # (round 6) q | k | v of the image tokens in ONE launch: q and k side by side in a [B, text + image, 2 c] buffer --
+                # rows [ctx, nk) written here (q | k), the k half of rows [0, ctx) by the text projection (its q half is never read)
+                # -- and V transposed into vtb; the attention kernel takes q and k as strided views of that buffer
+                qkb = torch.zeros((B, nk, 2 * c), dtype=f16, device=dev)
+                kbuf = qkb[:, :, c:]
+                kv_keep.append((kbuf, vtb, qkb))
+                gemm(a=a, w=w[pre + "qkv.w"], N=3 * c, B=B, H=T, W=1, c1=c, out=qkb[:, ctx:], out_ld=2 * c, bias=w[pre + "qkv.b"],
+                     out_bs=nk * 2 * c, out2=vtb[:, :, ctx:], out2_ld=nk, n_split=2 * c)
+                q_ptr, q_bs, q_ld = qkb[:, ctx:].data_ptr(), nk * 2 * c, 2 * c
+                k_ptr, k_bs, k_ld = kbuf.data_ptr(), nk * 2 * c, 2 * c
+                q = None
+            else:
+                q = dense(a, B, T, c, c, w[pre + "q.w"], bias=w[pre + "q.b"])
+                kbuf = torch.zeros((B, nk, c), dtype=f16, device=dev)
+                kv_keep.append((kbuf, vtb))
+                dense(a, B, T, c, c, w[pre + "k.w"], bias=w[pre + "k.b"], out=kbuf[:, ctx:], out_ld=c, out_bs=nk * c)
+                dense(a, B, T, c, c, w[pre + "v.w"], bias=w[pre + "v.b"], out=vtb[:, :, ctx:], out_ld=nk,
+                      out_mode=ops.OUT_TRANSPOSED)
+                q_ptr, q_bs, q_ld = q.data_ptr(), T * c, c
+                k_ptr, k_bs, k_ld = kbuf.data_ptr(), nk * c, c
             late_text[0] = True
-            dense(xf_out, B, ctx, xw, c, w[pre + "ek.w"], bias=w[pre + "ek.b"], out=kbuf, out_ld=c, out_bs=nk * c)
+            dense(xf_out, B, ctx, xw, c, w[pre + "ek.w"], bias=w[pre + "ek.b"], out=kbuf, out_ld=k_ld, out_bs=k_bs)
             dense(xf_out, B, ctx, xw, c, w[pre + "ev.w"], bias=w[pre + "ev.b"], out=vtb, out_ld=nk,
                   out_mode=ops.OUT_TRANSPOSED)
             late_text[0] = False
             o = a   # the normed input is dead after the projections
-            emit(lambda q=q, kbuf=kbuf, vtb=vtb, o=o: ops.attention(
-                q.data_ptr(), kbuf.data_ptr(), vtb.data_ptr(), o.data_ptr(), B, heads, 64, T, nk, 64 ** -0.5,
-                T * c, c, nk * c, c, c * nk, nk, T * c, c), "attention", 4 * B * heads * T * nk * 64)
+            emit(lambda vtb=vtb, o=o, q_ptr=q_ptr, q_bs=q_bs, q_ld=q_ld, k_ptr=k_ptr, k_bs=k_bs, k_ld=k_ld: ops.attention(
+                q_ptr, k_ptr, vtb.data_ptr(), o.data_ptr(), B, heads, 64, T, nk, 64 ** -0.5,
+                q_bs, q_ld, k_bs, k_ld, c * nk, nk, T * c, c), "attention", 4 * B * heads * T * nk * 64)
             out = dense(o, B, T, c, c, w[pre + "proj.w"], bias=w[pre + "proj.b"], residual=x)
-            A.release(q); A.release(a)
+            if q is not None:
+                A.release(q)
+            A.release(a)
             return out
 
         # ---- UNet walk (text2im_model.py:106-123)
@@ -796,9 +817,10 @@ class Text2ImUNet:
         # ---- key / value slots: the constant rows now, the per-step rows in loop_step
         def slots(Tt):
             ent = []
-            for j, (kbuf, vtb) in enumerate(P.kv_keep):
+            for j, kv in enumerate(P.kv_keep):
+                kbuf, vtb = kv[0], kv[1]      # (kbuf may be the k half of a merged [B, nk, 2 c] q | k buffer: strides, not shapes)
                 c, nk = kbuf.shape[2], kbuf.shape[1]
-                ent.append((Tt.k[j], kbuf, ctx * c * 2, nk * c * 2, c * 2, c * 2, ctx, c * 2))
+                ent.append((Tt.k[j], kbuf, ctx * c * 2, kbuf.stride(0) * 2, c * 2, kbuf.stride(1) * 2, ctx, c * 2))
                 ent.append((Tt.vt[j], vtb, c * ctx * 2, c * nk * 2, ctx * 2, nk * 2, c, ctx * 2))
             return ops.glide_kv_slots(ent, dev)
         L.tabs = (Tc, Tu)

@@ -47,7 +47,11 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
             # 1024, SDv2 batch 2 233 ops instead of 238 at EQUAL time (4.2824 vs 4.2825 ms: every consumer block folds the statistics
             # before its first MFMA, which costs what the 7 us launch did), Wukong batch 16 +0.4 %, 96 x 96 batch 8 +0.5 %; at 256
             # (the levels whose GroupNorm launch doubles as a split-K reduce) +0.5 % / +1.0 % / +1.6 %.  Off.
-            "unet_gn_proj_fuse": int(os.environ.get("MDX_UNET_GN_PROJ_FUSE", "0"))}
+            "unet_gn_proj_fuse": int(os.environ.get("MDX_UNET_GN_PROJ_FUSE", "0")),
+            # Taichu-GLIDE AttentionBlock (unet.py:267-297): 1 = q | k | v of the image tokens in ONE launch (q | k row-major into a
+            # [B, text + image, 2 C] buffer, V transposed: mdx_gemm_desc.n_split with out_bs) instead of three -- 44 launches fewer
+            # per base evaluation.  0 = three launches (A/B)
+            "glide_qkv_merge": int(os.environ.get("MDX_GLIDE_QKV_MERGE", "1"))}
 
 
 def set_option(name, value):

@@ -269,6 +269,44 @@ def test_full_size_unet_every_row_of_batches_that_are_not_benchmarked(model):
         assert worst <= 4e-3, (model, B, worst)
 
 
+_SWEEP_PAIRS = [("sd2", 32, 3), ("sd2", 32, 8), ("sd2", 32, 13), ("sd2", 40, 5), ("sd2", 48, 4), ("sd2", 48, 10), ("sd2", 64, 5),
+                ("sd2", 64, 8), ("sd2", 72, 3), ("wukong", 32, 4), ("wukong", 32, 16), ("wukong", 40, 6), ("wukong", 48, 7),
+                ("wukong", 64, 4), ("wukong", 64, 12)]
+
+
+@pytest.mark.parametrize("model", ["sd2", "wukong"])
+def test_shape_sweep_subset_with_an_oracle_row_per_pair(model):
+    """Round 6 (round-5 review item 6): a subset of tools/shape_sweep.py inside the suite, and not only batch-B against batch-1 of
+    the SAME library -- per (latent, batch) pair that neither the benchmarks nor the other parity tests run, ONE row of the batch-B
+    evaluation is compared with the fp32 oracle (rows rotate: B - 1, so that the rows a wrong tile-table row would leave unwritten --
+    the second half of a tile pair, round 5 -- are the ones looked at) and every row with its own batch-1 evaluation.  The tile table
+    is keyed by (M, N, K, ksize, launch variant): this is the check that a row measured at one (B, H, W) is right at another
+    factorisation of M."""
+    from minddiffusion_amd.configs import SD2_UNET, WUKONG_UNET
+    _threads()
+    cfg, ocfg, cd = (SD2_UNET, O.SD2_UNET, 1024) if model == "sd2" else (WUKONG_UNET, O.WUKONG_UNET, 768)
+    net, oracle = _unet(cfg, ocfg, 9)
+    net.use_graph = False
+    dev = lambda a: torch.tensor(a, device=DEV)
+    for (m, hw, B) in [q for q in _SWEEP_PAIRS if q[0] == model]:
+        rng = np.random.RandomState(1000 * hw + B)
+        x = rng.randn(B, 4, hw, hw).astype(np.float32)
+        ctx = rng.randn(B, 77, cd).astype(np.float32)
+        ts = np.full((B,), 400.0 + B, np.float32)
+        full = net(dev(x), dev(ts), dev(ctx)).cpu()
+        r = B - 1
+        ref = oracle(x[r:r + 1], torch.tensor(ts[r:r + 1]), ctx[r:r + 1])
+        check(f"sweep_{model}_latent{hw}_B{B}_row{r}_vs_oracle", full[r:r + 1], ref, rel_l2=5e-3, max_abs=5e-2)
+        worst = 0.0
+        for q in range(B):
+            one = net(dev(x[q:q + 1]), dev(ts[q:q + 1]), dev(ctx[q:q + 1])).cpu()
+            worst = max(worst, metrics_rel(full[q:q + 1], one))
+        print("PARITY", {"name": f"sweep_{model}_latent{hw}_B{B}_worst_row_vs_batch1", "rel_l2": worst})
+        assert worst <= 4e-3, (model, hw, B, worst)
+        net._plans.clear()
+        torch.cuda.empty_cache()
+
+
 def test_full_size_unet_320_pixel_latent_with_ragged_token_counts():
     """320 x 320 pixels = a 40 x 40 latent: the reference takes any multiple of 64 pixels (txt2img.py --H / --W), and the 10 x 10 and
     5 x 5 levels then have 100 / 25 tokens per sample -- not multiples of 8 (round 5: planning used to refuse them).  Full SDv2
