@@ -332,7 +332,7 @@ class Text2ImUNet:
             Bq, HW, C1 = x1.shape
             C = C1 + (0 if x2 is None else x2.shape[2])
             gn_need[0] = max(gn_need[0], ops.groupnorm_ws_floats(Bq, HW, C))
-            call = dict(x1=x1, x2=x2, cs=None, meta=len(meta),
+            call = dict(x1=x1, x2=x2, cs=None, meta=len(meta), g=g, b=b, eps=1e-5,
                         prod=(producer.get(x1.data_ptr()), None if x2 is None else producer.get(x2.data_ptr())))
             producer.pop(out.data_ptr(), None)
             gn_calls.append(call)
@@ -487,6 +487,10 @@ class Text2ImUNet:
             # keys / values = [text | image]: the text rows (encoder_kv of xf_out, unet.py:289-297) depend on the tokens alone, so
             # they live in buffers of their own (not the arena: they must survive the step) and their two projections join the
             # plan's text prefix; only the image rows are written per step
+            # Memory: these buffers are per (B, H, W) PLAN and are never arena-reused -- B * (text + image) * 3 c halves per
+            # AttentionBlock (base model at 16 rows: 22 blocks, 0.14 GB; up-sampler at 8 rows: 0.02 GB), plus a second captured
+            # graph (graph_main) per plan.  Whether the text rows are current is the CALLER's statement (text_epoch): nothing on the
+            # device re-checks tok_static, and forward_nhwc() without an epoch recomputes the prefix
             vtb = torch.zeros((B, c, nk), dtype=f16, device=dev)
             if ops.get_option("glide_qkv_merge") and T % 8 == 0:
                 # (round 6) q | k | v of the image tokens in ONE launch: q and k side by side in a [B, text + image, 2 c] buffer --
@@ -497,6 +501,12 @@ class Text2ImUNet:
                 kv_keep.append((kbuf, vtb, qkb))
                 gemm(a=a, w=w[pre + "qkv.w"], N=3 * c, B=B, H=T, W=1, c1=c, out=qkb[:, ctx:], out_ld=2 * c, bias=w[pre + "qkv.b"],
                      out_bs=nk * 2 * c, out2=vtb[:, :, ctx:], out2_ld=nk, n_split=2 * c)
+                # AttentionBlock.norm has no activation (unet.py:267-272): the merged projection can apply it to its A fragments from
+                # the producer's column statistics (mdx_gemm_desc.gn_colstats on a dense launch, as the LDM planner's
+                # unet_gn_proj_fuse).  Decided when the statistics are wired; on success the GroupNorm op is dropped
+                if (ops.get_option("glide_gn_qkv_fuse") and T % 64 == 0 and c % 64 == 0 and c <= 2560
+                        and producer.get(x.data_ptr()) is not None):
+                    gn_calls[-1]["proj"] = dict(desc=descs[-1], meta=len(meta) - 1)
                 q_ptr, q_bs, q_ld = qkb[:, ctx:].data_ptr(), nk * 2 * c, 2 * c
                 k_ptr, k_bs, k_ld = kbuf.data_ptr(), nk * 2 * c, 2 * c
                 q = None
@@ -611,6 +621,11 @@ class Text2ImUNet:
             for d in descs:
                 d.workspace = P.gemm_ws.data_ptr()
                 d.workspace_bytes = P.gemm_ws.numel() * 4
+        if any(m.get("dead") for m in meta):      # GroupNorm launches that moved into the GEMM behind them (all behind the emb chain)
+            keep = [i for i, m in enumerate(meta) if not m.get("dead")]
+            assert all(i >= P.n_emb for i, m in enumerate(meta) if m.get("dead"))
+            main[:] = [main[i] for i in keep]
+            meta[:] = [meta[i] for i in keep]
         ops.check_colstats_wiring(descs)
         ops.account_gemm_launches(meta)
         P.main, P.meta, P.descs, P.arena = main, meta, descs, A

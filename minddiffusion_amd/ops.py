@@ -51,7 +51,10 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
             # Taichu-GLIDE AttentionBlock (unet.py:267-297): 1 = q | k | v of the image tokens in ONE launch (q | k row-major into a
             # [B, text + image, 2 C] buffer, V transposed: mdx_gemm_desc.n_split with out_bs) instead of three -- 44 launches fewer
             # per base evaluation.  0 = three launches (A/B)
-            "glide_qkv_merge": int(os.environ.get("MDX_GLIDE_QKV_MERGE", "1"))}
+            "glide_qkv_merge": int(os.environ.get("MDX_GLIDE_QKV_MERGE", "1")),
+            # Taichu-GLIDE AttentionBlock.norm (GroupNorm without an activation) applied inside the merged q | k | v projection
+            # (mdx_gemm_desc.gn_colstats on a dense launch): 22 GroupNorm launches fewer per base evaluation
+            "glide_gn_qkv_fuse": int(os.environ.get("MDX_GLIDE_GN_QKV_FUSE", "0"))}
 
 
 def set_option(name, value):

@@ -164,8 +164,21 @@ def _build(graph=True):
     return net, OG.GlideUNetOracle(OTINY, params)
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_tiny_text2im_unet(graph):
+@pytest.mark.parametrize("graph,opts", [(False, {}), (True, {}), (True, {"glide_gn_qkv_fuse": 1}), (True, {"glide_qkv_merge": 0})])
+def test_tiny_text2im_unet(graph, opts, ops):
+    """opts: the planner options that change the AttentionBlock's launch list (round 6) -- AttentionBlock.norm applied inside the
+    merged q | k | v projection (opt-in: measured slower, profiles/r06_glide_gn_qkv_fuse_ab.txt) and the three-launch projection."""
+    old = {k: ops.get_option(k) for k in opts}
+    for k, v in opts.items():
+        ops.set_option(k, v)
+    try:
+        _tiny_text2im_unet(graph, "".join(f"_{k}{v}" for k, v in opts.items()))
+    finally:
+        for k, v in old.items():
+            ops.set_option(k, v)
+
+
+def _tiny_text2im_unet(graph, tag):
     net, oracle = _build(graph)
     rng = np.random.RandomState(7)
     B = 4
@@ -176,7 +189,7 @@ def test_tiny_text2im_unet(graph):
     ref = oracle(x, torch.full((B,), 333.0), tok, mask)
     got = net(torch.tensor(x, device=DEV), torch.full((B,), 333.0, device=DEV), torch.tensor(tok, device=DEV),
               torch.tensor(mask, device=DEV))
-    check(f"glide_tiny_unet_graph{int(graph)}", got, ref, rel_l2=5e-3, max_abs=5e-2)
+    check(f"glide_tiny_unet_graph{int(graph)}{tag}", got, ref, rel_l2=5e-3, max_abs=5e-2)
 
 
 def test_tiny_p_sample_loop():

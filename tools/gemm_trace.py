@@ -17,6 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # the trace marks exist only in the diagnostics build (make -C minddiffusion_amd/csrc trace)
 os.environ.setdefault("MDX_LIBRARY", os.path.join(ROOT, "minddiffusion_amd", "libmdx_trace.so"))
+if not os.path.exists(os.environ["MDX_LIBRARY"]):      # the diagnostics build does not travel to the GPU box (.gpurunignore): build it there
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "minddiffusion_amd", "csrc"), "-j16", "trace"], check=True,
+                   stdout=subprocess.DEVNULL)
 
 
 def trace_one(ops, lib, name, B, H, W, cin, cout, ks, sk, reps=3, flush_caches=True):
