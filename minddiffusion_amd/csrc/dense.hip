@@ -24,6 +24,11 @@
 
 namespace {
 
+// 1 = the batched store loops of gemm_epilogue<..., LEAN> (round 6); 0 = the generic per-pass loops (A/B builds: make variant)
+#ifndef MDX_LEAN_EPI
+#define MDX_LEAN_EPI 1
+#endif
+constexpr bool LEAN_EPI = MDX_LEAN_EPI != 0;
 constexpr int LNR_MAX = 24;      // LayerNorm-fold partials per row a thread holds across the K loop (K <= 1536); more: the epilogue folds
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -307,8 +312,8 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(const GemmParams p) {
     }
     const float lns_pre = __builtin_bit_cast(float, lns_raw);
     // (xpre is read only where the descriptor has a residual; the GEGLU store path fetches nothing)
-    gemm_epilogue<BM, BN, true, NW, LinearRows, NX>(p, acc, smem, LinearRows{m0}, n0, split, bpre, tile_m, tile_id, ln_pre, &lns_pre, xpre,
-                                                    ln_regs, lns_regs);
+    gemm_epilogue<BM, BN, true, NW, LinearRows, NX, LEAN_EPI>(p, acc, smem, LinearRows{m0}, n0, split, bpre, tile_m, tile_id, ln_pre, &lns_pre,
+                                                              xpre, ln_regs, lns_regs);
     trace_mark(p, 4);
 }
 

@@ -317,7 +317,12 @@ __device__ __forceinline__ bool splitk_last_block_reduce(const GemmParams& p, f3
 // Optional prefetches of the lean dense kernel (dense.hip), all issued BEFORE the K loop so that the epilogue of a lone block opens
 // with no global round trip: ln_pre = {mean, rstd} of this thread's row (tid < BM), lns_pre = S[n0 + tid] (tid < BN), xpre = the
 // residual (/ time-embedding) rows of this thread's first NXPRE store passes.
-template <int BM, int BN, bool SWAP, int NW, class RowMap, int NXPRE = 0>
+// LEAN (the lean dense kernel, dense.hip; round 6): the launch has no per-sample row bias and no out_bs (lean_dense_eligible), and
+// the store loops are written in BATCHES -- every staged row / residual row of the thread's passes requested first, then the
+// arithmetic, then the stores back to back, statistics last -- instead of one pass at a time behind the generic per-pass feature
+// branches (row bias and out_bs cost an integer division per pass; ~450 instructions per pass in the ISA of round 5, one pass
+// ~0.4 us for a wave that has its SIMD to itself).  Same operations on the same values in the same order: bit-identical output.
+template <int BM, int BN, bool SWAP, int NW, class RowMap, int NXPRE = 0, bool LEAN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / (16 * NW)][BN / 64], char* smem,
                                               const RowMap rm, const int n0, const int split, const float (&bpre)[16],
                                               const int row_block = 0, const int tile_lin = 0, const float* ln_pre = nullptr,
@@ -454,11 +459,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         const bool plain = p.epilogue != MDX_EPI_GEGLU;
         float bb[8];
         Row8Extras xa;
+        [[maybe_unused]] f16x8 lres[LEAN ? BM / RPP : 1];      // LEAN: the residual rows of ALL the thread's passes
         if (plain) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) bb[e] = bpre[e];   // fetched before the K loop (gemm_bias_prefetch)
             const int m = rm(r0);
-            if constexpr (NXPRE > 0) {
+            if constexpr (LEAN) {
+                // the rows the kernel did not fetch before its K loop: all requested now, in front of the staging pass, through a
+                // descriptor that answers zero when there is no residual (unconditional loads: nothing waits behind a branch)
+                const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(p.residual, p.residual ? p.res_bytes : 0u);
+#pragma unroll
+                for (int pass = 0; pass < BM / RPP; ++pass) {
+                    if (pass < NXPRE) {
+                        lres[pass] = xpre[pass < NXPRE ? pass : 0].res;
+                    } else {
+                        const int mp = rm(r0 + pass * RPP);
+                        const unsigned off = (mp < p.M && n < p.N) ? ((unsigned)mp * (unsigned)p.residual_ld + (unsigned)n) * 2u : MDX_OOB;
+                        lres[pass] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0));
+                    }
+                }
+            } else if constexpr (NXPRE > 0) {
                 xa = xpre[0];
             } else {
                 if (m < p.M && n < p.N) xa = epilogue_prefetch_row8(p, m, n);
@@ -523,6 +543,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     ba[e] = bpre[e];
                     bg[e] = bpre[8 + e];
                 }
+                if constexpr (LEAN) {
+                    constexpr int GP = BM / (NT / 8);      // passes: 32 rows each
+                    const bool okn = pn < p.N;
+                    const bool has_res = p.residual != nullptr;      // (uniform; GEGLU with a residual is not a shape of the models)
+                    f16x8 va[GP], vg[GP];
+#pragma unroll
+                    for (int pass = 0; pass < GP; ++pass) {
+                        const int row = r0 + pass * (NT / 8);
+                        va[pass] = *reinterpret_cast<const f16x8*>(&stg[row * SLD + chunk * 8]);
+                        vg[pass] = *reinterpret_cast<const f16x8*>(&stg[row * SLD + 64 + chunk * 8]);
+                    }
+#pragma unroll
+                    for (int pass = 0; pass < GP; ++pass) {
+                        const int m = rm(r0 + pass * (NT / 8));
+                        if (m < p.M && okn) {
+                            float f[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                f[e] = ((float)va[pass][e] + ba[e]) * gelu_tanh_f((float)vg[pass][e] + bg[e]);
+                            if (has_res) {
+                                const f16x8 rr = *reinterpret_cast<const f16x8*>(p.residual + (size_t)m * p.residual_ld + on);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] += (float)rr[e];
+                            }
+                            f16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (f16)f[e];
+                            *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + on) = o;
+                        }
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int pass = 0; pass < BM / (NT / 8); ++pass) {
                     const int row = r0 + pass * (NT / 8);
@@ -547,6 +599,71 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             float cs[8], cq[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
+            if constexpr (LEAN) {
+                // (epilogue is MDX_EPI_NONE here: the lean kernel takes no GELU / QuickGELU launch)
+                constexpr int PASSES = BM / RPP;
+                const bool okn = n < p.N;
+                const bool has_res = p.residual != nullptr;      // uniform
+                // (ii) the staged rows
+                f16x8 sv[PASSES];
+#pragma unroll
+                for (int pass = 0; pass < PASSES; ++pass)
+                    sv[pass] = *reinterpret_cast<const f16x8*>(&stg[(r0 + pass * RPP) * SLD + chunk * 8]);
+                // (iii) arithmetic + stores
+                f16x8 ov[PASSES];
+#pragma unroll
+                for (int pass = 0; pass < PASSES; ++pass) {
+                    const int m = rm(r0 + pass * RPP);
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (float)sv[pass][e] + bb[e];
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += (float)lres[pass][e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[pass][e] = (f16)f[e];
+                    if (m < p.M && okn) *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + n) = ov[pass];
+                }
+                // (iv) statistics of the fp16 values stored, in the generic loop's order
+                if (p.stats_out) {
+#pragma unroll
+                    for (int pass = 0; pass < PASSES; ++pass) {
+                        const int m = rm(r0 + pass * RPP);
+                        const bool ok = m < p.M && okn;
+                        float su = 0.f, sq = 0.f;
+                        if (ok) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float t = (float)ov[pass][e];
+                                su += t;
+                                sq += t * t;
+                            }
+                        }
+#pragma unroll
+                        for (int off = 4; off >= 1; off >>= 1) {
+                            su += __shfl_xor(su, off, 64);
+                            sq += __shfl_xor(sq, off, 64);
+                        }
+                        if ((chunk & 7) == 0 && ok)
+                            reinterpret_cast<float2*>(p.stats_out)[(size_t)m * (p.N >> 6) + (n >> 6)] = make_float2(su, sq);
+                    }
+                }
+                if (colstats) {
+#pragma unroll
+                    for (int pass = 0; pass < PASSES; ++pass) {
+                        const int m = rm(r0 + pass * RPP);
+                        if (m < p.M && okn) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float t = (float)ov[pass][e];
+                                cs[e] += t;
+                                cq[e] += t * t;
+                            }
+                        }
+                    }
+                }
+            }
             auto store_rows = [&](auto act) {
 #pragma unroll
                 for (int pass = 0; pass < BM / RPP; ++pass) {
@@ -597,13 +714,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     xa = xn;
                 }
             };
-            const int epi = __builtin_amdgcn_readfirstlane(p.epilogue);
-            if (epi == MDX_EPI_NONE)
-                store_rows([](float x) { return x; });
-            else if (epi == MDX_EPI_GELU)
-                store_rows([](float x) { return gelu_tanh_f(x); });
-            else
-                store_rows([](float x) { return quick_gelu_f(x); });
+            if constexpr (!LEAN) {
+                const int epi = __builtin_amdgcn_readfirstlane(p.epilogue);
+                if (epi == MDX_EPI_NONE)
+                    store_rows([](float x) { return x; });
+                else if (epi == MDX_EPI_GELU)
+                    store_rows([](float x) { return gelu_tanh_f(x); });
+                else
+                    store_rows([](float x) { return quick_gelu_f(x); });
+            }
             if (colstats) {   // (block-uniform) fold the RPP row lanes of every column in a fixed order: deterministic
                 __syncthreads();                                  // every thread is done reading the staged tile
                 float* part = reinterpret_cast<float*>(smem);     // [RPP][BN][2]
