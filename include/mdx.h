@@ -507,6 +507,10 @@ int mdx_probe_gemm_trace(void* buf, size_t bytes);
  * 6 v_pk_fma_f16, 7 v_pk_max_f16 -- on
  * `nblocks` blocks of 256 threads; time it from the host (tools/exp/r04n_valu_probe.py). */
 int mdx_probe_valu_rate(int kind, int iters, int nblocks, float* sink, mdx_stream_t s);
+/* Diagnostics (round 6): four slots per iteration of { one 32x32x16 MFMA } and / or VALU work -- kind 0 MFMA alone, 1 MFMA + 2 v_exp_f32,
+ * 2 MFMA + 8 v_fma_f32, 3 the 2 exps alone, 4 the 8 fmas alone, 5 MFMA + the softmax mix of one score pair, 6 that mix alone: does VALU
+ * work run in the shadow of an MFMA?  (tools/exp/r06_mix_probe.py) */
+int mdx_probe_mix_rate(int kind, int iters, int nblocks, float* sink, mdx_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -149,6 +149,7 @@ _ENV_OPTIONS = {
     "MDX_GN_WIDE_ROWS": ("gn_wide_rows", int), "MDX_GN_BOOST_MB": ("gn_boost_mb", int), "MDX_ATTN_OCC3": ("attn_occ3", int), "MDX_ATTN_KV_SPLIT": ("attn_kv_split", int),
     "MDX_ATTN_FAST_STAGE": ("attn_fast_stage", int), "MDX_GN_PREFETCH": ("gn_prefetch", int), "MDX_GEMM_LN_PREFETCH": ("gemm_ln_prefetch", int),
     "MDX_GEMM_DENSE_ISSUE": ("gemm_dense_issue", int), "MDX_GEMM_LEAN_DENSE": ("gemm_lean_dense", int),
+    "MDX_ATTN_PIPE": ("attn_pipe", int),
 }
 
 

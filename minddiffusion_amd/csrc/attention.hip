@@ -21,6 +21,7 @@
 #include "mdx_common.h"
 
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -46,6 +47,122 @@ struct AttnParams {
 constexpr int BQ = 128;
 constexpr int BKV = 64;
 constexpr int ATTN_MAX_SPLITS_K = 8;      // most KV splits of one item (mdx_attention_splitkv_f16)
+
+// The end of a block's work, shared by attn_kernel and attn_pipe_kernel: O /= l, staged [q][d] per wave in LDS, full-row stores -- or,
+// for a split-KV launch, the partial hand-off (normalised partial + {reference, row sum} to the workspace, ticket, last arriver combines).
+template <int D>
+__device__ __forceinline__ void attn_finish(const AttnParams& p, f32x16 (&acc_o)[(D + 31) / 32], const float m_run, const float l_run,
+                                            char* smem, const int b, const int h, const int qblk, const int q0, const int split) {
+    constexpr int DT = (D + 31) / 32;
+    constexpr bool LROW = (D % 32) != 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    // ---- finalize: O /= l ; stage [q][d] per wave in LDS, then full-row stores
+    float l_tot;
+    if constexpr (LROW) {      // O^T row D: d tile D / 32, local row D % 32 = (r & 3) + 8 (r >> 2) + 4 hi
+        constexpr int LR = D % 32, LREG = (LR & 3) + 4 * (LR >> 3), LHI = (LR >> 2) & 1;
+        const float mine = acc_o[D / 32][LREG];
+        const float other = __shfl_xor(mine, 32, 64);
+        l_tot = (hi == LHI) ? mine : other;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
+    const float inv = 1.0f / l_tot;
+    constexpr int OLD = DT * 32 + 8;
+    f16* og = reinterpret_cast<f16*>(smem) + wave * 32 * OLD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (f16)(acc_o[d][4 * g + e] * inv);
+            *reinterpret_cast<f16x4*>(&og[l31 * OLD + d * 32 + 8 * g + 4 * hi]) = v;
+        }
+    __syncthreads();
+    constexpr int CPR = D / 8;   // 16-B chunks per output row
+    if (p.nsplit > 1) {
+        // ---- split-KV hand-off (the scheme of splitk_last_block_reduce, gemm_internal.h): this block's NORMALISED partial
+        // O~ = O / l in fp16 (the rounding the final output gets anyway) and per query {m * scale_log2, l} go to the workspace with
+        // write-through (sc1) stores; drain; block barrier; one lane takes a ticket on the item's counter; the last arriver reads
+        // all nsplit partials with sc1 loads and stores  sum_s w_s O~_s / sum_s w_s,  w_s = l_s 2^(m_s - max m)  -- summed in split
+        // order whoever arrives last, so the result does not depend on the schedule.
+        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+        constexpr unsigned O_BYTES = (unsigned)BQ * D * 2u;
+        constexpr unsigned PART = O_BYTES + (unsigned)BQ * 8u;
+        const size_t item = ((size_t)b * p.heads + h) * p.qblocks + qblk;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.ws_part + item * p.nsplit * PART, (unsigned)p.nsplit * PART);
+        for (int idx = lane; idx < 32 * CPR; idx += 64) {
+            const int row = idx / CPR, chunk = idx - row * CPR;
+            const f16x8 v = *reinterpret_cast<const f16x8*>(&og[row * OLD + chunk * 8]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), rs,
+                                                   (unsigned)split * PART + (unsigned)(((wave * 32 + row) * D + chunk * 8) * 2), 0, /*sc1*/ 16);
+        }
+        if (hi == 0) {
+            u32x2v ml;
+            ml[0] = __float_as_uint(m_run * p.scale_log2);
+            ml[1] = __float_as_uint(l_tot);
+            __builtin_amdgcn_raw_buffer_store_b64(ml, rs, (unsigned)split * PART + O_BYTES + (unsigned)(wave * 32 + l31) * 8u, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem + 4 * 32 * OLD * 2);      // behind the four waves' staging rows
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.tickets + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old >= (unsigned)p.nsplit) __builtin_trap();     // counters not zero on entry (two streams on one workspace, mdx.h)
+            *flag = old == (unsigned)p.nsplit - 1u;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        if (tid == 0) __hip_atomic_store(p.tickets + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int idx = tid; idx < BQ * CPR; idx += 256) {
+            const int row = idx / CPR, chunk = idx - row * CPR;
+            const int qi = qblk * BQ + row;
+            if (qi >= p.Nq) continue;
+            // every partial's {reference, row sum} and O~ chunk in flight together (one fabric round trip, not 2 * nsplit)
+            u32x2v ml[ATTN_MAX_SPLITS_K];
+            u32x4v raw[ATTN_MAX_SPLITS_K];
+#pragma unroll
+            for (int z = 0; z < ATTN_MAX_SPLITS_K; ++z)
+                if (z < p.nsplit) {
+                    ml[z] = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)z * PART + O_BYTES + (unsigned)row * 8u, 0, 16);
+                    raw[z] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)z * PART + (unsigned)((row * D + chunk * 8) * 2), 0, 16);
+                }
+            float mmax = -INFINITY;
+#pragma unroll
+            for (int z = 0; z < ATTN_MAX_SPLITS_K; ++z)
+                if (z < p.nsplit) mmax = fmaxf(mmax, __uint_as_float(ml[z][0]));
+            float acc[8], wsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int z = 0; z < ATTN_MAX_SPLITS_K; ++z)
+                if (z < p.nsplit) {
+                    const f16x8 v = __builtin_bit_cast(f16x8, raw[z]);
+                    const float w = __uint_as_float(ml[z][1]) * __builtin_amdgcn_exp2f(__uint_as_float(ml[z][0]) - mmax);
+                    wsum += w;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += w * (float)v[e];
+                }
+            const float winv = 1.0f / wsum;
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)(acc[e] * winv);
+            *reinterpret_cast<f16x8*>(p.o + (size_t)b * p.o_bs + (size_t)qi * p.o_ld + h * D + chunk * 8) = o;
+        }
+        return;
+    }
+    for (int idx = lane; idx < 32 * CPR; idx += 64) {
+        const int row = idx / CPR, chunk = idx - row * CPR;
+        const int qi = q0 + row;
+        if (qi < p.Nq) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(&og[row * OLD + chunk * 8]);
+            *reinterpret_cast<f16x8*>(p.o + (size_t)b * p.o_bs + (size_t)qi * p.o_ld + h * D + chunk * 8) = v;
+        }
+    }
+}
 
 // OCC = blocks the register budget admits per CU (a block is one wave per SIMD): 2 is the form of rounds 1-3 (<= 256 VGPRs);
 // 3 (<= 168 VGPRs, D <= 64 only: the D = 64 kernel needs 182 unconstrained and fits 168 with eight spills OUTSIDE the tile loop)
@@ -322,110 +439,7 @@ __global__ __launch_bounds__(256, OCC) void attn_kernel(const AttnParams p) {
         __syncthreads();
     }
 
-    // ---- finalize: O /= l ; stage [q][d] per wave in LDS, then full-row stores
-    float l_tot;
-    if constexpr (LROW) {      // O^T row D: d tile D / 32, local row D % 32 = (r & 3) + 8 (r >> 2) + 4 hi
-        constexpr int LR = D % 32, LREG = (LR & 3) + 4 * (LR >> 3), LHI = (LR >> 2) & 1;
-        const float mine = acc_o[D / 32][LREG];
-        const float other = __shfl_xor(mine, 32, 64);
-        l_tot = (hi == LHI) ? mine : other;
-    } else {
-        l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    }
-    const float inv = 1.0f / l_tot;
-    constexpr int OLD = DT * 32 + 8;
-    f16* og = reinterpret_cast<f16*>(smem) + wave * 32 * OLD;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f16x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (f16)(acc_o[d][4 * g + e] * inv);
-            *reinterpret_cast<f16x4*>(&og[l31 * OLD + d * 32 + 8 * g + 4 * hi]) = v;
-        }
-    __syncthreads();
-    constexpr int CPR = D / 8;   // 16-B chunks per output row
-    if (p.nsplit > 1) {
-        // ---- split-KV hand-off (the scheme of splitk_last_block_reduce, gemm_internal.h): this block's NORMALISED partial
-        // O~ = O / l in fp16 (the rounding the final output gets anyway) and per query {m * scale_log2, l} go to the workspace with
-        // write-through (sc1) stores; drain; block barrier; one lane takes a ticket on the item's counter; the last arriver reads
-        // all nsplit partials with sc1 loads and stores  sum_s w_s O~_s / sum_s w_s,  w_s = l_s 2^(m_s - max m)  -- summed in split
-        // order whoever arrives last, so the result does not depend on the schedule.
-        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-        typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
-        constexpr unsigned O_BYTES = (unsigned)BQ * D * 2u;
-        constexpr unsigned PART = O_BYTES + (unsigned)BQ * 8u;
-        const size_t item = ((size_t)b * p.heads + h) * p.qblocks + qblk;
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.ws_part + item * p.nsplit * PART, (unsigned)p.nsplit * PART);
-        for (int idx = lane; idx < 32 * CPR; idx += 64) {
-            const int row = idx / CPR, chunk = idx - row * CPR;
-            const f16x8 v = *reinterpret_cast<const f16x8*>(&og[row * OLD + chunk * 8]);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), rs,
-                                                   (unsigned)split * PART + (unsigned)(((wave * 32 + row) * D + chunk * 8) * 2), 0, /*sc1*/ 16);
-        }
-        if (hi == 0) {
-            u32x2v ml;
-            ml[0] = __float_as_uint(m_run * p.scale_log2);
-            ml[1] = __float_as_uint(l_tot);
-            __builtin_amdgcn_raw_buffer_store_b64(ml, rs, (unsigned)split * PART + O_BYTES + (unsigned)(wave * 32 + l31) * 8u, 0, 16);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem + 4 * 32 * OLD * 2);      // behind the four waves' staging rows
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(p.tickets + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old >= (unsigned)p.nsplit) __builtin_trap();     // counters not zero on entry (two streams on one workspace, mdx.h)
-            *flag = old == (unsigned)p.nsplit - 1u;
-        }
-        __syncthreads();
-        if (*flag == 0) return;
-        if (tid == 0) __hip_atomic_store(p.tickets + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int idx = tid; idx < BQ * CPR; idx += 256) {
-            const int row = idx / CPR, chunk = idx - row * CPR;
-            const int qi = qblk * BQ + row;
-            if (qi >= p.Nq) continue;
-            // every partial's {reference, row sum} and O~ chunk in flight together (one fabric round trip, not 2 * nsplit)
-            u32x2v ml[ATTN_MAX_SPLITS_K];
-            u32x4v raw[ATTN_MAX_SPLITS_K];
-#pragma unroll
-            for (int z = 0; z < ATTN_MAX_SPLITS_K; ++z)
-                if (z < p.nsplit) {
-                    ml[z] = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)z * PART + O_BYTES + (unsigned)row * 8u, 0, 16);
-                    raw[z] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)z * PART + (unsigned)((row * D + chunk * 8) * 2), 0, 16);
-                }
-            float mmax = -INFINITY;
-#pragma unroll
-            for (int z = 0; z < ATTN_MAX_SPLITS_K; ++z)
-                if (z < p.nsplit) mmax = fmaxf(mmax, __uint_as_float(ml[z][0]));
-            float acc[8], wsum = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-            for (int z = 0; z < ATTN_MAX_SPLITS_K; ++z)
-                if (z < p.nsplit) {
-                    const f16x8 v = __builtin_bit_cast(f16x8, raw[z]);
-                    const float w = __uint_as_float(ml[z][1]) * __builtin_amdgcn_exp2f(__uint_as_float(ml[z][0]) - mmax);
-                    wsum += w;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += w * (float)v[e];
-                }
-            const float winv = 1.0f / wsum;
-            f16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)(acc[e] * winv);
-            *reinterpret_cast<f16x8*>(p.o + (size_t)b * p.o_bs + (size_t)qi * p.o_ld + h * D + chunk * 8) = o;
-        }
-        return;
-    }
-    for (int idx = lane; idx < 32 * CPR; idx += 64) {
-        const int row = idx / CPR, chunk = idx - row * CPR;
-        const int qi = q0 + row;
-        if (qi < p.Nq) {
-            const f16x8 v = *reinterpret_cast<const f16x8*>(&og[row * OLD + chunk * 8]);
-            *reinterpret_cast<f16x8*>(p.o + (size_t)b * p.o_bs + (size_t)qi * p.o_ld + h * D + chunk * 8) = v;
-        }
-    }
+    attn_finish<D>(p, acc_o, m_run, l_run, smem, b, h, qblk, q0, split);
 }
 
 
@@ -658,6 +672,324 @@ __global__ __launch_bounds__(512) void attn8_kernel(const AttnParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// attn_pipe (round 6): the four-wave flash attention with the tile loop SOFTWARE-PIPELINED inside every wave.
+//
+// attn_kernel runs a key tile as three dependent bursts -- 2 KS MFMAs of S^T = K Q^T, ~130 VALU instructions of softmax, 4 DT MFMAs
+// of O^T += V^T P^T -- and leaves it to the other waves of the SIMD to fill the pipe that a burst does not use.  They do not: a wave
+// issues one VALU instruction per ~7 clocks behind its own dependencies, the matrix pipe idles through every softmax and the VALU
+// through every MFMA burst (PMC, profiles/r02_attention_pmc.md: VALU issue 58 % + matrix pipe 38 % of the SIMD cycles), and the
+// eight-wave ping-pong (attn8 above) showed that coupling two waves with barriers does not buy the overlap either.  Here the overlap
+// is built INSIDE the wave's instruction stream: the iteration of key tile t issues
+//     QK^T of tile t + 1   (its scores wait in a second accumulator pair)
+//     softmax of tile t    (scores computed one iteration earlier; its row maximum was taken at the END of that iteration)
+//     PV of tile t
+// as 2 KS + 4 DT SLOTS of { one MFMA, ~6 independent VALU instructions } fenced with sched_barriers -- every MFMA has VALU work of an
+// older tile to run in its shadow and every exponential has an MFMA in flight -- plus the LDS fragment reads one or two slots ahead
+// of their MFMA.  K is staged one tile ahead of V (K(t + 2) and V(t + 1) are issued in iteration t): the same two-deep LDS ring.
+// Same arithmetic in the same order per output element as attn_kernel (the lazy reference maximum included): BIT-IDENTICAL results.
+// Full key tiles only (Nk % 64 == 0), no causal mask; unsplit or split-KV: the self-attention launches of the UNets (4096 / 9216 / 1024 /
+// 256 tokens; GLIDE's text | image keys); everything else stays on attn_kernel.
+#ifndef MDX_ATTN_PIPE_PKASM
+#define MDX_ATTN_PIPE_PKASM 0
+#endif
+template <class F, int... I>
+__device__ __forceinline__ void attn_static_for(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnParams p) {
+    mdx_kernarg_touch<sizeof(AttnParams)>();
+    constexpr int KS = (D + 15) / 16;
+    constexpr int DT = (D + 31) / 32;
+    constexpr int KCH = (2 * KS <= 8) ? 8 : (2 * KS <= 16 ? 16 : 32);
+    constexpr int K_ROWB = KCH * 16;
+    constexpr int K_RPI = 64 / KCH;
+    constexpr int K_DMA = BKV / K_RPI / 4;
+    constexpr int K_BYTES = BKV * K_ROWB;
+    constexpr int V_ROWB = 128;
+    constexpr int V_ROWS = DT * 32;
+    constexpr int V_DMA = (V_ROWS / 8 + 3) / 4;
+    constexpr int V_BYTES = V_ROWS * V_ROWB;
+    constexpr bool LROW = (D % 32) != 0;       // row sums through the ones row of the V^T tile (attn_kernel)
+    constexpr int NQ = 2 * KS;                 // QK^T MFMAs of a tile
+    constexpr int NP = 4 * DT;                 // PV MFMAs of a tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // K[2] | V^T[2]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    // split-KV launches: blockIdx.x = query block * nsplit + split (attn_kernel's order); this block's tiles [t_begin, t_end), even boundaries
+    const int qblk = p.nsplit > 1 ? (int)blockIdx.x / p.nsplit : (int)blockIdx.x;
+    const int split = p.nsplit > 1 ? (int)blockIdx.x - qblk * p.nsplit : 0;
+    const int q0 = qblk * BQ + wave * 32;
+    const int ntiles = p.Nk / BKV;
+    int t_begin = 0, t_end = ntiles;
+    if (p.nsplit > 1) {
+        t_begin = ((split * ntiles) / p.nsplit) & ~1;
+        t_end = split + 1 == p.nsplit ? ntiles : ((((split + 1) * ntiles) / p.nsplit) & ~1);
+    }
+    const int nt = t_end - t_begin;      // >= 2 (the host splits no finer than two tiles each)
+
+    const f16* kb = p.k + (size_t)b * p.k_bs + h * D;
+    const f16* vb = p.vt + (size_t)b * p.vt_bs + (size_t)h * D * p.vt_ld;
+    const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(kb, p.k_bytes);
+    const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(vb, p.vt_bytes);
+
+    f16x8 qf[KS];
+    {
+        const int qi = q0 + l31;
+        const f16* qp = p.q + (size_t)b * p.q_bs + (size_t)qi * p.q_ld + h * D + hi * 8;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (qi < p.Nq && s * 16 + hi * 8 < D)
+                qf[s] = *reinterpret_cast<const f16x8*>(qp + s * 16);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[s][e] = (f16)0.f;
+        }
+    }
+    auto kkey = [](int row) { return KCH == 8 ? ((row >> 1) & 7) : (row & 15); };
+    // every tile is full: per-lane source offsets once, the tile offset in the DMA's scalar operand (attn_kernel's stage_full)
+    unsigned k_voff[K_DMA], v_voff[V_DMA];
+#pragma unroll
+    for (int j = 0; j < K_DMA; ++j) {
+        const int row = (wave * K_DMA + j) * K_RPI + lane / KCH;
+        const int chunk = (lane % KCH) ^ kkey(row);
+        k_voff[j] = (chunk * 8 < D) ? (unsigned)(((size_t)row * p.k_ld + chunk * 8) * 2) : MDX_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < V_DMA; ++j) {
+        const int row = (wave * V_DMA + j) * 8 + (lane >> 3);
+        const unsigned chunk = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+        v_voff[j] = (row < D) ? (unsigned)(((size_t)row * p.vt_ld + chunk * 8) * 2) : MDX_OOB;
+    }
+    const unsigned k_tile_bytes = (unsigned)BKV * (unsigned)p.k_ld * 2u;
+    auto stage_k = [&](int t, int buf) {
+#pragma unroll
+        for (int j = 0; j < K_DMA; ++j)
+            dma16s(rs_k, smem + buf * K_BYTES + (wave * K_DMA + j) * 1024, k_voff[j], (unsigned)(t_begin + t) * k_tile_bytes);
+    };
+    auto stage_v = [&](int t, int buf) {
+#pragma unroll
+        for (int j = 0; j < V_DMA; ++j) {
+            const int inst = wave * V_DMA + j;
+            if (inst * 8 < (LROW ? D : V_ROWS))
+                dma16s(rs_v, smem + 2 * K_BYTES + buf * V_BYTES + inst * 1024, v_voff[j], (unsigned)(t_begin + t) * (BKV * 2u));
+        }
+    };
+
+    f32x16 acc_o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int vswz = (lane >> 1) & 7;
+    const int krow_l = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
+    f32x2 sc2v = {p.scale_log2, p.scale_log2};      // in VECTOR registers: with the scale in SGPRs the compiler splits every v_pk_fma_f32 in two v_fma_f32
+    asm volatile("" : "+v"(sc2v));
+
+    // K fragment s of 32-key tile kt (LDS buffer kb_i) / V^T fragment of chunk c, d tile d (buffer vb_i)
+    auto kfrag = [&](const int kb_i, const int kt, const int s) {
+        const int krow = kt * 32 + krow_l;
+        return *reinterpret_cast<const f16x8*>(smem + kb_i * K_BYTES + krow * K_ROWB + (((2 * s + hi) ^ kkey(krow)) << 4));
+    };
+    auto vfrag = [&](const int vb_i, const int c, const int d) {
+        return *reinterpret_cast<const f16x8*>(smem + 2 * K_BYTES + vb_i * V_BYTES + (d * 32 + l31) * V_ROWB + (((2 * c + hi) ^ vswz) << 4));
+    };
+    // row maximum of a score pair (this lane's 32 keys, then the lane ^ 32 exchange) -- attn_kernel's order
+    auto row_max = [&](const f32x16 (&sc)[2]) {
+        float mx = sc[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+
+    if constexpr (LROW) {
+        for (int i = tid; i < 2 * (V_ROWS - D) * 8; i += 256) {
+            const int buf = i / ((V_ROWS - D) * 8), rem = i - buf * (V_ROWS - D) * 8;
+            const int row = D + (rem >> 3);
+            f16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = row == D ? (f16)1.0f : (f16)0.f;
+            *reinterpret_cast<f16x8*>(smem + 2 * K_BYTES + buf * V_BYTES + row * V_ROWB + (rem & 7) * 16) = v;
+        }
+    }
+    // ---- prologue: K(0), V(0); then K(1) in flight under S(0) = K(0) Q^T and its row maximum
+    stage_k(0, 0);
+    stage_v(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nt > 1) stage_k(1, 1);
+    f32x16 sA[2], sB[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sA[kt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) sA[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfrag(0, kt, s), qf[s], sA[kt], 0, 0, 0);
+    }
+    float mx_cur = row_max(sA);
+
+    // One iteration: softmax + PV of the tile whose scores are `sc` (V^T in buffer VB), QK^T of the next tile (K in buffer KBN) into
+    // `sn` when NEXT.  mx_cur = row maximum of sc on entry, of sn on exit.
+    auto body = [&](auto kbn_c, auto vb_c, auto next_c, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
+        constexpr int KBN = decltype(kbn_c)::value;
+        constexpr int VB = decltype(vb_c)::value;
+        constexpr bool NEXT = decltype(next_c)::value;
+        // reference maximum (attn_kernel's lazy rule), outside the slots: the rescale is a rare branch
+        const float m_cand = fmaxf(m_run, mx_cur);
+        if (__builtin_amdgcn_ballot_w64((m_cand - m_run) * p.scale_log2 > 8.0f)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) * p.scale_log2);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+            m_run = m_cand;
+        }
+        const float mb = m_run * p.scale_log2;
+        const f32x2 nmb2 = {-mb, -mb};
+        f32x2 psum2 = {0.f, 0.f};
+        unsigned pw[16];       // P as packed fp16 pairs: pw[4 c .. 4 c + 3] = the B fragment of 16-key chunk c
+        // pair j (0 .. 15) of the tile: scores sc[j >> 3][2 (j & 7)], [.. + 1] -> two weights of P chunk j >> 2.  The empty asm
+        // statements pin every result INSIDE the slot it is written in: without them the row-sum adds (no consumer before the end
+        // of the iteration) and the exponentials (consumed slots later) are sunk to their uses, back into a serial burst
+        auto pair = [&](const int j) {
+            const int kt = j >> 3, r = 2 * (j & 7);
+            const f32x2 x2 = {sc[kt][r], sc[kt][r + 1]};
+            f32x2 a2;      // (the compiler splits the builtin in two v_fma_f32; v_pk_fma_f32 through inline asm measured SLOWER -- 9216 tokens 951 -> 1014 us,
+                           // profiles/r06_attn_pipe.txt: the asm is opaque to the hazard / latency model the slots are scheduled with)
+#if MDX_ATTN_PIPE_PKASM
+            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(a2) : "v"(x2), "v"(sc2v), "v"(nmb2));
+#else
+            a2 = __builtin_elementwise_fma(x2, sc2v, nmb2);
+#endif
+            const f32x2 pv2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+            if constexpr (!LROW) {
+                psum2 += pv2;
+                asm volatile("" : "+v"(psum2));
+            }
+            typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+            const h16x2 hv = {(f16)pv2.x, (f16)pv2.y};
+            pw[j] = __builtin_bit_cast(unsigned, hv);
+            asm volatile("" : "+v"(pw[j]));
+        };
+        auto pfrag = [&](const int c) {
+            u32x4a v;
+            v[0] = pw[4 * c]; v[1] = pw[4 * c + 1]; v[2] = pw[4 * c + 2]; v[3] = pw[4 * c + 3];
+            return __builtin_bit_cast(f16x8, v);
+        };
+        // Slots.  0 .. NQ - 1: QK^T MFMA i (k-step i >> 1 of key half i & 1: the two accumulator chains alternate) over pairs 0 .. 7.
+        // NQ .. NQ + NP - 1: PV MFMA ip (chunk ip / DT, d tile ip % DT); pairs 8 .. 15 over the first NP - DT of them (chunk 2 is
+        // complete before slot NQ + 2 DT, chunk 3 before NQ + 3 DT) and the next tile's row maximum, 32 / NP scores per slot.
+        // LDS fragments are read TWO slots ahead of their MFMA (a read issued one slot ahead is still in flight when it is needed).
+        float mx_part = -INFINITY;
+        f16x8 fr[3] = {};        // fragment of slot i sits in fr[i % 3]
+        auto frag_of = [&](const int i) {      // the LDS fragment slot i multiplies (K of the NEXT tile, or V^T of this one)
+            if (i < NQ) return kfrag(KBN, i & 1, i >> 1);
+            return vfrag(VB, (i - NQ) / DT, (i - NQ) % DT);
+        };
+        constexpr int I0 = NEXT ? 0 : NQ;       // first slot that exists
+        if constexpr (!NEXT) {                  // last tile: no QK^T slots -- their pairs first
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pair(j);
+        }
+        fr[I0 % 3] = frag_of(I0);
+        fr[(I0 + 1) % 3] = frag_of(I0 + 1);
+        attn_static_for([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i >= I0) {
+                if constexpr (i + 2 < NQ + NP) fr[(i + 2) % 3] = frag_of(i + 2);
+                if constexpr (i < NQ) {
+                    if constexpr (i < 2)      // first MFMA of a chain: C = 0 (an inline constant, no accumulator initialisation)
+                        sn[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i % 3], qf[i >> 1], f32x16{}, 0, 0, 0);
+                    else
+                        sn[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i % 3], qf[i >> 1], sn[i & 1], 0, 0, 0);
+#pragma unroll
+                    for (int j = (i * 8) / NQ; j < ((i + 1) * 8) / NQ; ++j) pair(j);
+                } else {
+                    constexpr int ip = i - NQ;
+                    acc_o[ip % DT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[i % 3], pfrag(ip / DT), acc_o[ip % DT], 0, 0, 0);
+#pragma unroll
+                    for (int j = 8; j < 16; ++j)
+                        if (((j - 8) * (NP - DT)) / 8 == ip) pair(j);
+                    if constexpr (NEXT) {
+#pragma unroll
+                        for (int e = (ip * 32) / NP; e < ((ip + 1) * 32) / NP; ++e) mx_part = fmaxf(mx_part, sn[e >> 4][e & 15]);
+                        asm volatile("" : "+v"(mx_part));
+                    }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // the slot's MFMA first ...
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // ... the LDS read of the fragment two slots on ...
+                __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);     // ... then its VALU work, in the MFMA's shadow
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }, std::make_integer_sequence<int, NQ + NP>{});
+        if constexpr (!LROW) l_run += psum2.x + psum2.y;
+        if constexpr (NEXT) {      // lane <-> lane ^ 32 exchange of the partial maximum (attn_kernel's one-instruction swap)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx_part), __float_as_uint(mx_part), false, false);
+            mx_cur = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    // iteration t: K(t + 1) [buffer (t + 1) & 1] and V(t) [buffer t & 1] landed; K(t + 2) -> buffer t & 1, V(t + 1) -> buffer (t + 1) & 1
+    int t = 0;
+    for (; t + 2 < nt; t += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage_k(t + 2, 0);
+        stage_v(t + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        body(C1{}, C0{}, std::true_type{}, sA, sB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 3 < nt) stage_k(t + 3, 1);
+        stage_v(t + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        body(C0{}, C1{}, std::true_type{}, sB, sA);
+    }
+    // the last one or two tiles (scores of tile t in sA)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nt) {
+        stage_v(t + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        body(C1{}, C0{}, std::true_type{}, sA, sB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        body(C0{}, C1{}, std::false_type{}, sB, sA);
+    } else {
+        body(C1{}, C0{}, std::false_type{}, sA, sB);
+    }
+    __syncthreads();
+
+    attn_finish<D>(p, acc_o, m_run, l_run, smem, b, h, qblk, q0, split);
+}
+
+template <int D>
+void launch_attn_pipe(const AttnParams& p, dim3 grid, hipStream_t st) {
+    constexpr int KS = (D + 15) / 16, DT = (D + 31) / 32;
+    constexpr int KCH = (2 * KS <= 8) ? 8 : (2 * KS <= 16 ? 16 : 32);
+    constexpr size_t ring = 2 * ((size_t)BKV * KCH * 16 + (size_t)DT * 32 * 128);
+    constexpr size_t ostage = (size_t)4 * 32 * (DT * 32 + 8) * 2 + 16;      // + the split-KV "last arriver" flag
+    constexpr size_t lds = ring > ostage ? ring : ostage;
+    static MdxPerDeviceOnce attr_once;
+    if (attr_once.first())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_pipe_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_pipe_kernel<D>, grid, dim3(256), lds, st, p);
+}
+
 template <int D>
 void launch_attn8(const AttnParams& p, dim3 grid, hipStream_t st) {
     constexpr int KS = (D + 15) / 16, DT = (D + 31) / 32;
@@ -801,6 +1133,16 @@ static int attention_impl(const void* q, long q_bs, int q_ld, const void* k, lon
             default: launch_attn8<80>(p, g8, st); break;
         }
         MDX_LAUNCH_CHECK("mdx_attention_f16(attn8)");
+        return MDX_OK;
+    }
+    // software-pipelined form (attn_pipe_kernel): full key tiles, no mask, unsplit, at least two key tiles
+    if (mdx_opt(MDX_OPT_ATTN_PIPE) && !causal && D <= 80 && Nk % BKV == 0 && Nk >= 2 * BKV) {      // (split launches: >= 2 tiles per split, checked above)
+        switch (D) {
+            case 40: launch_attn_pipe<40>(p, grid, st); break;
+            case 64: launch_attn_pipe<64>(p, grid, st); break;
+            default: launch_attn_pipe<80>(p, grid, st); break;
+        }
+        MDX_LAUNCH_CHECK("mdx_attention_f16(pipe)");
         return MDX_OK;
     }
     const bool occ3 = mdx_opt(MDX_OPT_ATTN_OCC3) != 0;

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(const GemmParams p) {
     }
     const float lns_pre = __builtin_bit_cast(float, lns_raw);
     // (xpre is read only where the descriptor has a residual; the GEGLU store path fetches nothing)
-    gemm_epilogue<BM, BN, true, NW, LinearRows, NX, LEAN_EPI>(p, acc, smem, LinearRows{m0}, n0, split, bpre, tile_m, tile_id, ln_pre, &lns_pre,
+    gemm_epilogue<BM, BN, true, NW, LinearRows, NX, LEAN_EPI ? 1 : 0>(p, acc, smem, LinearRows{m0}, n0, split, bpre, tile_m, tile_id, ln_pre, &lns_pre,
                                                               xpre, ln_regs, lns_regs);
     trace_mark(p, 4);
 }

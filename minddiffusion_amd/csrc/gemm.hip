@@ -31,6 +31,11 @@
 #ifndef MDX_HALO_ABLATE
 #define MDX_HALO_ABLATE 0
 #endif
+// 1 = the HALO patch tiles run the batched store loops of gemm_epilogue<..., EMODE 2> (round 6); 0 = the generic per-pass loops (A/B builds)
+#ifndef MDX_HALO_LEAN_EPI
+#define MDX_HALO_LEAN_EPI 1
+#endif
+constexpr int HALO_EMODE = MDX_HALO_LEAN_EPI ? 2 : 0;
 
 #include <stdlib.h>
 
@@ -699,8 +704,8 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
             return;
         } else {
             if constexpr (PW == 16)
-                gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split, bpre,
-                                                tile_m, tile_id);
+                gemm_epilogue<BM, BN, SWAP, NW, PatchRows, 0, HALO_EMODE>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W, pb}, n0,
+                                                                          split, bpre, tile_m, tile_id);
             else
                 gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{tile_m * BM}, n0, split, bpre, tile_m, tile_id);
             trace_mark(p, 4);
@@ -989,8 +994,8 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void conv3x3_halo_kernel
     __syncthreads();
     trace_mark(p, 3);
     if constexpr (PW == 16)
-        gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W}, n0, split, bpre, tile_m,
-                                        tile_id);
+        gemm_epilogue<BM, BN, SWAP, NW, PatchRows, 0, HALO_EMODE>(p, acc, smem, PatchRows{(pb * p.H + py0) * p.W + px0, p.W, pb}, n0, split, bpre,
+                                                                  tile_m, tile_id);
     else   // two whole 64-pixel samples: tile rows are consecutive output rows
         gemm_epilogue<BM, BN, SWAP, NW>(p, acc, smem, LinearRows{tile_m * BM}, n0, split, bpre, tile_m, tile_id);
     trace_mark(p, 4);
@@ -1602,6 +1607,8 @@ bool halo_eligible(const GemmParams& p, int bm) {
     if (!mdx_opt(MDX_OPT_GEMM_HALO)) return false;
     if (!(p.ksize == 3 && p.stride == 1 && !p.upsample && p.c2 == 0 && p.cin % 64 == 0 && p.out_mode == MDX_OUT_ROWMAJOR))
         return false;
+    if (p.out_bs) return false;      // (no conv writes a strided-sample output; the patch epilogue does not carry the form)
+    if (p.residual && (size_t)p.M * (size_t)p.residual_ld * 2 >= 0x80000000ull) return false;      // (its residual rows go through a 32-bit-offset descriptor)
     if (bm == 128 && halo8_eligible(p)) return true;
     return p.H % (bm / 16) == 0 && p.W % 16 == 0;
 }

@@ -154,11 +154,14 @@ __device__ __forceinline__ void trace_mark(const GemmParams& p, int slot) {
 struct LinearRows {
     int m0;
     __device__ __forceinline__ int operator()(int row) const { return m0 + row; }
+    __device__ __forceinline__ int sample() const { return 0; }      // (never asked: EMODE 2 is for patch tiles)
 };
 // HALO conv tiles are 8 x 16 pixel patches: row = py*16 + px
 struct PatchRows {
     int base, W;   // base = (b*H + y0)*W + x0
+    int b;         // the sample every row of the patch belongs to (batched epilogue, EMODE 2)
     __device__ __forceinline__ int operator()(int row) const { return base + (row >> 4) * W + (row & 15); }
+    __device__ __forceinline__ int sample() const { return b; }
 };
 
 // The row-major epilogue's bias columns of this thread, fetched BEFORE the K loop: biases are cold in HBM (1.7 GB of
@@ -322,12 +325,18 @@ __device__ __forceinline__ bool splitk_last_block_reduce(const GemmParams& p, f3
 // arithmetic, then the stores back to back, statistics last -- instead of one pass at a time behind the generic per-pass feature
 // branches (row bias and out_bs cost an integer division per pass; ~450 instructions per pass in the ISA of round 5, one pass
 // ~0.4 us for a wave that has its SIMD to itself).  Same operations on the same values in the same order: bit-identical output.
-template <int BM, int BN, bool SWAP, int NW, class RowMap, int NXPRE = 0, bool LEAN = false>
+// EMODE: 0 = the generic per-pass loops; 1 = LEAN as above; 2 = the same batched loops for HALO patch tiles (conv3x3_halo_kernel,
+// PW = 16: out_bs is excluded by halo_eligible, and every row of a patch lies in ONE sample, so the per-sample row bias -- the
+// time-embedding term of a ResBlock's first conv, openaimodel.py:188-190 -- is one row of 8 floats per thread for the whole tile
+// instead of a division and two loads per pass).
+template <int BM, int BN, bool SWAP, int NW, class RowMap, int NXPRE = 0, int EMODE = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[BM / (16 * NW)][BN / 64], char* smem,
                                               const RowMap rm, const int n0, const int split, const float (&bpre)[16],
                                               const int row_block = 0, const int tile_lin = 0, const float* ln_pre = nullptr,
                                               const float* lns_pre = nullptr, const Row8Extras* xpre = nullptr,
                                               const bool ln_pre_valid = true, const bool lns_pre_valid = true) {
+    constexpr bool LEAN = EMODE != 0;
+    constexpr bool ROWB = EMODE == 2;
     constexpr int NT = NW * 64;           // threads per block
     constexpr int WROWS = BM / (NW / 2);  // rows of the block tile owned by one wave row (waves are (NW/2) x 2)
     constexpr int TM = WROWS / 32;
@@ -460,11 +469,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         float bb[8];
         Row8Extras xa;
         [[maybe_unused]] f16x8 lres[LEAN ? BM / RPP : 1];      // LEAN: the residual rows of ALL the thread's passes
+        [[maybe_unused]] u32x4 lrb[2] = {};                     // EMODE 2: the patch's row-bias row, this thread's 8 columns
         if (plain) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) bb[e] = bpre[e];   // fetched before the K loop (gemm_bias_prefetch)
             const int m = rm(r0);
             if constexpr (LEAN) {
+                if constexpr (ROWB) {      // the tile's ONE row-bias row (zeros from the descriptor when there is none)
+                    const __amdgpu_buffer_rsrc_t rs_rb = make_rsrc(p.rowbias, p.rowbias ? (unsigned)p.B * (unsigned)p.rowbias_ld * 4u : 0u);
+                    const unsigned off = n < p.N ? ((unsigned)rm.sample() * (unsigned)p.rowbias_ld + (unsigned)n) * 4u : MDX_OOB;
+                    lrb[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_rb, off, 0, 0);
+                    lrb[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_rb, off, 16, 0);
+                }
                 // the rows the kernel did not fetch before its K loop: all requested now, in front of the staging pass, through a
                 // descriptor that answers zero when there is no residual (unconditional loads: nothing waits behind a branch)
                 const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(p.residual, p.residual ? p.res_bytes : 0u);
@@ -604,6 +620,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                 constexpr int PASSES = BM / RPP;
                 const bool okn = n < p.N;
                 const bool has_res = p.residual != nullptr;      // uniform
+                [[maybe_unused]] const bool has_rb = p.rowbias != nullptr;
                 // (ii) the staged rows
                 f16x8 sv[PASSES];
 #pragma unroll
@@ -617,6 +634,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     float f[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = (float)sv[pass][e] + bb[e];
+                    if constexpr (ROWB) {
+                        if (has_rb) {      // (uniform; the generic loop's order: row bias, then residual)
+                            const f32x4 q0 = __builtin_bit_cast(f32x4, lrb[0]), q1 = __builtin_bit_cast(f32x4, lrb[1]);
+                            f[0] += q0[0]; f[1] += q0[1]; f[2] += q0[2]; f[3] += q0[3];
+                            f[4] += q1[0]; f[5] += q1[1]; f[6] += q1[2]; f[7] += q1[3];
+                        }
+                    }
                     if (has_res) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] += (float)lres[pass][e];

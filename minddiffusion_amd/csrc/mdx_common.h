@@ -80,6 +80,7 @@ enum MdxOpt {
     MDX_OPT_GEMM_DENSE_ISSUE,    // 1: dense launches of the generic GEMM kernel (ksize 1, stride 1, one source) keep the per-lane source offset fixed and put the K offset in the DMA instructions' scalar operand (0 = the general tap / source decode per K tile)
     MDX_OPT_GEMM_LN_PREFETCH,    // 1: LayerNorm-fold consumers (mdx_gemm_desc.ln_stats) fetch their rows' statistics partials and S[n] before the K loop (0 = at the head of the epilogue)
     MDX_OPT_GEMM_LEAN_DENSE,     // 1: dense row-major launches run the lean kernel of dense.hip (division-free prologue, first DMAs ~80 instructions in, epilogue reads prefetched before the K loop); 0 = the generic gemm_kernel (same bits)
+    MDX_OPT_ATTN_PIPE,           // 1: full-tile unmasked unsplit attention launches (D <= 80) run the software-pipelined kernel (attn_pipe_kernel: QK^T of tile t + 1, softmax and PV of tile t interleaved MFMA by MFMA inside every wave; same bits); 0 = attn_kernel
     MDX_OPT_COUNT
 };
 int mdx_opt(int id);

@@ -21,8 +21,8 @@ static const char* const g_opt_names[MDX_OPT_COUNT] = {"gemm_tuned", "gemm_bm", 
                                                         "gemm_splitk_fixup_max", "gemm_spread", "halo_nsb", "gn_min_blocks",
                                                         "gn_fused", "gn_col_chunks", "gemm_conv8p", "gemm_conv8p_min_m", "gemm_subpixel_min_tiles", "gemm_conv8p_var", "attn8", "attn8_min_blocks",
                                                         "gn_wide_rows", "gn_fused_small", "gn_boost_mb", "attn_occ3", "attn_kv_split", "attn_fast_stage",
-                                                        "gn_prefetch", "gemm_dense_issue", "gemm_ln_prefetch", "gemm_lean_dense"};
-static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1, 4, 1, 4096, 32, 0, 0, 192, 0, 0, 40, 1, 1, 1, 1, 1, 1, 1};
+                                                        "gn_prefetch", "gemm_dense_issue", "gemm_ln_prefetch", "gemm_lean_dense", "attn_pipe"};
+static int g_opt[MDX_OPT_COUNT] = {1, 0, 0, 0, 1, 1, 4, 1, 0, 512, 1, 4, 1, 4096, 32, 0, 0, 192, 0, 0, 40, 1, 1, 1, 1, 1, 1, 1, 1};
 
 int mdx_opt(int id) { return g_opt[id]; }
 
@@ -502,7 +502,88 @@ __global__ __launch_bounds__(256) void valu_probe_kernel(int iters, float* sink)
     for (int i = 0; i < 8; ++i) a += x[i] + y[i].x + y[i].y + (float)hx[i][0] + (float)hx[i][1];
     if (a == 123.456f) sink[0] = a;
 }
+// Does VALU work run in the shadow of an MFMA?  (round 6, attention softmax.)  Four slots per iteration; a slot is
+//   kind 0: one v_mfma_f32_32x32x16_f16 (two independent accumulator chains alternate)        kind 3: two v_exp_f32
+//   kind 1: the MFMA + two v_exp_f32 (independent chains)                                       kind 4: eight v_fma_f32
+//   kind 2: the MFMA + eight v_fma_f32                                                          kind 6: the softmax mix alone
+//   kind 5: the MFMA + the softmax mix of one score pair (2 fma, 2 exp, 1 packed add, 1 cvt_pk)
+template <int KIND>
+__global__ __launch_bounds__(256) void mix_probe_kernel(int iters, float* sink) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x16 acc[2];
+    f16x8 a, b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        a[e] = (f16)(0.001f * (float)((threadIdx.x + e) & 15));
+        b[e] = (f16)(0.002f * (float)((threadIdx.x + 3 * e) & 7));
+    }
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.001f * (float)(threadIdx.x + i) - 0.5f;
+    f32x2 ps = {0.f, 0.f};
+    unsigned pw = 0;
+    constexpr bool MF = KIND == 0 || KIND == 1 || KIND == 2 || KIND == 5;
+    constexpr bool MFA = KIND >= 7;       // 7 / 8 / 9: the accumulators (9: A and B too) live in AccVGPRs (inline asm, "a" constraint)
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            if constexpr (MF) acc[sl & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[sl & 1], 0, 0, 0);
+            if constexpr (MFA) {
+                if constexpr (KIND == 9)
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[sl & 1]) : "a"(a), "a"(b));
+                else
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[sl & 1]) : "v"(a), "v"(b));
+            }
+            if constexpr (KIND == 1 || KIND == 3) {
+                x[2 * sl] = __builtin_amdgcn_exp2f(x[2 * sl]);
+                x[2 * sl + 1] = __builtin_amdgcn_exp2f(x[2 * sl + 1]);
+            } else if constexpr (KIND == 2 || KIND == 4 || KIND == 7) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = __builtin_fmaf(x[i], 0.999f, 1e-6f);
+            } else if constexpr (KIND == 5 || KIND == 6 || KIND == 8 || KIND == 9) {
+                const float u = __builtin_fmaf(x[2 * sl], 0.999f, -0.25f), v = __builtin_fmaf(x[2 * sl + 1], 0.999f, -0.25f);
+                const f32x2 e2 = {__builtin_amdgcn_exp2f(u), __builtin_amdgcn_exp2f(v)};
+                ps += e2;
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 hv = {(_Float16)e2.x, (_Float16)e2.y};
+                pw ^= __builtin_bit_cast(unsigned, hv);
+                x[2 * sl] = e2.x - 1.0f;
+                x[2 * sl + 1] = e2.y - 1.0f;
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float t = ps.x + ps.y + (float)pw;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += x[i];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc[0][r] + acc[1][r];
+    if (t == 123.456f) sink[0] = t;
+}
 }  // namespace
+
+extern "C" int mdx_probe_mix_rate(int kind, int iters, int nblocks, float* sink, mdx_stream_t s) {
+    MDX_REQUIRE(sink && iters > 0 && nblocks > 0 && kind >= 0 && kind <= 9, "mdx_probe_mix_rate: bad arguments");
+    hipStream_t st = (hipStream_t)s;
+    switch (kind) {
+        case 0: hipLaunchKernelGGL(mix_probe_kernel<0>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 1: hipLaunchKernelGGL(mix_probe_kernel<1>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 2: hipLaunchKernelGGL(mix_probe_kernel<2>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 3: hipLaunchKernelGGL(mix_probe_kernel<3>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 4: hipLaunchKernelGGL(mix_probe_kernel<4>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 5: hipLaunchKernelGGL(mix_probe_kernel<5>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 7: hipLaunchKernelGGL(mix_probe_kernel<7>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 8: hipLaunchKernelGGL(mix_probe_kernel<8>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        case 9: hipLaunchKernelGGL(mix_probe_kernel<9>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+        default: hipLaunchKernelGGL(mix_probe_kernel<6>, dim3(nblocks), dim3(256), 0, st, iters, sink); break;
+    }
+    MDX_LAUNCH_CHECK("mdx_probe_mix_rate");
+    return MDX_OK;
+}
 
 extern "C" int mdx_probe_valu_rate(int kind, int iters, int nblocks, float* sink, mdx_stream_t s) {
     MDX_REQUIRE(sink && iters > 0 && nblocks > 0 && kind >= 0 && kind <= 7, "mdx_probe_valu_rate: bad arguments");

@@ -942,6 +942,55 @@ def test_attention_eight_wave_form(ops, ramp, D, heads, Nq, Nk):
     check(f"attention8_vs_four_wave_{ramp}_d{D}_q{Nq}_k{Nk}", outs[2], outs[0], rel_l2=1e-3)
 
 
+@pytest.mark.parametrize("ramp", [None] + sorted(RAMPS))
+@pytest.mark.parametrize("D,heads,Nq,Nk,splits", [(64, 2, 256, 256, -1), (64, 5, 1024, 1024, -1), (40, 8, 512, 512, -1), (80, 2, 256, 640, -1),
+                                                  (64, 1, 512, 128, -1), (64, 3, 200, 4224, -1), (40, 2, 100, 192, -1), (80, 1, 128, 2048, -1),
+                                                  (64, 2, 256, 512, 2), (64, 1, 128, 4096, 8), (40, 8, 256, 640, 3), (80, 2, 128, 768, 3),
+                                                  (64, 3, 384, 3200, 0)])
+def test_attention_software_pipelined_form(ops, ramp, D, heads, Nq, Nk, splits):
+    """attn_pipe_kernel (csrc/attention.hip, round 6; option attn_pipe): QK^T of key tile t + 1, softmax and PV of tile t interleaved MFMA
+    by MFMA inside every wave, K staged one tile ahead of V, the next tile's row maximum taken at the end of the iteration.  Two,
+    three and many key tiles (the odd / even tails of the two-tile unrolled loop), ragged query counts, i.i.d. scores and the
+    stale-maximum ramps (the lazily moved reference is decided one iteration after its maximum was taken); unsplit (splits = -1) and
+    split-KV launches (forced counts, 0 = the library's choice; a split's tile range starts at an even tile).  Against the float64
+    softmax, and against attn_kernel BIT FOR BIT: the same operations on the same values in the same order per output element."""
+    B = 2
+    C = heads * D
+    rng = np.random.RandomState(Nq + Nk + D + (sum(map(ord, ramp)) if ramp else 0))
+    q = h16(0.5 * rng.standard_normal((B, Nq, C)))
+    k = h16(0.5 * rng.standard_normal((B, Nk, C)))
+    v = h16(rng.standard_normal((B, Nk, C)))
+    if ramp:
+        scale_log2 = D ** -0.5 * 1.4426950408889634
+        for hh in range(heads):
+            q[:, :, hh * D + D - 1] = 8.0
+            for j in range(Nk):
+                k[:, j, hh * D + D - 1] = RAMPS[ramp](j // 64) / (8.0 * scale_log2)
+        q, k = h16(q), h16(k)
+    qt, kt, vt_ = [torch.tensor(t, dtype=torch.float64).reshape(B, -1, heads, D).permute(0, 2, 1, 3) for t in (q, k, v)]
+    ref = torch.matmul(torch.softmax(torch.matmul(qt, kt.transpose(2, 3)) * D ** -0.5, -1), vt_).permute(0, 2, 1, 3).reshape(B, Nq, C)
+    vt = np.ascontiguousarray(v.transpose(0, 2, 1))
+    qd, kd, vtd = dev16(q), dev16(k), dev16(vt)
+    outs = {}
+    old = ops.get_option("attn_pipe")
+    items = (Nq + 127) // 128 * heads * B
+    ws = ops.attention_workspace(65536 + items * 8 * (128 * D * 2 + 1024), DEV) if splits >= 0 else None
+    for form in (1, 0):
+        ops.set_option("attn_pipe", form)
+        try:
+            out = torch.full((B, Nq, C), float("nan"), dtype=torch.float16, device=DEV)
+            ops.attention(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), out.data_ptr(), B, heads, D, Nq, Nk, D ** -0.5,
+                          Nq * C, C, Nk * C, C, C * Nk, Nk, Nq * C, C, ws=ws, kv_splits=max(splits, 0))
+            torch.cuda.synchronize()
+            if ws is not None:
+                assert int(ws[: items * 4].view(torch.int32).abs().sum()) == 0, "arrival counters not back at zero"
+            outs[form] = out
+        finally:
+            ops.set_option("attn_pipe", old)
+    check(f"attention_pipe_{ramp}_d{D}_h{heads}_q{Nq}_k{Nk}_s{splits}", outs[1], ref, rel_l2=2e-3, max_abs=2e-2)
+    assert torch.equal(outs[1], outs[0]), f"pipelined attention differs from attn_kernel: max |d| = {(outs[1].float() - outs[0].float()).abs().max().item():.3e}"
+
+
 @pytest.mark.parametrize("occ3", [1, 0])
 @pytest.mark.parametrize("ramp", [None, "stale6.5", "always12", "sawtooth"])
 @pytest.mark.parametrize("D,heads,Nq,Nk,splits", [
