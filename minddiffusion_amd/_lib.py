@@ -132,6 +132,7 @@ SIGNATURES = {
     "mdx_probe_mfma_16x16x32_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdx_probe_gemm_trace": (c_int, [c_void_p, c_size_t]),
     "mdx_probe_valu_rate": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mdx_probe_mix_rate": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
     "mdx_probe_l2_stream": (c_int, [c_void_p, c_size_t, ctypes.c_uint, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mdx_probe_dma_stream": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
