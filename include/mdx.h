@@ -227,6 +227,20 @@ typedef struct mdx_gemm_desc {
                              source) the launch computes 4 Cin instead of 9 Cin products per output on the un-upsampled tensor; otherwise
                              `w` and the upsampling gather are used.  The summed taps are rounded to fp16 once: results differ from the
                              nine-product form by fp16 rounding of the weights (parity-tested against the oracle at the usual 1e-3). */
+    /* Cross-attention over a short cached context as the EPILOGUE of its query projection (round 6; BasicTransformerBlock.attn2,
+     * attention.py:108, 138-152 with the context keys / values of :119-121 cached per context tensor): when xattn_k is set the launch
+     * computes q = a W^T (with the LayerNorm fold if ln_stats is set), keeps each 64-column tile of it -- ONE HEAD: the head dim must be
+     * 64 -- on chip, and writes  out[m][64 h ..] = softmax(q_h K_h^T * xattn_scale) V_h  instead of q: the separate attention launch and
+     * the fp16 round trip of q disappear, the arithmetic is that of mdx_attention_f16 on the fp16-rounded q (bit-identical).
+     *   xattn_k  [B][xattn_cap][N] fp16 (keys, row-major: head h in columns 64 h ..), xattn_vt [B][N][xattn_cap] fp16 (values, transposed),
+     *   xattn_len <= 128 keys of xattn_cap rows are attended to.
+     * Dense row-major launches only (ksize 1, one source, no epilogue / residual / statistics / n_split / out_bs), N % 64 == 0, tokens per
+     * sample % 128 == 0 or == 64; set tile_n = 64 and splitk = 1. */
+    const void* xattn_k;
+    const void* xattn_vt;
+    int xattn_len;
+    int xattn_cap;
+    float xattn_scale;
 } mdx_gemm_desc;
 
 #define MDX_GEMM_WS_HEAD 16384 /* reserved bytes at the head of mdx_gemm_desc.workspace (the arrival counters' former home; their size) */

@@ -38,6 +38,7 @@ class GemmDesc(ctypes.Structure):
         ("gn_eps", c_float),
         ("skip_a", c_void_p), ("skip_a2", c_void_p), ("skip_c1", c_int), ("skip_c2", c_int), ("skip_w", c_void_p),
         ("w_frag", c_int), ("stages", c_int), ("w_sub", c_void_p),
+        ("xattn_k", c_void_p), ("xattn_vt", c_void_p), ("xattn_len", c_int), ("xattn_cap", c_int), ("xattn_scale", c_float),
     ]
 
 

@@ -40,7 +40,128 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 //   3  + the LayerNorm partials of the thread's row in registers (up to 24: ~50 more VGPRs, two blocks per CU) -- the full form;
 //      a VMEM instruction costs a lone wave ~50 clocks to issue, and 29 of them in front of the first barrier cost the launch more
 //      than the round trips they hide
-template <int BM, int BN, int NS, int PF>
+// Cross-attention over a short cached context as the epilogue of the query projection (mdx_gemm_desc.xattn_k; BN = 64 = head dim): the
+// tile's fp16 q rows are in LDS at `stg` ([BM][72]), the head's K / V^T tiles (at most two of 64 keys; attn_kernel's LDS images) at `xs`.
+// Every wave takes 32 query rows through attn_kernel's tile program -- S^T = K Q^T, lazy-reference online softmax, O^T += V^T P^T, the
+// masked form on a ragged last tile -- normalises, stages its 32 x 64 output rows over its own q rows and stores them: the same
+// operations on the same values in the same order as mdx_attention_f16 on the stored q (bit-identical).
+template <int BM>
+__device__ __forceinline__ void xattn_tile_epilogue(const GemmParams& p, char* smem, const char* xs, const int m0, const int n0) {
+    constexpr int SLD = 72;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave * 32 >= BM) return;
+    const int hi = lane >> 5, l31 = lane & 31;
+    f16* stg = reinterpret_cast<f16*>(smem);
+    f16x8 qf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) qf[s4] = *reinterpret_cast<const f16x8*>(&stg[(wave * 32 + l31) * SLD + 16 * s4 + 8 * hi]);
+    f32x16 acc_o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int vswz = (lane >> 1) & 7;
+    const int krow_l = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);      // attn_kernel's key permutation
+    const int ntile = (p.xa_len + 63) >> 6;
+    auto tile = [&](const int t, auto mask_c) {
+        constexpr bool MASK = decltype(mask_c)::value;
+        const char* sk = xs + t * 16384;
+        const char* sv = sk + 8192;
+        f32x16 acc_s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_s[kt][r] = 0.f;
+            const int krow = kt * 32 + krow_l;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(sk + krow * 128 + (((2 * s4 + hi) ^ ((krow >> 1) & 7)) << 4));
+                acc_s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s4], acc_s[kt], 0, 0, 0);
+            }
+        }
+        if constexpr (MASK) {
+            const int key0 = t * 64, kmax = p.xa_len - 1;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kt * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
+                    if (key > kmax) acc_s[kt][r] = -INFINITY;
+                }
+        }
+        float mx = acc_s[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc_s[kt][r]);
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float m_cand = fmaxf(m_run, mx);
+        if (__builtin_amdgcn_ballot_w64((m_cand - m_run) * p.xa_scale_log2 > 8.0f)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_cand) * p.xa_scale_log2);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+            m_run = m_cand;
+        }
+        const float mb = m_run * p.xa_scale_log2;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 sc2 = {p.xa_scale_log2, p.xa_scale_log2}, nmb2 = {-mb, -mb};
+        f32x2 psum2 = {0.f, 0.f};
+        f16x8 pf[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 x2 = {acc_s[kt][r], acc_s[kt][r + 1]};
+                const f32x2 a2 = __builtin_elementwise_fma(x2, sc2, nmb2);
+                const f32x2 pv2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+                psum2 += pv2;
+                pf[kt * 2 + (r >> 3)][r & 7] = (f16)pv2.x;
+                pf[kt * 2 + (r >> 3)][(r & 7) + 1] = (f16)pv2.y;
+            }
+        l_run += psum2.x + psum2.y;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const f16x8 vf = *reinterpret_cast<const f16x8*>(sv + (d * 32 + l31) * 128 + (((2 * c + hi) ^ vswz) << 4));
+                acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c], acc_o[d], 0, 0, 0);
+            }
+    };
+    for (int t = 0; t < ntile; ++t) {
+        if ((t + 1) * 64 > p.xa_len) tile(t, std::true_type{}); else tile(t, std::false_type{});
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    f16* og = stg + wave * 32 * SLD;      // this wave's own q rows: its fragments are in registers
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (f16)(acc_o[d][4 * g + e] * inv);
+            *reinterpret_cast<f16x4*>(&og[l31 * SLD + d * 32 + 8 * g + 4 * hi]) = v;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (wave-local hand-over through LDS)
+    for (int idx = lane; idx < 32 * 8; idx += 64) {
+        const int row = idx >> 3, chunk = idx & 7;
+        const int m = m0 + wave * 32 + row;
+        if (m < p.M) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(&og[row * SLD + chunk * 8]);
+            *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + n0 + chunk * 8) = v;
+        }
+    }
+}
+
+template <int BM, int BN, int NS, int PF, bool XA = false>
 __global__ __launch_bounds__(256, 2) void dense_kernel(const GemmParams p) {
     mdx_kernarg_touch<sizeof(GemmParams)>();
     constexpr int NW = 4;
@@ -312,8 +433,42 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(const GemmParams p) {
     }
     const float lns_pre = __builtin_bit_cast(float, lns_raw);
     // (xpre is read only where the descriptor has a residual; the GEGLU store path fetches nothing)
-    gemm_epilogue<BM, BN, true, NW, LinearRows, NX, LEAN_EPI ? 1 : 0>(p, acc, smem, LinearRows{m0}, n0, split, bpre, tile_m, tile_id, ln_pre, &lns_pre,
-                                                              xpre, ln_regs, lns_regs);
+    if constexpr (XA) {
+        static_assert(BN == 64, "cross-attention epilogue: one 64-wide head per tile");
+        // the head's K / V^T tiles -> LDS behind the staging area, in flight while the accumulators are corrected and staged
+        constexpr int XOFF = ((BM * 72 * 2 + 2 * BM * 4 + BN * 4 + 1023) / 1024) * 1024;
+        char* xs = smem + XOFF;
+        {
+            const int bsamp = m0 / p.HoWo, head = n0 >> 6;
+            const f16* kb = p.xa_k + (size_t)bsamp * p.xa_cap * p.N + head * 64;
+            const f16* vb = p.xa_vt + ((size_t)bsamp * p.N + head * 64) * p.xa_cap;
+            const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(kb, (unsigned)(((size_t)(p.xa_len - 1) * p.N + 64) * 2));
+            const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(vb, (unsigned)((size_t)64 * p.xa_cap * 2));
+            const int ntile = (p.xa_len + 63) >> 6;
+            for (int t = 0; t < ntile; ++t) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int inst = wave * 2 + j;
+                    const int krow = inst * 8 + (lane >> 3);
+                    const int kchunk = (lane & 7) ^ ((krow >> 1) & 7);
+                    const int key = t * 64 + krow;
+                    dma16(rs_k, xs + t * 16384 + inst * 1024, key < p.xa_len ? (unsigned)(((size_t)key * p.N + kchunk * 8) * 2) : MDX_OOB);
+                    const int vrow = inst * 8 + (lane >> 3);
+                    const unsigned vchunk = (unsigned)((lane & 7) ^ ((vrow >> 1) & 7));
+                    const int kc = t * 64 + (int)vchunk * 8;
+                    dma16(rs_v, xs + t * 16384 + 8192 + inst * 1024, kc < p.xa_cap ? (unsigned)(((size_t)vrow * p.xa_cap + kc) * 2) : MDX_OOB);
+                }
+            }
+        }
+        gemm_epilogue<BM, BN, true, NW, LinearRows, NX, 3>(p, acc, smem, LinearRows{m0}, n0, split, bpre, tile_m, tile_id, ln_pre, &lns_pre, xpre,
+                                                           ln_regs, lns_regs);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();      // K / V^T of every wave's DMAs landed (the staged q tile was ordered by the epilogue's own barrier)
+        xattn_tile_epilogue<BM>(p, smem, xs, m0, n0);
+    } else {
+        gemm_epilogue<BM, BN, true, NW, LinearRows, NX, LEAN_EPI ? 1 : 0>(p, acc, smem, LinearRows{m0}, n0, split, bpre, tile_m, tile_id, ln_pre,
+                                                                  &lns_pre, xpre, ln_regs, lns_regs);
+    }
     trace_mark(p, 4);
 }
 
@@ -327,6 +482,19 @@ void launch_dense_one(const GemmParams& p, dim3 grid, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_kernel<BM, BN, NS, PF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((dense_kernel<BM, BN, NS, PF>), grid, dim3(256), lds, st, p);
+}
+
+// the cross-attention-epilogue instantiations (BN = 64, prefetch level 1): LDS = ring | staged q + LayerNorm extras + two K / V^T tile pairs
+template <int BM, int NS>
+void launch_dense_xa(const GemmParams& p, dim3 grid, hipStream_t st) {
+    constexpr size_t ring = (size_t)NS * (BM + 64) * 64 * 2;
+    constexpr size_t xa = (size_t)((BM * 72 * 2 + 2 * BM * 4 + 64 * 4 + 1023) / 1024) * 1024 + 2 * 16384;
+    constexpr size_t lds = ring > xa ? ring : xa;
+    static MdxPerDeviceOnce attr_once;
+    if (attr_once.first())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_kernel<BM, 64, NS, 1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((dense_kernel<BM, 64, NS, 1, true>), grid, dim3(256), lds, st, p);
 }
 
 template <int BM, int BN, int NS>
@@ -361,6 +529,12 @@ bool mdx_dense_launch(const GemmParams& p, int bm, int bn, int ns, dim3 grid, hi
     const int opt = mdx_opt(MDX_OPT_GEMM_LEAN_DENSE);
     const bool small = (long)g.x * g.y <= 512;
     const int pf = opt == 2 ? 0 : (opt == 3 && small ? 2 : (opt == 4 && small ? 3 : 1));
+    if (p.xa_k) {      // cross-attention epilogue (mdx_gemm_desc.xattn_k): 64-column tiles, ring depth 2 .. 4
+        if (bn != 64 || ns < 2 || ns > 4) return false;
+        if (bm == 64) { if (ns == 2) launch_dense_xa<64, 2>(p, g, st); else if (ns == 3) launch_dense_xa<64, 3>(p, g, st); else launch_dense_xa<64, 4>(p, g, st); return true; }
+        if (bm == 128) { if (ns == 2) launch_dense_xa<128, 2>(p, g, st); else if (ns == 3) launch_dense_xa<128, 3>(p, g, st); else launch_dense_xa<128, 4>(p, g, st); return true; }
+        return false;
+    }
     if (bm == 64 && bn == 64) return launch_dense_ns<64, 64>(p, ns, pf, g, st);
     if (bm == 64 && bn == 128) return launch_dense_ns<64, 128>(p, ns, pf, g, st);
     if (bm == 128 && bn == 64) return launch_dense_ns<128, 64>(p, ns, pf, g, st);

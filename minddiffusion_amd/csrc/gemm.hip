@@ -1295,6 +1295,23 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
                         "Cin <= 640, images larger than 8 x 8 and tile-major weights");
         }
     }
+    p.xa_k = (const f16*)d->xattn_k;
+    p.xa_vt = (const f16*)d->xattn_vt;
+    p.xa_len = d->xattn_len;
+    p.xa_cap = d->xattn_cap;
+    p.xa_scale_log2 = d->xattn_scale * 1.4426950408889634f;
+    if (p.xa_k) {
+        const int howo = d->H * d->W;
+        MDX_REQUIRE(p.xa_vt && d->xattn_len > 0 && d->xattn_len <= 128 && d->xattn_cap >= d->xattn_len && d->xattn_cap % 8 == 0,
+                    "mdx_gemm_f16: cross-attention epilogue needs xattn_vt, 0 < xattn_len <= 128 <= ... xattn_cap (a multiple of 8)");
+        MDX_REQUIRE(d->ksize == 1 && d->stride == 1 && !d->upsample && d->c2 == 0 && d->N % 64 == 0 && d->c1 % 64 == 0 &&
+                        d->epilogue == MDX_EPI_NONE && d->out_mode == MDX_OUT_ROWMAJOR && !d->residual && !d->rowbias && !d->stats_out &&
+                        !d->colstats_out && !d->n_split && !d->out_bs && !d->gn_colstats && !d->defer_reduce,
+                    "mdx_gemm_f16: the cross-attention epilogue rides on a plain dense row-major projection (N %% 64 == 0, Cin %% 64 == 0)");
+        MDX_REQUIRE(d->tile_n == 64 && d->splitk == 1 && (howo % 128 == 0 || howo == 64) && (d->tile_m == 0 || d->tile_m == 64 || d->tile_m == 128),
+                    "mdx_gemm_f16: the cross-attention epilogue needs tile_n = 64 (one head per tile), splitk = 1 and tokens per sample %% 128 == 0 (or == 64)");
+        MDX_REQUIRE((size_t)d->xattn_cap * d->N * 2 <= 0x80000000ull, "mdx_gemm_f16: cross-attention context larger than 2 GiB per sample");
+    }
     p.w_sub = (const f16*)d->w_sub;
     p.w_sub_bytes = 0;
     p.c8_sub = 0;
@@ -2106,6 +2123,9 @@ extern "C" int mdx_gemm_f16(const mdx_gemm_desc* d, mdx_stream_t s) {
     if (rc != MDX_OK) return rc;
     const bool fastk = lg.fastk, nw8 = lg.nw8, swap = lg.swap;
     const int ntiles = lg.ntiles;
+    MDX_REQUIRE(!p.xa_k || (lg.lean && !halo && bn == 64 && ns == 1 && (p.HoWo % c.bm) == 0),
+                "mdx_gemm_f16: the cross-attention epilogue needs the lean dense kernel on %d x 64 tiles inside one sample (got tile %d x %d, %d splits)",
+                c.bm, c.bm, bn, ns);
     dim3 grid = lg.grid;
     p.trace = (g_gemm_trace && (size_t)grid.x * grid.y <= g_gemm_trace_slots) ? g_gemm_trace : nullptr;
     GemmCfg cc = c;

@@ -65,6 +65,11 @@ struct GemmParams {
     // tile ids a launch has)
     unsigned inv_tiles_n, inv_tiles_m;
     unsigned res_bytes;      // bytes of the residual tensor ([M][residual_ld] fp16), for its buffer descriptor
+    // cross-attention over a cached context as the epilogue of the query projection (mdx_gemm_desc.xattn_k; lean dense kernel, BN = 64 = head dim)
+    const f16* xa_k;         // [B][xa_cap][N]
+    const f16* xa_vt;        // [B][N][xa_cap]
+    int xa_len, xa_cap;
+    float xa_scale_log2;     // scale * log2(e)
 };
 
 }  // namespace mdx_int
@@ -325,7 +330,8 @@ __device__ __forceinline__ bool splitk_last_block_reduce(const GemmParams& p, f3
 // arithmetic, then the stores back to back, statistics last -- instead of one pass at a time behind the generic per-pass feature
 // branches (row bias and out_bs cost an integer division per pass; ~450 instructions per pass in the ISA of round 5, one pass
 // ~0.4 us for a wave that has its SIMD to itself).  Same operations on the same values in the same order: bit-identical output.
-// EMODE: 0 = the generic per-pass loops; 1 = LEAN as above; 2 = the same batched loops for HALO patch tiles (conv3x3_halo_kernel,
+// EMODE: 0 = the generic per-pass loops; 1 = LEAN as above; 3 = LEAN, but STOP behind the staging barrier (the fp16 tile stays in LDS for
+// the caller: cross-attention epilogue of dense.hip); 2 = the same batched loops for HALO patch tiles (conv3x3_halo_kernel,
 // PW = 16: out_bs is excluded by halo_eligible, and every row of a patch lies in ONE sample, so the per-sample row bias -- the
 // time-embedding term of a ResBlock's first conv, openaimodel.py:188-190 -- is one row of 8 floats per thread for the whole tile
 // instead of a division and two loads per pass).
@@ -468,13 +474,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         const bool plain = p.epilogue != MDX_EPI_GEGLU;
         float bb[8];
         Row8Extras xa;
-        [[maybe_unused]] f16x8 lres[LEAN ? BM / RPP : 1];      // LEAN: the residual rows of ALL the thread's passes
+        [[maybe_unused]] f16x8 lres[(LEAN && EMODE != 3) ? BM / RPP : 1];      // LEAN: the residual rows of ALL the thread's passes
         [[maybe_unused]] u32x4 lrb[2] = {};                     // EMODE 2: the patch's row-bias row, this thread's 8 columns
         if (plain) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) bb[e] = bpre[e];   // fetched before the K loop (gemm_bias_prefetch)
             const int m = rm(r0);
-            if constexpr (LEAN) {
+            if constexpr (LEAN && EMODE != 3) {
                 if constexpr (ROWB) {      // the tile's ONE row-bias row (zeros from the descriptor when there is none)
                     const __amdgpu_buffer_rsrc_t rs_rb = make_rsrc(p.rowbias, p.rowbias ? (unsigned)p.B * (unsigned)p.rowbias_ld * 4u : 0u);
                     const unsigned off = n < p.N ? ((unsigned)rm.sample() * (unsigned)p.rowbias_ld + (unsigned)n) * 4u : MDX_OOB;
@@ -514,6 +520,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             }
         __syncthreads();
         trace_mark(p, 5);
+        if constexpr (EMODE == 3) {
+            // stage only: the caller (dense.hip, cross-attention epilogue) consumes the fp16 tile in LDS -- as the values the store loop
+            // would have written: fp16(float(staged) + bias) (the LayerNorm fold's W beta term arrives as a bias)
+            constexpr int CPR3 = BN / 8, RPP3 = NT / CPR3;
+            const int chunk3 = tid % CPR3, r03 = tid / CPR3;
+            if (p.bias) {
+#pragma unroll
+                for (int pass = 0; pass < BM / RPP3; ++pass) {
+                    f16x8* q = reinterpret_cast<f16x8*>(&stg[(r03 + pass * RPP3) * SLD + chunk3 * 8]);
+                    f16x8 v = *q;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + bpre[e]);
+                    *q = v;
+                }
+            }
+            return;
+        }
         if (p.n_split && n0 >= p.n_split) {
             // a V tile of the merged q|k|v projection: out2[(b * Nv + n - n_split) * out2_ld + tok], 8 consecutive tokens
             // per 16-B store, gathered column-wise from the staged [m][n] tile (2-byte LDS reads; small next to a launch)

@@ -509,6 +509,7 @@ class UNetModel:
         P.attn_ws = None         # split-KV attention workspace (ops.attention_workspace), sized after the walk
         attn_ws_need = [0]
         ctx_kv = {}
+        xattn_descs = []
 
         def conv3(src, cin, cout, wt, bias, h, wd, stride=1, upsample=0, rowbias=None, residual=None, src2=None, c2=0,
                   skip=None, gn=None, wsub=None):
@@ -818,15 +819,30 @@ class UNetModel:
                              stats_out=st)
                 A.release(qk); vt_release(vt); A.release(tok)
                 # --- attn2 (cross): K / V^T of the context are produced by the context plan
+                # (round 6) head dim 64 (SDv2): the 77-key attention rides on the query projection as its EPILOGUE -- one 64-column
+                # tile is one head (mdx_gemm_desc.xattn_k): no attention launch, no fp16 round trip of q; bit-identical to the two launches
+                xfuse = (ops.get_option("unet_xattn_fuse") and not _selfctx and dh == 64 and TC <= 128 and TC % 8 == 0
+                         and (n % 128 == 0 or n == 64))
+                if xfuse:
+                    kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
+                    vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
+                    ctx_kv[t] = (kc, vtc)
+                    xkw = dict(tile_n=64, splitk=1, xattn_k=kc, xattn_vt=vtc, xattn_len=TC, xattn_cap=TC, xattn_scale=scale, out=o,
+                               out_ld=inner)
                 if st is None:
                     emit(lambda ln=ln, tok2=tok2, t=t: ops.layernorm(tok2, w[t + "norm2.g"], w[t + "norm2.b"], 1e-5, out=ln),
                          "layernorm")
-                    q2 = dense(main, ln, B, n, inner, inner, w[t + "attn2.q.w"])
+                    q2 = dense(main, ln, B, n, inner, inner, w[t + "attn2.q.w"], **(xkw if xfuse else {}))
                 else:
-                    q2 = dense(main, tok2, B, n, inner, inner, w[t + "attn2.q.w"], **consumer(t + "attn2.q"))
+                    q2 = dense(main, tok2, B, n, inner, inner, w[t + "attn2.q.w"], **consumer(t + "attn2.q"), **(xkw if xfuse else {}))
                     if _selfctx:    # k / v below read LayerNorm(tok2) itself: one explicit launch (this form is not a hot path)
                         emit(lambda ln=ln, tok2=tok2, t=t: ops.layernorm(tok2, w[t + "norm2.g"], w[t + "norm2.b"], 1e-5, out=ln),
                              "layernorm")
+                if xfuse:
+                    xattn_descs.append(descs[-1])      # (their xattn_len follows the context: _ensure_context)
+                    meta[-1]["flops"] += 4 * B * heads * n * 77 * dh
+                    meta[-1]["info"] += f" +cross-attention h={heads} d={dh}"
+                    q2 = None
                 if _selfctx:
                     # context = default(context, x) (attention.py:133): keys / values are projections of attn2's own input
                     k2 = dense(main, ln, B, n, inner, inner, w[t + "attn2.k.w"])
@@ -839,7 +855,7 @@ class UNetModel:
                         n * inner, inner, n * inner, inner, inner * nv2, nv2, n * inner, inner, ws=P.attn_ws),
                         "attention", 4 * B * heads * n * n * dh, 1, f"attn2-self B={B} h={heads} N={n} d={dh}")
                     A.release(k2); vt_release(v2t)
-                else:
+                elif not xfuse:
                     kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
                     vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
                     ctx_kv[t] = (kc, vtc)
@@ -849,7 +865,9 @@ class UNetModel:
                         "attention", 4 * B * heads * n * 77 * dh, 1, f"cross B={B} h={heads} N={n} d={dh}")
                 tok3 = dense(main, o, B, n, inner, inner, w[t + "attn2.o.w"], bias=w[t + "attn2.o.b"], residual=tok2,
                              stats_out=st)
-                A.release(q2); A.release(tok2)
+                if q2 is not None:
+                    A.release(q2)
+                A.release(tok2)
                 # --- feed-forward (GEGLU fused in the first GEMM's epilogue)
                 if st is None:
                     emit(lambda ln=ln, tok3=tok3, t=t: ops.layernorm(tok3, w[t + "norm3.g"], w[t + "norm3.b"], 1e-5, out=ln),
@@ -1053,6 +1071,7 @@ class UNetModel:
         P.ragged_vt = ragged_vt     # (owned by the plan: descriptors hold raw pointers)
         P.heads_fused = heads_fused
         P.ctx_kv = ctx_kv     # the cached context K / V^T buffers: descriptors hold raw pointers only
+        P.xattn_descs = xattn_descs
         P.graph = None
         P.graph_failed = False
         self._plans[key] = P
@@ -1076,6 +1095,8 @@ class UNetModel:
         P.ctx_pad.zero_()
         P.ctx_pad[:, :T].copy_(context)
         P.ctx_len = T
+        for d in getattr(P, "xattn_descs", ()):      # the query projections that carry their cross-attention (mdx_gemm_desc.xattn_len)
+            d.xattn_len = T
         for op in P.ctxops:
             op()
         self._ctx_key = key

@@ -48,6 +48,9 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
             # before its first MFMA, which costs what the 7 us launch did), Wukong batch 16 +0.4 %, 96 x 96 batch 8 +0.5 %; at 256
             # (the levels whose GroupNorm launch doubles as a split-K reduce) +0.5 % / +1.0 % / +1.6 %.  Off.
             "unet_gn_proj_fuse": int(os.environ.get("MDX_UNET_GN_PROJ_FUSE", "0")),
+            # (round 6) SDv2 (head dim 64): BasicTransformerBlock.attn2 -- to_q + the attention over the cached 77 context keys -- as ONE
+            # launch, the attention as the epilogue of the query projection (mdx_gemm_desc.xattn_k); 0 = projection + attention launches
+            "unet_xattn_fuse": int(os.environ.get("MDX_UNET_XATTN_FUSE", "1")),
             # Taichu-GLIDE AttentionBlock (unet.py:267-297): 1 = q | k | v of the image tokens in ONE launch (q | k row-major into a
             # [B, text + image, 2 C] buffer, V transposed: mdx_gemm_desc.n_split with out_bs) instead of three -- 44 launches fewer
             # per base evaluation.  0 = three launches (A/B)
@@ -384,7 +387,8 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
                    out_mode=OUT_ROWMAJOR, splitk=0, workspace=None, out_bs=0, out2=None, out2_ld=0, n_split=0, asym_pad=0,
                    stats_out=None, ln_stats=None, ln_s=None, ln_eps=1e-5, tile_m=0, tile_n=0, colstats_out=None, stages=0,
                    w_frag=0, skip_a=None, skip_a2=None, skip_c1=0, skip_c2=0, skip_w=None, gn_colstats=None, gn_nrb=0,
-                   gn_gamma=None, gn_beta=None, gn_eps=1e-5, gn_silu=1, w_sub=None):
+                   gn_gamma=None, gn_beta=None, gn_eps=1e-5, gn_silu=1, w_sub=None, xattn_k=None, xattn_vt=None, xattn_len=0,
+                   xattn_cap=0, xattn_scale=0.0):
     d = GemmDesc()
     d.a = a.data_ptr()
     d.a2 = 0 if a2 is None else a2.data_ptr()
@@ -423,6 +427,9 @@ def make_gemm_desc(a, w, N, B, H, W, c1, out, out_ld, a2=None, c2=0, bias=None, 
     d.colstats_out = 0 if colstats_out is None else colstats_out.data_ptr()
     d.colstats_cap = 0 if colstats_out is None else int(colstats_out.shape[0])
     d.w_sub = 0 if w_sub is None else w_sub.data_ptr()
+    if xattn_k is not None:      # cross-attention as the epilogue of the query projection (include/mdx.h)
+        d.xattn_k, d.xattn_vt = xattn_k.data_ptr(), xattn_vt.data_ptr()
+        d.xattn_len, d.xattn_cap, d.xattn_scale = int(xattn_len), int(xattn_cap), float(xattn_scale)
     return d
 
 

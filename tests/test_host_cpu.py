@@ -125,8 +125,9 @@ def test_unet_constructor_variants_plan_on_the_host(name):
     assert gemms and all("desc" in m and " split=" in m["info"] for m in gemms)
     blocks = sum(1 for k in base.w if k.endswith("attn2.q.w"))
     n = lambda Pl, kind: sum(m["kind"] == kind for m in Pl.meta)
+    xf = lambda Pl: sum("+cross-attention" in m["info"] for m in Pl.meta)      # attn2 riding on its query projection (head dim 64, round 6)
     if name == "depth2":                # a second BasicTransformerBlock per SpatialTransformer: 2 attentions and 6 GEMMs each
-        assert n(P, "attention") == n(P0, "attention") + 2 * blocks and n(P, "gemm") == n(P0, "gemm") + 6 * blocks   # (+ 2 context GEMMs outside the op list)
+        assert n(P, "attention") + xf(P) == n(P0, "attention") + xf(P0) + 2 * blocks and n(P, "gemm") == n(P0, "gemm") + 6 * blocks   # (+ 2 context GEMMs outside the op list)
         assert len(P.ctxops) == len(P0.ctxops) + 2 * blocks
     elif name == "pool_resample":       # the resampling convs become parameter-free pooling / nearest ops
         assert n(P, "gemm") == n(P0, "gemm") - 2 and n(P, "small") == n(P0, "small") + 2
@@ -859,19 +860,26 @@ def test_unet_plan_fuses_the_320_channel_transformer_blocks():
         ops.set_option("unet_gn_proj_fuse", 1024)
         P1 = build()._plan(2, 64, 64)               # launch-per-op transformers, SpatialTransformer.norm folded into proj_in (round 5)
         ops.set_option("unet_gn_proj_fuse", 0)
-        P0 = build()._plan(2, 64, 64)               # ... and with the GroupNorm launches of rounds 1-4
+        P0x = build()._plan(2, 64, 64)              # ... with the GroupNorm launches of rounds 1-4 (cross-attention on its projection: round 6)
+        ops.set_option("unet_xattn_fuse", 0)
+        P0 = build()._plan(2, 64, 64)               # ... and with one launch per op, as in rounds 1-2
     finally:
         ops.set_option("unet_st_tail", -1)
         ops.set_option("unet_st_head", -1)
         ops.set_option("unet_gn_proj_fuse", pf)
+        ops.set_option("unet_xattn_fuse", 1)
     assert not P0.tails and not P0.heads_fused
+    # round 6: with head dim 64 every unfused transformer block's cross-attention rides on its query projection (one launch fewer)
+    nx = sum("+cross-attention" in m["info"] for m in P0x.meta)
+    assert nx == sum(m["info"].startswith("cross ") for m in P0.meta) > blocks320 and len(P0.main) - len(P0x.main) == nx
+    assert all(m["desc"].xattn_k and m["desc"].tile_n == 64 and m["desc"].splitk == 1 for m in P0x.meta if "+cross-attention" in m["info"])
     # round 5: every transformer whose level has >= unet_gn_proj_fuse tokens per sample loses its GroupNorm launch to proj_in
     # (all of them here: 4096 and 1024 tokens), the GEMM count is unchanged, and the fused-head plan P already had none to lose at
     # the 320-channel level but folds the 640-channel ones
     folded1 = sum("+groupnorm(in)" in m["info"] for m in P1.meta)
     assert folded1 == sum(m["info"].startswith("self ") for m in P1.meta) and folded1 > blocks320
     assert kinds(P0)["groupnorm"] - kinds(P1)["groupnorm"] == folded1 and kinds(P0)["gemm"] == kinds(P1)["gemm"]
-    assert len(P0.main) - len(P1.main) == folded1 and not any("+groupnorm(in)" in m["info"] for m in P0.meta)
+    assert len(P0x.main) - len(P1.main) == folded1 and not any("+groupnorm(in)" in m["info"] for m in P0.meta)
     assert not any("+groupnorm(in)" in m["info"] for m in P.meta)      # the option is off by default (measured equal-or-slower)
     try:
         ops.set_option("unet_gn_proj_fuse", 1024)
@@ -885,9 +893,11 @@ def test_unet_plan_fuses_the_320_channel_transformer_blocks():
             assert d.gn_colstats and d.gn_nrb > 0 and d.gn_silu == 0 and d.ksize == 1 and (d.H * d.W) % ops.gemm_query(d)[0] == 0
     try:
         ops.set_option("unet_gn_proj_fuse", 0)
+        ops.set_option("unet_xattn_fuse", 0)
         P = build()._plan(2, 64, 64)                # (the comparison below is about the fused head / tail alone)
     finally:
         ops.set_option("unet_gn_proj_fuse", pf)
+        ops.set_option("unet_xattn_fuse", 1)
     k, k0 = kinds(P), kinds(P0)
     # per fused block: 8 GEMMs (proj_in, q|k|v, to_out, q, to_out, ff1, ff2, proj_out) become 2, the GroupNorm and the
     # cross-attention launch disappear
@@ -1015,7 +1025,7 @@ def test_lean_dense_kernel_wait_counts_equal_the_loads_it_issues(tmp_path):
                     f"{ROOT}/minddiffusion_amd/csrc/dense.hip"], check=True, capture_output=True)
     txt = out.read_text()
     n = 0
-    for m in re.finditer(r"^_ZN12_GLOBAL__N_112dense_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d)EEEvN7mdx_int10GemmParamsE:\s*;", txt, re.M):
+    for m in re.finditer(r"^_ZN12_GLOBAL__N_112dense_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d)ELb[01]EEEvN7mdx_int10GemmParamsE:\s*;", txt, re.M):
         bm, bn, ns, pf = (int(m.group(i)) for i in (1, 2, 3, 4))
         body = txt[m.end():txt.index(".end_amdhsa_kernel", m.end())]
         lines = body.split("\n")

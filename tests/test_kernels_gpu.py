@@ -991,6 +991,72 @@ def test_attention_software_pipelined_form(ops, ramp, D, heads, Nq, Nk, splits):
     assert torch.equal(outs[1], outs[0]), f"pipelined attention differs from attn_kernel: max |d| = {(outs[1].float() - outs[0].float()).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("B,T,C,L,tile_m,lnfold", [
+    (2, 1024, 640, 77, 0, True),      # SDv2 32 x 32 level at UNet batch 2: 10 heads, the LayerNorm-fold consumer form the planner emits
+    (2, 256, 1280, 77, 0, True),      # 16 x 16 level, 20 heads
+    (2, 64, 1280, 77, 64, True),      # 8 x 8 level: 64 tokens per sample, 64-row tiles
+    (3, 128, 320, 77, 128, False),    # plain projection (explicit LayerNorm in front), 128-row tiles, odd batch
+    (2, 256, 128, 64, 64, False),     # exactly one full key tile: no masked tile
+    (1, 128, 192, 128, 0, False),     # two full key tiles
+    (2, 128, 64, 5, 0, False),        # a handful of keys, one head
+])
+def test_dense_with_cross_attention_epilogue(ops, B, T, C, L, tile_m, lnfold):
+    """mdx_gemm_desc.xattn_k (round 6): BasicTransformerBlock.attn2 -- q = LN(x) Wq^T, softmax(q K^T / sqrt(64)) V over the cached context
+    keys -- with the attention as the EPILOGUE of the query projection (one 64-column tile = one head).  Against the oracle's fp32
+    arithmetic, and against the two launches it replaces (projection, mdx_attention_f16) BIT FOR BIT."""
+    heads = C // 64
+    cap = (L + 7) // 8 * 8
+    rng = np.random.RandomState(B * T + C + L)
+    x = h16(rng.standard_normal((B * T, C)))
+    wq = h16(rng.standard_normal((C, C)) / math.sqrt(C))
+    k = h16(0.7 * rng.standard_normal((B, L, C)))
+    v = h16(rng.standard_normal((B, L, C)))
+    kd = torch.zeros((B, cap, C), dtype=torch.float16, device=DEV)
+    kd[:, :L] = dev16(k)
+    vtd = torch.zeros((B, C, cap), dtype=torch.float16, device=DEV)
+    vtd[:, :, :L] = dev16(np.ascontiguousarray(v.transpose(0, 2, 1)))
+    xd = dev16(x)
+    scale = 64 ** -0.5
+    kw = {}
+    if lnfold:      # the planner's form: the projection runs on the raw rows with gamma-scaled weights + the producer's row statistics
+        g = (1.0 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+        bt = (0.1 * rng.standard_normal(C)).astype(np.float32)
+        xt = torch.tensor(x).float()
+        xn = (xt - xt.mean(1, keepdim=True)) / torch.sqrt(xt.var(1, unbiased=False, keepdim=True) + 1e-5) * torch.tensor(g) + torch.tensor(bt)
+        qref = xn @ torch.tensor(wq).float().T
+        wg, sv, cb = ops.fold_layernorm(torch.tensor(wq).to(DEV), torch.tensor(g).to(DEV), torch.tensor(bt).to(DEV))
+        wd = ops.pack_gemm_weight(wg)
+        nt = C // 64
+        st = torch.zeros((B * T, nt, 2), dtype=torch.float32, device=DEV)
+        xs = xd.float().reshape(B * T, nt, 64)
+        st[:, :, 0], st[:, :, 1] = xs.sum(2), (xs * xs).sum(2)
+        kw = dict(ln_stats=st, ln_s=sv, bias=cb)      # (the fold's W beta term is the projection's bias)
+    else:
+        qref = torch.tensor(x).float() @ torch.tensor(wq).float().T
+        wd = pack_dense(wq)
+    qh = qref.reshape(B, T, heads, 64).permute(0, 2, 1, 3)
+    kh = torch.tensor(k).float().reshape(B, L, heads, 64).permute(0, 2, 1, 3)
+    vh = torch.tensor(v).float().reshape(B, L, heads, 64).permute(0, 2, 1, 3)
+    ref = torch.matmul(torch.softmax(torch.matmul(qh, kh.transpose(2, 3)) * scale, -1), vh).permute(0, 2, 1, 3).reshape(B * T, C)
+    # the two launches
+    q = torch.empty((B * T, C), dtype=torch.float16, device=DEV)
+    d0 = ops.make_gemm_desc(xd, wd, C, B, T, 1, C, q, C, tile_n=64, splitk=1, tile_m=tile_m, **kw)
+    ops.gemm_run(d0)
+    two = torch.empty((B * T, C), dtype=torch.float16, device=DEV)
+    ops.attention(q.data_ptr(), kd.data_ptr(), vtd.data_ptr(), two.data_ptr(), B, heads, 64, T, L, scale,
+                  T * C, C, cap * C, C, C * cap, cap, T * C, C)
+    # the fused launch
+    one = torch.full((B * T, C), float("nan"), dtype=torch.float16, device=DEV)
+    d1 = ops.make_gemm_desc(xd, wd, C, B, T, 1, C, one, C, tile_n=64, splitk=1, tile_m=tile_m, xattn_k=kd, xattn_vt=vtd, xattn_len=L,
+                            xattn_cap=cap, xattn_scale=scale, **kw)
+    qq = ops.gemm_query(d1)
+    assert qq[3] == 2 and qq[1] == 64 and qq[2] == 1, qq
+    ops.gemm_run(d1)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), f"fused cross-attention differs from projection + mdx_attention_f16: max |d| = {(one.float() - two.float()).abs().max().item():.3e}"
+    check(f"dense_xattn_B{B}_T{T}_C{C}_L{L}_tm{tile_m}_ln{int(lnfold)}", one, ref, rel_l2=3e-3, max_abs=3e-2)
+
+
 @pytest.mark.parametrize("occ3", [1, 0])
 @pytest.mark.parametrize("ramp", [None, "stale6.5", "always12", "sawtooth"])
 @pytest.mark.parametrize("D,heads,Nq,Nk,splits", [
