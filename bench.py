@@ -254,8 +254,8 @@ def cpu_baseline(n_evals=3):
     }
 
 
-PMC_FILE = "r05_pmc_traffic.json"
-PMC_MFMA_FILE = "r05_pmc_mfma.json"      # the headline config; the other LDM configs: r05_pmc_mfma_<config>.json
+PMC_FILE = "r06_pmc_traffic.json"
+PMC_MFMA_FILE = "r06_pmc_mfma.json"      # the headline config; the other LDM configs: r06_pmc_mfma_<config>.json
 
 
 def pmc_traffic(gemm_launches_now):
@@ -531,8 +531,8 @@ def run_config(config, args, rank, world, device, steps, warmup, cpu):
             if config == "sd2_512":
                 roof["traffic"], roof["traffic_note"] = pmc_traffic(gemm_launches)
                 pmc_mfma_busy(roof, gemm_launches)
-            elif os.path.exists(os.path.join(ROOT, "profiles", f"r05_pmc_mfma_{config}.json")):
-                pmc_mfma_busy(roof, gemm_launches, f"r05_pmc_mfma_{config}.json")
+            elif os.path.exists(os.path.join(ROOT, "profiles", f"r06_pmc_mfma_{config}.json")):
+                pmc_mfma_busy(roof, gemm_launches, f"r06_pmc_mfma_{config}.json")
         else:
             # Taichu-GLIDE: one image = 60 guided base evaluations (UNet batch 2P) + 27 super-resolution evaluations (batch P);
             # profile both plans and weight them by their evaluation counts

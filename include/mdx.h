@@ -235,7 +235,7 @@ typedef struct mdx_gemm_desc {
      *   xattn_k  [B][xattn_cap][N] fp16 (keys, row-major: head h in columns 64 h ..), xattn_vt [B][N][xattn_cap] fp16 (values, transposed),
      *   xattn_len <= 128 keys of xattn_cap rows are attended to.
      * Dense row-major launches only (ksize 1, one source, no epilogue / residual / statistics / n_split / out_bs), N % 64 == 0, tokens per
-     * sample % 128 == 0 or == 64; set tile_n = 64 and splitk = 1. */
+     * sample % 128 == 0 (or % 64 == 0 with tile_m = 64); set tile_n = 64 and splitk = 1. */
     const void* xattn_k;
     const void* xattn_vt;
     int xattn_len;

@@ -1308,8 +1308,10 @@ int fill_params(const mdx_gemm_desc* d, GemmParams& p) {
                         d->epilogue == MDX_EPI_NONE && d->out_mode == MDX_OUT_ROWMAJOR && !d->residual && !d->rowbias && !d->stats_out &&
                         !d->colstats_out && !d->n_split && !d->out_bs && !d->gn_colstats && !d->defer_reduce,
                     "mdx_gemm_f16: the cross-attention epilogue rides on a plain dense row-major projection (N %% 64 == 0, Cin %% 64 == 0)");
-        MDX_REQUIRE(d->tile_n == 64 && d->splitk == 1 && (howo % 128 == 0 || howo == 64) && (d->tile_m == 0 || d->tile_m == 64 || d->tile_m == 128),
-                    "mdx_gemm_f16: the cross-attention epilogue needs tile_n = 64 (one head per tile), splitk = 1 and tokens per sample %% 128 == 0 (or == 64)");
+        MDX_REQUIRE(d->tile_n == 64 && d->splitk == 1 && (howo % 128 == 0 || (howo % 64 == 0 && d->tile_m == 64)) &&
+                        (d->tile_m == 0 || d->tile_m == 64 || d->tile_m == 128),
+                    "mdx_gemm_f16: the cross-attention epilogue needs tile_n = 64 (one head per tile), splitk = 1 and an M tile inside one sample "
+                    "(tokens per sample %% 128 == 0, or %% 64 == 0 with tile_m = 64)");
         MDX_REQUIRE((size_t)d->xattn_cap * d->N * 2 <= 0x80000000ull, "mdx_gemm_f16: cross-attention context larger than 2 GiB per sample");
     }
     p.w_sub = (const f16*)d->w_sub;

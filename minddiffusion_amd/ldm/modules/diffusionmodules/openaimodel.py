@@ -822,12 +822,12 @@ class UNetModel:
                 # (round 6) head dim 64 (SDv2): the 77-key attention rides on the query projection as its EPILOGUE -- one 64-column
                 # tile is one head (mdx_gemm_desc.xattn_k): no attention launch, no fp16 round trip of q; bit-identical to the two launches
                 xfuse = (ops.get_option("unet_xattn_fuse") and not _selfctx and dh == 64 and TC <= 128 and TC % 8 == 0
-                         and (n % 128 == 0 or n == 64))
+                         and n % 64 == 0)
                 if xfuse:
                     kc = torch.zeros((B, TC, inner), dtype=f16, device=dev)
                     vtc = torch.zeros((B, inner, TC), dtype=f16, device=dev)
                     ctx_kv[t] = (kc, vtc)
-                    xkw = dict(tile_n=64, splitk=1, xattn_k=kc, xattn_vt=vtc, xattn_len=TC, xattn_cap=TC, xattn_scale=scale, out=o,
+                    xkw = dict(tile_n=64, splitk=1, tile_m=0 if n % 128 == 0 else 64, xattn_k=kc, xattn_vt=vtc, xattn_len=TC, xattn_cap=TC, xattn_scale=scale, out=o,
                                out_ld=inner)
                 if st is None:
                     emit(lambda ln=ln, tok2=tok2, t=t: ops.layernorm(tok2, w[t + "norm2.g"], w[t + "norm2.b"], 1e-5, out=ln),

@@ -995,6 +995,7 @@ def test_attention_software_pipelined_form(ops, ramp, D, heads, Nq, Nk, splits):
     (2, 1024, 640, 77, 0, True),      # SDv2 32 x 32 level at UNet batch 2: 10 heads, the LayerNorm-fold consumer form the planner emits
     (2, 256, 1280, 77, 0, True),      # 16 x 16 level, 20 heads
     (2, 64, 1280, 77, 64, True),      # 8 x 8 level: 64 tokens per sample, 64-row tiles
+    (2, 576, 640, 77, 64, True),      # 24 x 24 level of a 768-pixel run: tokens per sample % 128 != 0 -> 64-row tiles
     (3, 128, 320, 77, 128, False),    # plain projection (explicit LayerNorm in front), 128-row tiles, odd batch
     (2, 256, 128, 64, 64, False),     # exactly one full key tile: no masked tile
     (1, 128, 192, 128, 0, False),     # two full key tiles

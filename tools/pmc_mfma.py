@@ -40,6 +40,11 @@ def main():
     except sqlite3.Error:
         pass
     evals = len(seen["attention"]) / per_eval if seen["attention"] else 1.0
+    if seen.get("eval_marker"):      # one launch per UNet evaluation (tools/pmc_traffic.py family())
+        evals = float(len(seen["eval_marker"]))
+    agg.pop("eval_marker", None)
+    seen.pop("eval_marker", None)
+    dur.pop("eval_marker", None)
     out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- " + command,
            "unet_evals_in_trace": evals, "simds": 1024,
            "formula": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES * 32 SIMDs per shader engine); "

@@ -21,12 +21,14 @@ from collections import defaultdict
 def family(name):
     if name.startswith("void at::") or "at::native" in name or "rocclr" in name:
         return None   # torch's weight-initialisation / copy kernels
-    if ("gemm_kernel" in name or "conv3x3_halo_kernel" in name or "st_tail_kernel" in name or "st_head_kernel" in name
-            or "conv8p_kernel" in name):
+    if "nchw_to_nhwc_kernel" in name:
+        return "eval_marker"      # exactly one launch per UNet evaluation (LatentDiffusion.apply_model's layout boundary)
+    if ("gemm_kernel" in name or "dense_kernel" in name or "conv3x3_halo_kernel" in name or "st_tail_kernel" in name
+            or "st_head_kernel" in name or "conv8p_kernel" in name):
         return "gemm"      # (the fused SpatialTransformer head / tail launches are chains of dense GEMMs)
     if "splitk_reduce" in name:
         return "splitk_reduce"
-    if "attn_kernel" in name:
+    if "attn_kernel" in name or "attn_pipe_kernel" in name or "attn8_kernel" in name:
         return "attention"
     if "gn_stats" in name or "gn_apply" in name or "gn_fused" in name:
         return "groupnorm"
@@ -57,6 +59,10 @@ def main():
     # attention launches per SDv2 UNet evaluation: 32, or 27 when the five 64 x 64 cross-attentions run inside the fused tails
     per_eval = float(sys.argv[3]) if len(sys.argv) > 3 else 32.0
     evals = fetch["attention"][0] / per_eval if fetch["attention"][0] else 1.0
+    if fetch.get("eval_marker", [0])[0]:      # (round 6: the attention count per evaluation depends on which cross-attentions ride on their
+        evals = float(fetch["eval_marker"][0])       # projections; the layout-boundary kernel runs exactly once per evaluation)
+    for agg in (fetch, write):
+        agg.pop("eval_marker", None)
     out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- " + command,
            "unet_evals_in_trace": evals,
            "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B); MALL hits included",
