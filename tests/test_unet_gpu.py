@@ -144,6 +144,34 @@ def test_context_cache_invalidation():
     assert float((a - b).abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_context_length_may_change_between_calls(graph):
+    """The cross-attention that rides on its query projection (mdx_gemm_desc.xattn_len, round 6) and the attention launches read the
+    context length of the CURRENT call: 7, then 12, then 3 text tokens through one plan (the captured graph is rebuilt when the length
+    changes), each against the oracle; and the planner option off gives the same bits."""
+    from minddiffusion_amd import ops
+    cfg = _tiny_cfg()
+    params = O.init_params(_oracle_cfg(cfg), seed=4)
+    net = _build(cfg, params, graph)
+    oracle = O.UNetOracle(_oracle_cfg(cfg), params)
+    assert any("+cross-attention" in m["info"] for m in net._plan(2, 8, 8).meta), "the tiny UNet (head dim 64, 64 tokens) should fuse"
+    outs = []
+    for T in (7, 12, 3, 12):
+        x, ctx = _inputs(2, 8, 8, T, cfg["context_dim"], seed=10 + T)
+        got = net(torch.tensor(x, device=DEV), torch.full((2,), 250.0, device=DEV), torch.tensor(ctx, device=DEV))
+        check(f"context_length_{T}_graph{int(graph)}", got, oracle(x, torch.full((2,), 250.0), ctx), rel_l2=5e-3)
+        outs.append(got.clone())
+    old = ops.get_option("unet_xattn_fuse")
+    ops.set_option("unet_xattn_fuse", 0)
+    try:
+        net0 = _build(cfg, params, graph)
+        x, ctx = _inputs(2, 8, 8, 12, cfg["context_dim"], seed=22)
+        two = net0(torch.tensor(x, device=DEV), torch.full((2,), 250.0, device=DEV), torch.tensor(ctx, device=DEV))
+    finally:
+        ops.set_option("unet_xattn_fuse", old)
+    assert torch.equal(two, outs[-1]) and torch.equal(outs[1], outs[-1]), "fused cross-attention changes the UNet's bits"
+
+
 @pytest.mark.parametrize("sampler,S,scale", [("plms", 5, 3.0), ("ddim", 5, 3.0), ("ddim", 4, 1.0), ("plms", 10, 7.5)])
 def test_tiny_sampler_trajectory(sampler, S, scale):
     from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion
