@@ -146,14 +146,15 @@ def build_model(device, cfg_name="sd2"):
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
-def family_profile(P, ops_list=None, passes=3):
+def family_profile(P, ops_list=None, passes=3, meta=None):
     """Per-op HIP-event timing of one evaluation of a planned network (UNetModel / Text2ImUNet plan `P`): the ops run in
     their real sequence on the launch stream (so weights stream from HBM, activations sit where the previous op left them),
     each bracketed by an event pair recorded on that stream.  Returns {kind: {ms, ops, launches, flops, bytes}} with the
     minimum over `passes` of each family's summed time.  kinds: gemm (implicit-GEMM conv / dense incl. their split-K
     reduce), attention, groupnorm, layernorm, small."""
     ops_list = P.main if ops_list is None else ops_list
-    meta = P.meta[len(P.meta) - len(ops_list):]
+    meta = P.meta[len(P.meta) - len(ops_list):] if meta is None else meta
+    assert len(meta) == len(ops_list)
     best = None
     for _ in range(passes):
         evs = []
@@ -479,13 +480,17 @@ def run_config(config, args, rank, world, device, steps, warmup, cpu):
             ctx = torch.randn(nb, 77, cfg["ctx_dim"], device=device, dtype=torch.float16)
             xs = torch.randn(nb, model.unet.in_channels, h, w, device=device)     # (9 channels for the inpainting UNet)
             tsv = torch.full((nb,), 501.0, device=device)
+            # (round 6) what the sampler's guidance call ran: the guidance-duplicate prefix from ops option unet_cfg_dup rows on
+            dupkw = {"cfg_dup": True} if getattr(model.unet._plan(nb, h, w), "dup_graph", None) is not None else {}
+            if dupkw:
+                xs[batch:] = xs[:batch]
             for _ in range(3):
-                model.apply_model_nhwc(xs, tsv, ctx)
+                model.apply_model_nhwc(xs, tsv, ctx, **dupkw)
             evs = []
             for _ in range(20):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                model.apply_model_nhwc(xs, tsv, ctx)
+                model.apply_model_nhwc(xs, tsv, ctx, **dupkw)
                 e1.record()
                 evs.append((e0, e1))
             torch.cuda.synchronize()
@@ -499,8 +504,12 @@ def run_config(config, args, rank, world, device, steps, warmup, cpu):
             tflop_per_unit = cfg["tflop_per_row"] * 2 * n_evals + cfg.get("vae_tflop", 0.0)   # CFG doubles the rows
             Pl = model.unet._plan(nb, h, w)
             # what actually ran in the timed region: a captured hipGraph replay, or (capture failed / --no-graph) eager launches
-            result["config"]["hip_graph"] = Pl.graph is not None
-            fams = family_profile(Pl, Pl.main[Pl.temb_ops:])
+            result["config"]["hip_graph"] = Pl.graph is not None or getattr(Pl, "dup_graph", None) is not None
+            # (round 6) a guidance batch of >= ops option unet_cfg_dup rows runs conv_in .. the first self-attention on one half
+            # (UNetModel._dup_body): profile the op list the sampler's graph was captured from
+            dup = getattr(Pl, "dup_graph", None) is not None
+            result["config"]["cfg_dup_prefix"] = dup
+            fams = family_profile(Pl, Pl.dup_body, meta=Pl.dup_meta) if dup else family_profile(Pl, Pl.main[Pl.temb_ops:])
             roof = roofline_from_families(family_fractions(fams), f"one UNet evaluation at batch {nb}")
             gemm_launches = fams["gemm"]["launches"]
             if cfg.get("vae"):   # VAE decode alone: HIP events around AutoencoderKL.decode, median of 10 warm calls

@@ -120,18 +120,19 @@ class LatentDiffusion:
         c_concat, c_crossattn = self._split_cond(cond, c_concat, c_crossattn)
         return self.model(x_noisy, t, c_concat=c_concat, c_crossattn=c_crossattn)
 
-    def apply_model_nhwc(self, x_noisy, t, cond, temb=None):
+    def apply_model_nhwc(self, x_noisy, t, cond, temb=None, cfg_dup=False):
         """Fast path used by the samplers: returns the UNet's static NHWC fp16 eps buffer [B, H*W, 8]
         (valid until the next call) so the fused sampler-step kernel can consume it without a layout pass.
         `x_noisy` already carries the c_concat channels for hybrid / concat conditioning (the sampler writes them once);
         `cond` is the text context ('crossattn' / 'hybrid'), the class labels ('adm'), or ignored (None / 'concat').
-        temb: the row of time_embedding_table() that belongs to `t` (optional)."""
+        temb: the row of time_embedding_table() that belongs to `t` (optional).  cfg_dup: the batch is [uncond ; cond] of the same
+        x_noisy and t (UNetModel.forward_nhwc)."""
         key = self.model.conditioning_key
         if key == "adm":
             return self.unet.forward_nhwc(x_noisy, t, None, y=_first(cond))
         if key is None or key == "concat":
             return self.unet.forward_nhwc(x_noisy, t, None, temb=temb)
-        return self.unet.forward_nhwc(x_noisy, t, cond, temb=temb)
+        return self.unet.forward_nhwc(x_noisy, t, cond, temb=temb, cfg_dup=cfg_dup)
 
     def time_embedding_table(self, t):
         """UNetModel.time_embedding_table: the timestep-only part of the UNet for all steps of a run, batched."""

@@ -34,9 +34,12 @@ class DPMSolverSampler:
     def register_buffer(self, name, attr):
         setattr(self, name, attr)
 
-    def _eps_nhwc(self, x, t, cond, temb=None):
+    def _eps_nhwc(self, x, t, cond, temb=None, cfg_dup=False):
         if hasattr(self.model, "apply_model_nhwc"):
-            return self.model.apply_model_nhwc(x, t, cond, **({} if temb is None else {"temb": temb}))
+            kw = {} if temb is None else {"temb": temb}
+            if cfg_dup:     # both halves of the batch are the same x and t: only the contexts differ
+                kw["cfg_dup"] = True
+            return self.model.apply_model_nhwc(x, t, cond, **kw)
         e = self.model.apply_model(x, t, cond).to(torch.float32).contiguous()
         return ops.nchw_to_nhwc(e, (e.shape[1] + 7) // 8 * 8)
 
@@ -86,7 +89,7 @@ class DPMSolverSampler:
             if use_cfg:
                 x_in[:b].copy_(img)
                 x_in[b:].copy_(img)
-                eps = self._eps_nhwc(x_in, t_all[k], c_in, None if temb_all is None else temb_all[k])
+                eps = self._eps_nhwc(x_in, t_all[k], c_in, None if temb_all is None else temb_all[k], cfg_dup=True)
                 eps_u, eps_c = eps[:b], eps[b:]
             else:
                 eps_u, eps_c = None, self._eps_nhwc(img, t_all[k], c_in, None if temb_all is None else temb_all[k])

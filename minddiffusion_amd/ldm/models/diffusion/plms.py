@@ -99,9 +99,12 @@ class _SamplerBase:
 
     # ---- model call: prefer the NHWC fast path of our LatentDiffusion; any object with the reference's
     #      apply_model(x, t, cond) -> NCHW eps still works (its output is re-laid-out by a HIP kernel).
-    def _eps_nhwc(self, x, t, cond, temb=None):
+    def _eps_nhwc(self, x, t, cond, temb=None, cfg_dup=False):
         if hasattr(self.model, "apply_model_nhwc"):
-            return self.model.apply_model_nhwc(x, t, cond, **({} if temb is None else {"temb": temb})), None
+            kw = {} if temb is None else {"temb": temb}
+            if cfg_dup:     # both halves of the batch are the same x and t: only the contexts differ
+                kw["cfg_dup"] = True
+            return self.model.apply_model_nhwc(x, t, cond, **kw), None
         e = self.model.apply_model(x, t, cond)
         e = e.to(torch.float32).contiguous()
         buf = ops.nchw_to_nhwc(e, (e.shape[1] + 7) // 8 * 8)
@@ -215,6 +218,8 @@ class _SamplerBase:
                 x_in[nb - b:, cx:] = cc                              # batch = [uncond ; cond]
                 if use_cfg:
                     x_in[:b, cx:] = cc if uc_cat is None else uc_cat.to(device=dev, dtype=torch.float32)
+        # the two halves of a guidance batch are the same UNet input unless the unconditional branch has its own c_concat
+        same_halves = use_cfg and c_in is not None and (c_cat is None or uc_cat is None)
         if mask is not None:
             mask = torch.as_tensor(mask).to(device=dev, dtype=torch.float32)
             x0 = torch.as_tensor(x0).to(device=dev, dtype=torch.float32)
@@ -239,7 +244,7 @@ class _SamplerBase:
             if use_cfg:
                 x_in[:b, :cx].copy_(x)
                 x_in[b:, :cx].copy_(x)
-                eps, keep = self._eps_nhwc(x_in, t_row, c_in, temb)
+                eps, keep = self._eps_nhwc(x_in, t_row, c_in, temb, cfg_dup=same_halves)
                 return eps[:b], eps[b:], keep           # batch = [uncond ; cond] (plms.py:192-195)
             if x_in is not None:
                 x_in[:, :cx].copy_(x)

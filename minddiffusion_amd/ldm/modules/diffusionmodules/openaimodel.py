@@ -504,6 +504,9 @@ class UNetModel:
 
         xin = A.get((B, H * W, self.cin_pad))
         emit(lambda: ops.nchw_to_nhwc(P.x_static, self.cin_pad, out=xin), "small")
+        # checkpoint of the guidance-duplicate prefix (_dup_body): the ops of the first conv and of the first self-attention, and the
+        # tensors that are live behind the latter
+        ck = {"xin": xin}
 
         P.ctx_pad = None
         P.attn_ws = None         # split-KV attention workspace (ops.attention_workspace), sized after the walk
@@ -765,6 +768,8 @@ class UNetModel:
                     qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
                     n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * n, n, n * inner, inner, ws=P.attn_ws),
                     "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
+                if "op" not in ck and "conv_in" in ck and len(hs) == 1:     # (only the first conv's output is held as a skip)
+                    ck.update(op=main[-1], live=(x, tok, o))
                 out = fused_tail(t0, tail_rows(t0, n, heads, dh), o, tok, x, ch, inner, heads, dh, n)
                 A.release(qk); A.release(vt); A.release(tok); A.release(o)
                 return out
@@ -810,13 +815,18 @@ class UNetModel:
                     qk.data_ptr(), qk.data_ptr() + inner * 2, vt.data_ptr(), o.data_ptr(), B, heads, dh, n, n, scale,
                     n * 2 * inner, 2 * inner, n * 2 * inner, 2 * inner, inner * nv, nv, n * inner, inner, ws=P.attn_ws),
                     "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
+                first = "op" not in ck and "conv_in" in ck and len(hs) == 1     # (only the first conv's output is held as a skip)
                 rows_t = tail_rows(t, n, heads, dh)
                 if rows_t:
+                    if first:
+                        ck.update(op=main[-1], live=(x, tok, o))
                     out = fused_tail(t, rows_t, o, tok, x, ch, inner, heads, dh, n)
                     A.release(qk); vt_release(vt); A.release(tok); A.release(ln)
                     return out
                 tok2 = dense(main, o, B, n, inner, inner, w[t + "attn1.o.w"], bias=w[t + "attn1.o.b"], residual=tok,
                              stats_out=st)
+                if first:       # attn1's output projection (+ the row statistics attn2.q's LayerNorm fold reads) is still context-free
+                    ck.update(op=main[-1], live=(x, tok2) + (() if st is None else (st,)))
                 A.release(qk); vt_release(vt); A.release(tok)
                 # --- attn2 (cross): K / V^T of the context are produced by the context plan
                 # (round 6) head dim 64 (SDv2): the 77-key attention rides on the query projection as its EPILOGUE -- one 64-column
@@ -922,6 +932,7 @@ class UNetModel:
                 pre = f"input_blocks.{i}.{j}."
                 if layer[0] == "conv":
                     cur, h, wd = conv3(xin, self.cin_pad, layer[2], w[pre + "w"], w[pre + "b"], h, wd)
+                    ck["conv_in"] = main[-1]
                     A.release(xin)
                     continue
                 new, h2, w2 = layer_op(pre, layer, cur, None, h, wd)
@@ -929,6 +940,7 @@ class UNetModel:
                     A.release(cur)
                 cur, h, wd = new, h2, w2
             hs.append((cur, h, wd))
+        ck.setdefault("op", None)      # (no self-attention in input block 1: no guidance-duplicate prefix)
         for j, layer in enumerate(self.middle_block):
             new, h, wd = layer_op(f"middle_block.{j}.", layer, cur, None, h, wd)
             if not held(cur):
@@ -1072,7 +1084,9 @@ class UNetModel:
         P.heads_fused = heads_fused
         P.ctx_kv = ctx_kv     # the cached context K / V^T buffers: descriptors hold raw pointers only
         P.xattn_descs = xattn_descs
+        P.ck = ck if (ck.get("op") is not None and not _selfctx) else None
         P.graph = None
+        P.dup_graph = None
         P.graph_failed = False
         self._plans[key] = P
         return P
@@ -1102,8 +1116,9 @@ class UNetModel:
         self._ctx_key = key
         self._ctx_ref = weakref.ref(context)
         # the attention ops read P.ctx_len at call time; a captured graph bakes it in
-        if P.graph is not None and getattr(P, "graph_ctx_len", None) != T:
+        if getattr(P, "graph_ctx_len", None) != T:
             P.graph = None
+            P.dup_graph = None
 
     def time_embedding_table(self, t):
         """Everything the UNet derives from the timestep alone -- sinusoid, time_embed MLP and the 22 ResBlock
@@ -1122,11 +1137,13 @@ class UNetModel:
         e2 = ops.dense_small(e1, w["te2.w"], w["te2.b"])
         return ops.dense_small(e2, w["emb.w"], w["emb.b"], act_in=True)
 
-    def forward_nhwc(self, x, timesteps, context=None, temb=None, y=None):
+    def forward_nhwc(self, x, timesteps, context=None, temb=None, y=None, cfg_dup=False):
         """Run the UNet; returns the plan's static NHWC fp16 eps buffer [B, H*W, 8] (first 4 channels valid).
         The buffer is overwritten by the next call.  temb: optional row(s) of time_embedding_table() for `timesteps`
         ([emb_total] or [B, emb_total]); the time-embedding launches are then skipped.  y: [B] class labels of a
-        class-conditional UNet (num_classes)."""
+        class-conditional UNet (num_classes).  cfg_dup: the caller states that the two halves of the batch carry the SAME x and
+        timesteps and differ only in `context` (classifier-free guidance, plms.py:192-195 `x_in = cat([x] * 2)`): the launches in
+        front of the first cross-attention may then run on one half (_dup_body)."""
         if (y is not None) != (self.num_classes is not None):      # openaimodel.py:545-547
             raise MdxError("UNetModel: must specify y if and only if the model is class-conditional")
         if y is not None and temb is not None:
@@ -1168,25 +1185,70 @@ class UNetModel:
                 P.y_static.copy_(yy)
             for op in P.main[:P.temb_ops]:
                 op()
+        dup = self._dup_body(P) if (cfg_dup and context is not None and y is None) else None
         if self.use_graph and not P.graph_failed:
+            if dup is not None:
+                if P.dup_graph is None:
+                    self._capture(P, dup)
+                if P.dup_graph is not None:
+                    P.dup_graph.replay()
+                    return P.eps_nhwc
             if P.graph is None:
                 self._capture(P)
             if P.graph is not None:
                 P.graph.replay()
                 return P.eps_nhwc
-        for op in P.main[P.temb_ops:]:
+        body = dup if dup is not None else P.main[P.temb_ops:]
+        for op in body:
             op()
-        self.last_launch_count = len(P.main)
+        self.last_launch_count = P.temb_ops + len(body)
         return P.eps_nhwc
 
-    def _capture(self, P):
+    def _dup_body(self, P):
+        """The op list of one evaluation whose batch is [uncond ; cond] of the SAME latents (classifier-free guidance, plms.py:192-195):
+        until the first cross-attention both halves compute the same numbers -- conv_in, the first ResBlock, the first
+        SpatialTransformer's GroupNorm / proj_in / qkv, its self-attention (at 64^2 .. 96^2 tokens the largest attention of the
+        network) and attn1's output projection.  Those launches run from the plan of HALF the batch; its live tensors (the ResBlock
+        output, the token stream and its LayerNorm row statistics) are then written to both halves of this plan's buffers and this
+        plan continues with attn2.  conv_in itself runs at the full batch (its output is the outermost skip connection, with column
+        statistics for the last GroupNorm: writing it costs what copying it would).  None when the option is off
+        (ops option unet_cfg_dup = smallest batch, 0 = never), the batch is odd or the network has no attention at its first level."""
+        mn = ops.get_option("unet_cfg_dup")
+        if not mn or P.B < mn or P.B % 2 or P.ck is None:
+            return None
+        if hasattr(P, "dup_body"):
+            return P.dup_body
+        P.dup_body = None
+        h = P.B // 2
+        PA = self._plan(h, P.H, P.W)
+        if PA.ck is None:
+            return None
+        ib, ic = P.main.index(P.ck["op"]), P.main.index(P.ck["conv_in"])
+        ja, jc = PA.main.index(PA.ck["op"]), PA.main.index(PA.ck["conv_in"])
+        xin_a, xin_b = PA.ck["xin"], P.ck["xin"]
+        copies = [lambda: xin_a.copy_(xin_b[:h]), lambda: PA.emb_all.copy_(P.emb_all[:h])]
+        spread = []
+        for src, dst in zip(PA.ck["live"], P.ck["live"]):
+            assert dst.shape[0] == 2 * src.shape[0] and dst.shape[1:] == src.shape[1:]
+            spread.append(lambda src=src, dst=dst, k=src.shape[0]: (dst[:k].copy_(src), dst[k:].copy_(src)))
+        P.dup_half = PA
+        P.dup_body = P.main[P.temb_ops:ic + 1] + copies + PA.main[jc:ja + 1] + spread + P.main[ib + 1:]
+        small = {"kind": "small", "flops": 0, "launches": 1, "info": "guidance-duplicate prefix: copy"}
+        P.dup_meta = (P.meta[P.temb_ops:ic + 1] + [dict(small) for _ in copies] + PA.meta[jc:ja + 1]
+                      + [dict(small, launches=2) for _ in spread] + P.meta[ib + 1:])     # (parallel to dup_body, for the profilers)
+        return P.dup_body
+
+    def _capture(self, P, dup=None):
         """Capture the whole forward as one hipGraph (kills ~450 launch gaps per call)."""
         try:
-            body = P.main[P.temb_ops:]   # the graph starts from P.emb_all (filled eagerly or from the sampler's table)
+            body = dup if dup is not None else P.main[P.temb_ops:]   # the graph starts from P.emb_all (filled eagerly or from the sampler's table)
             for op in body:  # warm-up outside capture
                 op()
             torch.cuda.synchronize()
-            P.graph = ops.capture_graph(body)
+            if dup is not None:
+                P.dup_graph = ops.capture_graph(body)
+            else:
+                P.graph = ops.capture_graph(body)
             P.graph_ctx_len = P.ctx_len
         except Exception as e:  # pragma: no cover - depends on the runtime
             P.graph = None

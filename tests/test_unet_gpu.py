@@ -172,6 +172,52 @@ def test_context_length_may_change_between_calls(graph):
     assert torch.equal(two, outs[-1]) and torch.equal(outs[1], outs[-1]), "fused cross-attention changes the UNet's bits"
 
 
+@pytest.mark.parametrize("name", ["tiny", "wukong_style", "depth2_updown", "no_attention_at_level_0"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_guidance_duplicate_prefix(name, graph):
+    """A guidance batch is cat([x] * 2) with [uncond ; cond] contexts (plms.py:192-195): forward_nhwc(cfg_dup=True) runs conv_in .. the
+    first self-attention from the HALF-batch plan and writes its live tensors to both halves (UNetModel._dup_body, round 6).  Checked
+    against the oracle at even and odd half batches, with the sampler's time-embedding rows, across a context-length change, and
+    next to the plain evaluation of the same inputs (other tiles at half the batch: equal to rounding, not to the bit)."""
+    from minddiffusion_amd import ops
+    from minddiffusion_amd.configs import SMALL_WUKONG_UNET
+    cfg = {"tiny": _tiny_cfg(), "wukong_style": dict(SMALL_WUKONG_UNET),
+           "depth2_updown": dict(_tiny_cfg(), transformer_depth=2, resblock_updown=True),
+           "no_attention_at_level_0": dict(_tiny_cfg(), attention_resolutions=[2])}[name]
+    ocfg = _oracle_cfg(cfg)
+    params = O.init_params(ocfg, seed=21)
+    net = _build(cfg, params, graph)
+    oracle = O.UNetOracle(ocfg, params)
+    old = ops.get_option("unet_cfg_dup")
+    ops.set_option("unet_cfg_dup", 2)
+    try:
+        for (B, H, W, T, use_table) in ((4, 8, 8, 7, False), (6, 8, 8, 12, True), (2, 16, 16, 77, True), (4, 8, 8, 5, False)):
+            x, ctx = _inputs(B, H, W, T, cfg["context_dim"], seed=3 * B + T)
+            x[B // 2:] = x[:B // 2]
+            ts = np.full((B,), 437.0, np.float32)
+            xd, td, cd = torch.tensor(x, device=DEV), torch.tensor(ts, device=DEV), torch.tensor(ctx, device=DEV)
+            kw = {"temb": net.time_embedding_table(td[:1])[0]} if use_table else {}
+            got = ops.nhwc_to_nchw(net.forward_nhwc(xd, td, cd, cfg_dup=True, **kw), net.final_channels, H, W).clone()
+            P = net._plan(B, H, W)
+            if name == "no_attention_at_level_0":
+                assert P.ck is None and net._dup_body(P) is None
+            else:
+                assert P.dup_body is not None and (P.dup_graph is not None) == graph
+                assert sum(m["flops"] for m in P.dup_meta) < 0.99 * sum(m["flops"] for m in P.meta)
+            check(f"guidance_dup_{name}_graph{int(graph)}_B{B}_{H}x{W}_T{T}", got, oracle(x, torch.tensor(ts), ctx), rel_l2=5e-3,
+                  max_abs=5e-2)
+            plain = ops.nhwc_to_nchw(net.forward_nhwc(xd, td, cd, **kw), net.final_channels, H, W)
+            rel = float((got - plain).norm() / plain.norm())
+            assert rel < 2e-3, rel
+            again = ops.nhwc_to_nchw(net.forward_nhwc(xd, td, cd, cfg_dup=True, **kw), net.final_channels, H, W)
+            assert torch.equal(got, again), "replay of the guidance-duplicate body is not deterministic"
+        # below the option's batch, and with the option off, the call is the plain evaluation
+        ops.set_option("unet_cfg_dup", 8)
+        assert net._dup_body(net._plan(4, 8, 8)) is None
+    finally:
+        ops.set_option("unet_cfg_dup", old)
+
+
 @pytest.mark.parametrize("sampler,S,scale", [("plms", 5, 3.0), ("ddim", 5, 3.0), ("ddim", 4, 1.0), ("plms", 10, 7.5)])
 def test_tiny_sampler_trajectory(sampler, S, scale):
     from minddiffusion_amd.ldm.models.diffusion.ddpm import LatentDiffusion

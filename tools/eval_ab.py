@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--guidance", action="store_true", help="the batch is [uncond ; cond] of the same latents and the call says so "
+                    "(forward_nhwc(cfg_dup=True)): arms can then differ in unet_cfg_dup")
     args = ap.parse_args()
     from bench import build_model
     from minddiffusion_amd import ops
@@ -52,23 +54,26 @@ def main():
         x = torch.randn(B, 4, h, h, device=dev)
         ctx = torch.randn(B, 77, net.context_dim, device=dev, dtype=torch.float16)
         t = torch.full((B,), 501.0, device=dev)
-        net.forward_nhwc(x, t, ctx)
+        if args.guidance:
+            x[B // 2:] = x[:B // 2]
+        net.forward_nhwc(x, t, ctx, cfg_dup=args.guidance)
         P = net._plans[(B, h, h)]
-        assert P.graph is not None
-        plans[name] = (net, P)
+        g = P.dup_graph if (args.guidance and P.dup_graph is not None) else P.graph
+        assert g is not None
+        plans[name] = (net, P, g, len(P.dup_body) if g is P.dup_graph else len(P.main))
         torch.cuda.synchronize()
     for k in allopts:
         ops.set_option(k, defaults[k])
     times = {name: [] for name, _ in arms}
     for r in range(args.rounds):
         for name, _ in arms:
-            P = plans[name][1]
-            P.graph.replay()
+            g = plans[name][2]
+            g.replay()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.iters):
-                P.graph.replay()
+                g.replay()
             e1.record()
             torch.cuda.synchronize()
             times[name].append(e0.elapsed_time(e1) / args.iters)
@@ -79,9 +84,9 @@ def main():
         med = ms[len(ms) // 2]
         base = base or med
         res["arms"][name] = dict(options=opts, ms_per_eval_median=round(med, 4), ms_per_eval_min=round(ms[0], 4),
-                                 all=[round(x, 4) for x in times[name]], launches=len(plans[name][1].main))
+                                 all=[round(x, 4) for x in times[name]], launches=plans[name][3])
         print(f"{args.model} B={B} latent={h}  {name:12s} {med:8.4f} ms / evaluation (min {ms[0]:.4f})  {100 * (med / base - 1):+.2f} %  "
-              f"ops {len(plans[name][1].main)}  {opts}", flush=True)
+              f"ops {plans[name][3]}  {opts}", flush=True)
     if args.out:
         json.dump(res, open(args.out, "w"), indent=1)
 
