@@ -96,7 +96,8 @@ def test_config2_wukong_plms50_batch8_full_size_vs_fixture():
     got, _ = PLMSSampler(model).sample(50, 8, (4, 64, 64), conditioning={"c_crossattn": [dev(inp["c"])]}, x_T=dev(inp["x_T"]),
                                        unconditional_guidance_scale=inp["scale"],
                                        unconditional_conditioning={"c_crossattn": [dev(inp["uc"])]}, verbose=False)
-    assert net._plans[(16, 64, 64)].graph is not None
+    # (round 6) a guidance batch of >= 4 rows replays the graph of the guidance-duplicate body (UNetModel._dup_body)
+    assert net._plans[(16, 64, 64)].dup_graph is not None
     check("traj_config2_wukong_plms50_B8_image0", got[:1], z["final"].astype(np.float32), rel_l2=5e-3, max_rel=2e-2)
     _three_way("config2_wukong_plms50", got[:1].cpu(), z, meta)
 
@@ -112,7 +113,7 @@ def test_config3_sd2_768_ddim50_batch4_full_size_vs_fixture():
     got, _ = DDIMSampler(model).sample(50, 4, (4, 96, 96), conditioning=dev(inp["c"]), x_T=dev(inp["x_T"]),
                                        unconditional_guidance_scale=inp["scale"], unconditional_conditioning=dev(inp["uc"]),
                                        verbose=False)
-    assert net._plans[(8, 96, 96)].graph is not None
+    assert net._plans[(8, 96, 96)].dup_graph is not None
     check("traj_config3_sd2_768_ddim50_B4_image0", got[:1], z["final"].astype(np.float32), rel_l2=5e-3, max_rel=2e-2)
     _three_way("config3_sd2_768_ddim50", got[:1].cpu(), z, meta)
 

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--top", type=int, default=30)
     ap.add_argument("--model", default="sd2")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--guidance", action="store_true", help="profile the op list of a guidance batch (cat([x] * 2), UNetModel._dup_body: "
+                    "conv_in .. attn1.to_out of the first SpatialTransformer from the half-batch plan); needs batch >= ops option unet_cfg_dup")
     args = ap.parse_args()
     from bench import build_model, build_vae
     dev = torch.device("cuda:0")
@@ -41,13 +43,20 @@ def main():
         net._ensure_context(P, ctx)
         P.x_static.copy_(torch.randn(B, 4, h, h, device=dev))
         P.t_static.fill_(501.0)
-    for op in P.main:
+    oplist, metas = P.main, P.meta
+    if args.guidance:
+        for op in P.main[:P.temb_ops]:
+            op()
+        body = net._dup_body(P)
+        assert body is not None, "no guidance-duplicate prefix for this batch / network"
+        oplist, metas = body, P.dup_meta
+    for op in oplist:
         op()
     torch.cuda.synchronize()
-    best = [float("inf")] * len(P.main)
+    best = [float("inf")] * len(oplist)
     for _ in range(args.passes):
         evs = []
-        for op in P.main:
+        for op in oplist:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             op()
@@ -57,7 +66,7 @@ def main():
         for i, (a, b) in enumerate(evs):
             best[i] = min(best[i], a.elapsed_time(b) * 1e3)  # us
     kinds = collections.defaultdict(lambda: [0.0, 0, 0])
-    for t, m in zip(best, P.meta):
+    for t, m in zip(best, metas):
         k = kinds[m["kind"]]
         k[0] += t
         k[1] += 1
@@ -69,12 +78,12 @@ def main():
     order = sorted(range(len(best)), key=lambda i: -best[i])[: args.top]
     print("slowest ops:")
     for i in order:
-        m = P.meta[i]
+        m = metas[i]
         print(f"  #{i:3d} {m['kind']:10s} {best[i]:8.1f} us  {m['flops'] / max(best[i], 1e-9) / 1e6:7.1f} TF/s  {m['info']}")
     if args.out:
         with open(args.out, "w") as f:
             json.dump({"B": B, "latent": h, "total_us": total,
-                       "ops": [dict({k: v for k, v in m.items() if k != "desc"}, us=t) for t, m in zip(best, P.meta)]}, f)
+                       "ops": [dict({k: v for k, v in m.items() if k != "desc"}, us=t) for t, m in zip(best, metas)]}, f)
 
 
 if __name__ == "__main__":
