@@ -344,7 +344,8 @@ def main():
                 "metric": r["metric"], "value": r["value"], "unit": r["unit"], "steps": r["steps"], "warmup": r["warmup"],
                 "ms_per_step": r["ms_per_step"], "per_unet_step_ms": r.get("per_unet_step_ms"),
                 "workload": r["config"]["workload"], "global_batch": r["config"]["global_batch"],
-                "hip_graph": r["config"]["hip_graph"], "families": r["roofline"]["families"],
+                "hip_graph": r["config"]["hip_graph"], "cfg_dup_prefix": r["config"].get("cfg_dup_prefix"),
+                "families": r["roofline"]["families"],
                 "gemm_family_tflops": r["roofline"]["achieved"], "whole_path": r["roofline"]["whole_path"]}
     if rank == 0:
         print(json.dumps(result), flush=True)
