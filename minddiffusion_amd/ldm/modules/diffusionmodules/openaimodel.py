@@ -817,16 +817,17 @@ class UNetModel:
                     "attention", 4 * B * heads * n * n * dh, 1, f"self B={B} h={heads} N={n} d={dh}")
                 first = "op" not in ck and "conv_in" in ck and len(hs) == 1     # (only the first conv's output is held as a skip)
                 rows_t = tail_rows(t, n, heads, dh)
+                if first:       # splice point "behind the self-attention": every plan has it
+                    ck.update(op=main[-1], live=(x, tok, o))
                 if rows_t:
-                    if first:
-                        ck.update(op=main[-1], live=(x, tok, o))
                     out = fused_tail(t, rows_t, o, tok, x, ch, inner, heads, dh, n)
                     A.release(qk); vt_release(vt); A.release(tok); A.release(ln)
                     return out
                 tok2 = dense(main, o, B, n, inner, inner, w[t + "attn1.o.w"], bias=w[t + "attn1.o.b"], residual=tok,
                              stats_out=st)
-                if first:       # attn1's output projection (+ the row statistics attn2.q's LayerNorm fold reads) is still context-free
-                    ck.update(op=main[-1], live=(x, tok2) + (() if st is None else (st,)))
+                if first:       # attn1's output projection (+ the row statistics attn2.q's LayerNorm fold reads) is still context-free:
+                    # a later splice point, used when BOTH plans of a guidance-duplicate pair have it (the fused tail starts at to_out)
+                    ck.update(op2=main[-1], live2=(x, tok2) + (() if st is None else (st,)))
                 A.release(qk); vt_release(vt); A.release(tok)
                 # --- attn2 (cross): K / V^T of the context are produced by the context plan
                 # (round 6) head dim 64 (SDv2): the 77-key attention rides on the query projection as its EPILOGUE -- one 64-column
@@ -1208,9 +1209,10 @@ class UNetModel:
         """The op list of one evaluation whose batch is [uncond ; cond] of the SAME latents (classifier-free guidance, plms.py:192-195):
         until the first cross-attention both halves compute the same numbers -- conv_in, the first ResBlock, the first
         SpatialTransformer's GroupNorm / proj_in / qkv, its self-attention (at 64^2 .. 96^2 tokens the largest attention of the
-        network) and attn1's output projection.  Those launches run from the plan of HALF the batch; its live tensors (the ResBlock
-        output, the token stream and its LayerNorm row statistics) are then written to both halves of this plan's buffers and this
-        plan continues with attn2.  conv_in itself runs at the full batch (its output is the outermost skip connection, with column
+        network) and, where it is a launch of its own in both plans, attn1's output projection.  Those launches run from the plan of
+        HALF the batch; its live tensors (the ResBlock output, the token stream and the attention output -- or the token stream behind
+        to_out and its LayerNorm row statistics) are then written to both halves of this plan's buffers and this plan continues
+        with what follows.  conv_in itself runs at the full batch (its output is the outermost skip connection, with column
         statistics for the last GroupNorm: writing it costs what copying it would).  None when the option is off
         (ops option unet_cfg_dup = smallest batch, 0 = never), the batch is odd or the network has no attention at its first level."""
         mn = ops.get_option("unet_cfg_dup")
@@ -1223,13 +1225,19 @@ class UNetModel:
         PA = self._plan(h, P.H, P.W)
         if PA.ck is None:
             return None
-        ib, ic = P.main.index(P.ck["op"]), P.main.index(P.ck["conv_in"])
-        ja, jc = PA.main.index(PA.ck["op"]), PA.main.index(PA.ck["conv_in"])
+        # the splice point: behind attn1's output projection when both plans launch it (a plan whose fused tail starts at to_out
+        # does not), else behind the self-attention
+        late = "op2" in P.ck and "op2" in PA.ck and len(P.ck["live2"]) == len(PA.ck["live2"])
+        ko, kl = ("op2", "live2") if late else ("op", "live")
+        ib, ic = P.main.index(P.ck[ko]), P.main.index(P.ck["conv_in"])
+        ja, jc = PA.main.index(PA.ck[ko]), PA.main.index(PA.ck["conv_in"])
         xin_a, xin_b = PA.ck["xin"], P.ck["xin"]
         copies = [lambda: xin_a.copy_(xin_b[:h]), lambda: PA.emb_all.copy_(P.emb_all[:h])]
         spread = []
-        for src, dst in zip(PA.ck["live"], P.ck["live"]):
-            assert dst.shape[0] == 2 * src.shape[0] and dst.shape[1:] == src.shape[1:]
+        for src, dst in zip(PA.ck[kl], P.ck[kl]):
+            if not (dst.shape[0] == 2 * src.shape[0] and dst.shape[1:] == src.shape[1:] and dst.dtype == src.dtype):
+                raise MdxError(f"UNetModel: guidance-duplicate prefix: live tensors of the two plans do not pair up "
+                               f"({tuple(src.shape)} vs {tuple(dst.shape)})")
             spread.append(lambda src=src, dst=dst, k=src.shape[0]: (dst[:k].copy_(src), dst[k:].copy_(src)))
         P.dup_half = PA
         P.dup_body = P.main[P.temb_ops:ic + 1] + copies + PA.main[jc:ja + 1] + spread + P.main[ib + 1:]

@@ -53,7 +53,7 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
             "unet_xattn_fuse": int(os.environ.get("MDX_UNET_XATTN_FUSE", "1")),
             # (round 6) classifier-free guidance evaluates cat([x] * 2) with [uncond ; cond] contexts (plms.py:192-195): up to the
             # first cross-attention both halves are the same numbers.  From this batch on (0 = never) a sampler's guidance call runs
-            # conv_in .. the first self-attention and its output projection on ONE half and write the result to both (UNetModel._dup_body)
+            # conv_in .. the first self-attention (and its output projection where that is a launch of its own) on ONE half and write the result to both (UNetModel._dup_body)
             "unet_cfg_dup": int(os.environ.get("MDX_UNET_CFG_DUP", "4")),
             # Taichu-GLIDE AttentionBlock (unet.py:267-297): 1 = q | k | v of the image tokens in ONE launch (q | k row-major into a
             # [B, text + image, 2 C] buffer, V transposed: mdx_gemm_desc.n_split with out_bs) instead of three -- 44 launches fewer

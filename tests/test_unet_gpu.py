@@ -172,7 +172,7 @@ def test_context_length_may_change_between_calls(graph):
     assert torch.equal(two, outs[-1]) and torch.equal(outs[1], outs[-1]), "fused cross-attention changes the UNet's bits"
 
 
-@pytest.mark.parametrize("name", ["tiny", "wukong_style", "depth2_updown", "no_attention_at_level_0"])
+@pytest.mark.parametrize("name", ["tiny", "wukong_style", "wukong_style_64x64", "depth2_updown", "no_attention_at_level_0"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_guidance_duplicate_prefix(name, graph):
     """A guidance batch is cat([x] * 2) with [uncond ; cond] contexts (plms.py:192-195): forward_nhwc(cfg_dup=True) runs conv_in .. the
@@ -181,7 +181,7 @@ def test_guidance_duplicate_prefix(name, graph):
     next to the plain evaluation of the same inputs (other tiles at half the batch: equal to rounding, not to the bit)."""
     from minddiffusion_amd import ops
     from minddiffusion_amd.configs import SMALL_WUKONG_UNET
-    cfg = {"tiny": _tiny_cfg(), "wukong_style": dict(SMALL_WUKONG_UNET),
+    cfg = {"tiny": _tiny_cfg(), "wukong_style": dict(SMALL_WUKONG_UNET), "wukong_style_64x64": dict(SMALL_WUKONG_UNET),
            "depth2_updown": dict(_tiny_cfg(), transformer_depth=2, resblock_updown=True),
            "no_attention_at_level_0": dict(_tiny_cfg(), attention_resolutions=[2])}[name]
     ocfg = _oracle_cfg(cfg)
@@ -191,7 +191,13 @@ def test_guidance_duplicate_prefix(name, graph):
     old = ops.get_option("unet_cfg_dup")
     ops.set_option("unet_cfg_dup", 2)
     try:
-        for (B, H, W, T, use_table) in ((4, 8, 8, 7, False), (6, 8, 8, 12, True), (2, 16, 16, 77, True), (4, 8, 8, 5, False)):
+        shapes = ((4, 8, 8, 7, False), (6, 8, 8, 12, True), (2, 16, 16, 77, True), (4, 8, 8, 5, False))
+        if name == "wukong_style_64x64":
+            # 4096 tokens at C = 320: the batch-2 plan runs the fused SpatialTransformer tail (256 row blocks), the batch-1 plan the
+            # unfused launches (128 < 192, tail_rows): the two plans splice behind the self-attention, the one point both have
+            shapes = ((2, 64, 64, 77, True),)
+            assert net._plan(2, 64, 64).tails and not net._plan(1, 64, 64).tails
+        for (B, H, W, T, use_table) in shapes:
             x, ctx = _inputs(B, H, W, T, cfg["context_dim"], seed=3 * B + T)
             x[B // 2:] = x[:B // 2]
             ts = np.full((B,), 437.0, np.float32)
@@ -213,7 +219,7 @@ def test_guidance_duplicate_prefix(name, graph):
             assert torch.equal(got, again), "replay of the guidance-duplicate body is not deterministic"
         # below the option's batch, and with the option off, the call is the plain evaluation
         ops.set_option("unet_cfg_dup", 8)
-        assert net._dup_body(net._plan(4, 8, 8)) is None
+        assert net._dup_body(net._plan(shapes[0][0], shapes[0][1], shapes[0][2])) is None
     finally:
         ops.set_option("unet_cfg_dup", old)
 

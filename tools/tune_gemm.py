@@ -114,6 +114,8 @@ def main():
     for (M, N, K, ks, var), d0 in sorted(shapes.items()):
         if (args.only_m and M != args.only_m) or (args.only_ks and ks != args.only_ks):
             continue
+        if d0.xattn_k:      # a query projection that carries its cross-attention: the planner fixes its tiles (one head per 64-column tile)
+            continue
         kt = (K + 63) // 64
         halo = ks == 3 and d0.c2 == 0 and (d0.c1 % 64 == 0) and d0.W % 16 == 0 and d0.H % 8 == 0
         halo8 = ks == 3 and d0.c2 == 0 and (d0.c1 % 64 == 0) and d0.W == 8 and d0.H == 8   # bm = 128: HALO, bm = 64: generic
