@@ -333,6 +333,43 @@ def test_unet_plan_builds_and_every_descriptor_validates():
         net._plan(1, 7, 8)   # not divisible by the downsampling factor
 
 
+def test_guidance_duplicate_op_list_on_host():
+    """UNetModel._dup_body composed from host-planned plans (nothing is launched): the full-batch plan up to conv_in, two copies into
+    the half-batch plan, that plan's ops up to the splice point, the copies back, the rest of the full-batch plan -- with the metadata
+    list in step; no prefix for an odd batch, below the option's batch, or for a UNet without attention at its first level."""
+    from minddiffusion_amd import ops
+    from minddiffusion_amd.configs import TINY_UNET, SMALL_WUKONG_UNET
+    from minddiffusion_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from minddiffusion_amd.weights import synthetic_unet_params_numpy
+    old = ops.get_option("unet_cfg_dup")
+    try:
+        for cfg in (TINY_UNET, SMALL_WUKONG_UNET):
+            net = UNetModel(device="cpu", **cfg)
+            net.load_state_dict(synthetic_unet_params_numpy(net.parameter_shapes(), 0))
+            ops.set_option("unet_cfg_dup", 4)
+            P, PA = net._plan(4, 8, 8), net._plan(2, 8, 8)
+            body = net._dup_body(P)
+            assert body is not None and len(body) == len(P.dup_meta) and P.dup_half is PA
+            ic = P.main.index(P.ck["conv_in"])
+            assert body[:ic + 1 - P.temb_ops] == P.main[P.temb_ops:ic + 1]                 # layout pass + conv_in at the full batch
+            key = "op2" if ("op2" in P.ck and "op2" in PA.ck) else "op"
+            ja, ib = PA.main.index(PA.ck[key]), P.main.index(P.ck[key])
+            assert body[-(len(P.main) - ib - 1):] == P.main[ib + 1:]                        # the full-batch plan behind the splice
+            assert all(op in body for op in PA.main[PA.main.index(PA.ck["conv_in"]):ja + 1])
+            assert not any(op in body for op in P.main[ic + 1:ib + 1])                      # the duplicated launches are gone
+            assert sum(m["flops"] for m in P.dup_meta) < sum(m["flops"] for m in P.meta[P.temb_ops:])
+            assert net._dup_body(net._plan(3, 8, 8)) is None                                # odd batch
+            assert net._dup_body(net._plan(2, 8, 8)) is None                                # below the option's batch
+            ops.set_option("unet_cfg_dup", 0)
+            assert net._dup_body(P) is None
+        ops.set_option("unet_cfg_dup", 2)
+        net = UNetModel(device="cpu", **dict(TINY_UNET, attention_resolutions=[2]))
+        net.load_state_dict(synthetic_unet_params_numpy(net.parameter_shapes(), 0))
+        assert net._plan(4, 8, 8).ck is None and net._dup_body(net._plan(4, 8, 8)) is None
+    finally:
+        ops.set_option("unet_cfg_dup", old)
+
+
 TINY_GLIDE = dict(image_size=16, num_channels=64, num_res_blocks=1, channel_mult=(1, 2), num_heads=1,
                   num_head_channels=64, num_heads_upsample=-1, attention_resolutions=(1, 2), dropout=0.0, text_ctx=16,
                   xf_width=64, xf_layers=2, xf_heads=1, xf_final_ln=True, n_vocab=100, xf_padding=True,
