@@ -1187,6 +1187,11 @@ class UNetModel:
             for op in P.main[:P.temb_ops]:
                 op()
         dup = self._dup_body(P) if (cfg_dup and context is not None and y is None) else None
+        if dup is not None and ops.get_option("unet_cfg_dup_check"):
+            hb = B // 2
+            same = torch.equal(P.x_static[:hb], P.x_static[hb:]) and torch.equal(P.emb_all[:hb], P.emb_all[hb:])
+            if not same:
+                raise MdxError("UNetModel: cfg_dup=True, but the two halves of the batch do not carry the same x / timesteps")
         if self.use_graph and not P.graph_failed:
             if dup is not None:
                 if P.dup_graph is None:

@@ -55,6 +55,10 @@ _OPTIONS = {"unet_st_tail": int(os.environ.get("MDX_UNET_ST_TAIL", "-1")),
             # first cross-attention both halves are the same numbers.  From this batch on (0 = never) a sampler's guidance call runs
             # conv_in .. the first self-attention (and its output projection where that is a launch of its own) on ONE half and write the result to both (UNetModel._dup_body)
             "unet_cfg_dup": int(os.environ.get("MDX_UNET_CFG_DUP", "4")),
+            # 1 = every cfg_dup call first compares the two halves of x (and of per-sample timesteps / temb rows) on the device and raises if
+            # they differ: a host synchronisation per call, for bringing up a new sampler -- the shipped samplers build both halves
+            # from one tensor
+            "unet_cfg_dup_check": int(os.environ.get("MDX_UNET_CFG_DUP_CHECK", "0")),
             # Taichu-GLIDE AttentionBlock (unet.py:267-297): 1 = q | k | v of the image tokens in ONE launch (q | k row-major into a
             # [B, text + image, 2 C] buffer, V transposed: mdx_gemm_desc.n_split with out_bs) instead of three -- 44 launches fewer
             # per base evaluation.  0 = three launches (A/B)

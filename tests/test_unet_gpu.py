@@ -217,6 +217,21 @@ def test_guidance_duplicate_prefix(name, graph):
             assert rel < 2e-3, rel
             again = ops.nhwc_to_nchw(net.forward_nhwc(xd, td, cd, cfg_dup=True, **kw), net.final_channels, H, W)
             assert torch.equal(got, again), "replay of the guidance-duplicate body is not deterministic"
+        if name == "tiny":      # the bring-up check (option unet_cfg_dup_check): halves that differ are refused
+            from minddiffusion_amd._lib import MdxError
+            ops.set_option("unet_cfg_dup_check", 1)
+            try:
+                net.forward_nhwc(xd, td, cd, cfg_dup=True)
+                bad = xd.clone()
+                bad[-1, 0, 0, 0] += 1.0
+                with pytest.raises(MdxError, match="do not carry the same"):
+                    net.forward_nhwc(bad, td, cd, cfg_dup=True)
+                tb = td.clone()
+                tb[-1] += 1.0
+                with pytest.raises(MdxError, match="do not carry the same"):
+                    net.forward_nhwc(xd, tb, cd, cfg_dup=True)
+            finally:
+                ops.set_option("unet_cfg_dup_check", 0)
         # below the option's batch, and with the option off, the call is the plain evaluation
         ops.set_option("unet_cfg_dup", 8)
         assert net._dup_body(net._plan(shapes[0][0], shapes[0][1], shapes[0][2])) is None
