@@ -45,6 +45,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 constexpr int C8_TICKET_SLOTS = MDX_GEMM_WS_HEAD / 4;     // floats (= ticket slots) reserved at the head of the workspace
 
+#ifndef MDX_C8_BATCHED_EPI
+#define MDX_C8_BATCHED_EPI 1
+#endif
 constexpr int C8_NT = 512;
 constexpr int C8_HINST = 41;                      // 324 halo rows / 8 rows per DMA instruction, rounded up
 constexpr int C8_HALO_BYTES = C8_HINST * 1024;    // 41 984
@@ -440,6 +443,50 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
     const int mbase = TAPS == 4 ? (pb * 2 * p.H + 2 * py0 + par_dy) * rw + 2 * px0 + par_dx : (pb * p.H + py0) * p.W + px0;
     const int rsy = TAPS == 4 ? 2 * rw : rw;                   // pixel step along y
     constexpr int NPASS = (256 + RPP - 1) / RPP;
+#if MDX_C8_BATCHED_EPI
+    // (round 6) the store loop in BATCHES, as in the lean dense kernel (gemm_epilogue EMODE 1): the residual rows of ALL passes are
+    // requested first, then the staged rows, then the arithmetic, then the stores back to back -- a pass no longer waits for its own
+    // LDS read and residual load one after the other (a block of this core has its CU to itself: nothing else hides them).  Same
+    // operations on the same values: same bits.
+    if (e_act) {
+        f16x8 rv[NPASS], sv[NPASS];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int row = e_r0 + pass * RPP;
+            rv[pass] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (p.residual && row < 256)
+                rv[pass] = *reinterpret_cast<const f16x8*>(p.residual + (size_t)(mbase + (row >> 4) * rsy + (row & 15) * rsx) * p.residual_ld + e_n);
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int row = e_r0 + pass * RPP;
+            sv[pass] = row < 256 ? *reinterpret_cast<const f16x8*>(&stg[row * SLD + e_chunk * 8]) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int row = e_r0 + pass * RPP;
+            if (row < 256) {
+                const int m = mbase + (row >> 4) * rsy + (row & 15) * rsx;
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (float)sv[pass][e] + bb[e];
+                    if (p.residual) f += (float)rv[pass][e];
+                    o[e] = (f16)f;
+                }
+                *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + e_n) = o;
+                if (colstats) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float tv = (float)o[e];    // statistics of the fp16 values actually stored
+                        cs[e] += tv;
+                        cq[e] += tv * tv;
+                    }
+                }
+            }
+        }
+    }
+#else
     if (e_act) {
         f16x8 res_n = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
         if (p.residual && e_r0 < 256)
@@ -472,6 +519,7 @@ __global__ __launch_bounds__(C8_NT) void conv8p_kernel(const GemmParams p) {
             }
         }
     }
+#endif
     if (colstats) {      // (block-uniform) fold the RPP row lanes of every column in a fixed order: deterministic
         __syncthreads();                                  // every thread is done reading the staged tile
         float* part = reinterpret_cast<float*>(smem);     // [RPP][BN][2]
